@@ -1,0 +1,239 @@
+"""CPU ORACLE #2 (test infrastructure, NOT product code) -- independent torch restatement with autograd.
+
+PARITY UNPINNED (see oracle/dmt_oracle.py header): cross-checks the numpy restatement (forward, fp64)
+and supplies gradients (autograd) for the backward parity tests; timed as `cpu_baseline` (kind "port")
+by bench.py.  Written independently of dmt_oracle.py: vectorised over padded [B,T] index tensors instead
+of per-entry loops; the zero-pad table `[0;E]` (base.py:87-89) is realised as an index shift.
+
+Citations relative to /root/reference/DMT_code/.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+PADDING_NUM = float(-2 ** 32 + 1)
+
+
+def _padded(sp, dtype=torch.long):
+    B, T = int(sp.dense_shape[0]), int(sp.dense_shape[1])
+    ind = torch.as_tensor(np.asarray(sp.indices), dtype=torch.long).reshape(-1, 2)
+    val = torch.as_tensor(np.asarray(sp.values)).to(dtype)
+    dense = torch.zeros((B, T), dtype=dtype)
+    valid = torch.zeros((B, T), dtype=torch.bool)
+    if ind.numel():
+        dense[ind[:, 0], ind[:, 1]] = val
+        valid[ind[:, 0], ind[:, 1]] = True
+    return dense, valid
+
+
+def _trans_prefix(i):
+    return "embedding_trans/trans_sequence_%d/encode_decode_sequence_%d/encode_decode_sequence_%d/" % (i, i, i)
+
+
+def _ln(x, g, b, eps=1e-8):
+    mu = x.mean(-1, keepdim=True)
+    var = (x - mu).pow(2).mean(-1, keepdim=True)
+    return g * (x - mu) * torch.rsqrt(var + eps) + b          # TransformerModel_util.py:72-76
+
+
+def _mha(q_in, kv_in, q_len, k_len, H, P, s):
+    """TransformerModel_util.py:160-209 / :11-56 (dropout off).  [B,Tq,d],[B,Tk,d] -> [B,Tq,d]."""
+    B, Tq, d = q_in.shape
+    Tk = kv_in.shape[1]
+    dh = d // H
+    Q = (q_in @ P[s + "dense/kernel"] + P[s + "dense/bias"]).view(B, Tq, H, dh).transpose(1, 2)
+    K = (kv_in @ P[s + "dense_1/kernel"] + P[s + "dense_1/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    V = (kv_in @ P[s + "dense_2/kernel"] + P[s + "dense_2/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    S = (Q @ K.transpose(-1, -2)) / (dh ** 0.5)                                   # [B,H,Tq,Tk]
+    kmask = (torch.arange(Tk)[None, :] < k_len[:, None])[:, None, None, :]
+    S = torch.where(kmask, S, torch.full_like(S, PADDING_NUM))
+    A = torch.softmax(S, dim=-1)
+    qmask = (torch.arange(Tq)[None, :] < q_len[:, None])[:, None, :, None]
+    A = torch.where(qmask, A, torch.full_like(A, PADDING_NUM))                     # post-softmax query mask (F13)
+    O = (A @ V).transpose(1, 2).reshape(B, Tq, d)
+    return _ln(O + q_in, P[s + "ln/gamma"], P[s + "ln/beta"])
+
+
+def _ff(x, P, s):
+    h = torch.relu(x @ P[s + "dense/kernel"] + P[s + "dense/bias"])
+    return _ln(h @ P[s + "dense_1/kernel"] + P[s + "dense_1/bias"] + x, P[s + "ln/gamma"], P[s + "ln/beta"])
+
+
+def _lookup_zero_pad(E, idx):
+    """[0;E][idx]  ==  E[idx-1] for idx>0, zeros for idx==0."""
+    rows = E[(idx - 1).clamp_min(0)]
+    return rows * (idx > 0).unsqueeze(-1).to(E.dtype)
+
+
+def _pool_mean(E, idx, valid, w):
+    rows = E[idx] * (w * valid.to(E.dtype)).unsqueeze(-1)
+    ws = (w * valid.to(E.dtype)).sum(1, keepdim=True)
+    return rows.sum(1) / torch.where(ws == 0, torch.ones_like(ws), ws)
+
+
+def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_intermediates=False):
+    """mmoe_transformer_unbias.py:293-316."""
+    any_p = next(iter(P.values()))
+    dt = any_p.dtype
+    feats_dense = torch.as_tensor(np.asarray(inputs["features"])).to(dt)
+    B = feats_dense.shape[0]
+    d, H = spec["d_model"], spec["num_heads"]
+    table_of = {f: n for (n, _r, _d, f, _s) in spec["embedding_list"]}
+    inter = {}
+
+    # ---- generate_data + trans_core (:130-223)
+    states = []
+    for i, pairs in enumerate(spec["attention_embed_pairs"]):
+        pre = _trans_prefix(i)
+        seq_parts, tar_parts = [], []
+        lens = None
+        for (uf, itf) in pairs:
+            idx, valid = _padded(inputs[uf])
+            lens = valid.sum(1)
+            seq_parts.append(_lookup_zero_pad(P["embedding_trans/%s/embedding" % table_of[uf]], idx))
+            tidx = torch.as_tensor(np.asarray(inputs[itf].values), dtype=torch.long)
+            tar_parts.append(_lookup_zero_pad(P["embedding_trans/%s/embedding" % table_of[itf]], tidx))
+        seq_emb = torch.cat(seq_parts, -1)
+        tar = torch.cat(tar_parts, -1)
+        T = seq_emb.shape[1]
+        x = seq_emb * (d ** 0.5) + P[pre + "positional_encoding_k_position_learn/embedding_position_learn"][:T][None]
+        blk = pre + "num_blocks_0/"
+        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/")
+        mem = _ff(x, P, blk + "positionwise_feedforward/")
+        y = (tar * (d ** 0.5))[:, None, :]
+        y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/")
+        ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
+        y = _ff(y, P, blk + ffs)
+        states.append(y[:, 0, :])
+        inter["seq_emb_%d" % i] = seq_emb
+        inter["tar_emb"] = tar
+        inter["memory_%d" % i] = mem
+    interest = torch.cat(states, -1)
+
+    # ---- embedding_combiner (base.py:93-134)
+    parts = [feats_dense]
+    for (name, _r, _dim, feat, _s) in spec["embedding_list"]:
+        idx, valid = _padded(inputs[feat])
+        wsp = inputs.get(feat + "Wts")
+        w = _padded(wsp, dtype=dt)[0] if wsp is not None else torch.ones(idx.shape, dtype=dt)
+        parts.append(_pool_mean(P["embedding_trans/%s/embedding" % name], idx, valid, w))
+    z = torch.cat(parts + [interest], -1)
+    inter["mmoe_input"] = z
+
+    # ---- expert_gate (:63-105)
+    experts = []
+    for e in range(spec["num_experts"]):
+        h = z
+        for li in range(len(spec["hidden_units_bottom"])):
+            s = "mmoe_layers/expert-%d/expert-layer-%d/" % (e, li)
+            h = torch.relu(h @ P[s + "weights"] + P[s + "biases"])
+        experts.append(h)
+    ex = torch.stack(experts, -1)
+    logits = []
+    for t, nm in enumerate(("click", "order")[: spec["num_tasks"]]):
+        s = "mmoe_layers/gates-%d/gates-layer-0/" % t
+        g = torch.softmax(z @ P[s + "weights"] + P[s + "biases"], -1)
+        inter["gate_%d" % t] = g
+        m = (ex * g[:, None, :]).sum(-1)
+        h = m
+        for li in range(len(spec["hidden_units_task"])):
+            s2 = "%s/%s-fc-%d/" % (nm, nm, li)
+            h = torch.relu(h @ P[s2 + "weights"] + P[s2 + "biases"])
+        s2 = "%s/%s-output/" % (nm, nm)
+        logits.append(h @ P[s2 + "weights"] + P[s2 + "biases"])
+    logits = tuple(logits)
+    if is_predict:
+        return (logits, inter) if return_intermediates else logits
+
+    # ---- bias tower (:235-289)
+    bparts = []
+    for (name, _r, _dim, feat, _s) in spec["embedding_list_bias"]:
+        idx, valid = _padded(inputs[feat])
+        wsp = inputs.get(feat + "Wts")
+        w = _padded(wsp, dtype=dt)[0] if wsp is not None else torch.ones(idx.shape, dtype=dt)
+        bparts.append(_pool_mean(P["%s/embedding" % name], idx, valid, w))
+    yb = torch.cat(bparts, -1)
+    n = len(spec["hidden_units_bias"])
+    for li in range(n):
+        yb = torch.relu(yb @ P["layer_bias%d/kernel" % li] + P["layer_bias%d/bias" % li])
+    yb = yb @ P["layer_bias%d/kernel" % n] + P["layer_bias%d/bias" % n]
+    out = (logits, yb)
+    return (out, inter) if return_intermediates else out
+
+
+def _xent(p, y, eps=1e-7):
+    """inference_mlp.py:162-168 via keras sparse_categorical_crossentropy (clip, log, softmax-CE)."""
+    q = torch.stack([1.0 - p.reshape(-1), p.reshape(-1)], -1).clamp(eps, 1.0 - eps)
+    lg = torch.log(q)
+    return torch.logsumexp(lg, -1) - lg.gather(1, y.reshape(-1, 1).long()).squeeze(1)
+
+
+def loss_unbias(out, mask, spec, loss_unbias_method="two_head_add", loss_ctr_rel_method="ctr_rel"):
+    """inference_mlp.py:173-223."""
+    (c, o), yb = out
+    dt = c.dtype
+    mask = torch.as_tensor(np.asarray(mask)).to(dt)
+    if loss_unbias_method == "two_head_multiply":
+        p_ctr, p_cvr = torch.sigmoid(c) * torch.sigmoid(yb), torch.sigmoid(o) * torch.sigmoid(yb)
+    else:
+        p_ctr, p_cvr = torch.sigmoid(c + yb), torch.sigmoid(o + yb)
+    y_clk = mask[:, 1:5].sum(-1)
+    y_ord = mask[:, 3] + mask[:, 4]
+    x_clk, x_ord = _xent(p_ctr, y_clk), _xent(p_cvr, y_ord)
+    if loss_ctr_rel_method == "ctr_rel":
+        x_clk = x_clk + _xent(torch.sigmoid(c), y_clk)
+        x_ord = x_ord + _xent(torch.sigmoid(o), y_ord)
+    wc = (mask * torch.tensor(spec["weight_ctr"], dtype=dt)).sum(-1)
+    wo = (mask * torch.tensor(spec["weight_ecvr"], dtype=dt)).sum(-1)
+    Bn = mask.shape[0]
+    return spec["loss_weight"][0] * (wc * x_clk).sum() / Bn + spec["loss_weight"][1] * (wo * x_ord).sum() / Bn
+
+
+def to_torch(P_np: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=True):
+    return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in P_np.items()}
+
+
+def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64):
+    P = to_torch(P_np, dtype)
+    out = forward(P, inputs, spec)
+    loss = loss_unbias(out, mask, spec)
+    loss.backward()
+    grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}
+    (c, o), yb = out
+    return float(loss), (c.detach().numpy(), o.detach().numpy(), yb.detach().numpy()), grads
+
+
+class TorchTrainer:
+    """CPU stand-in for the reference train step (run_dnn.py:148-207): forward, loss, dense Adam on every
+    variable with tf.train.AdamOptimizer arithmetic.  Used as bench.py's cpu_baseline (kind 'port')."""
+
+    def __init__(self, P_np, spec, lr=1e-3, dtype=torch.float32, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.spec = spec
+        self.P = to_torch(P_np, dtype)
+        self.m = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.b1p, self.b2p = beta1, beta2
+
+    def step(self, inputs, mask):
+        for p in self.P.values():
+            p.grad = None
+        out = forward(self.P, inputs, self.spec)
+        loss = loss_unbias(out, mask, self.spec)
+        loss.backward()
+        a = self.lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
+        with torch.no_grad():
+            for k, p in self.P.items():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                m, v = self.m[k], self.v[k]
+                m.add_((g - m) * (1.0 - self.b1))
+                v.add_((g * g - v) * (1.0 - self.b2))
+                p.sub_((m * a) / (v.sqrt() + self.eps))
+        self.b1p *= self.b1
+        self.b2p *= self.b2
+        return float(loss), out
