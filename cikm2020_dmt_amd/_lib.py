@@ -1,0 +1,138 @@
+"""ctypes binding of libdmt_hip.so (the C ABI declared in include/dmt_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (see DESIGN.md "Failure behaviour").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdmt_hip.so")
+
+DMT_F32, DMT_BF16 = 0, 1
+DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
+DMT_SEQ_TARGET = 100
+DMT_ERR_UNSUPPORTED = -3
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GatherFeature(C.Structure):
+    _fields_ = [("table", c_vp), ("rows", c_i32), ("dim", c_i32), ("idx", c_vp), ("wts", c_vp), ("lens", c_vp),
+                ("T", c_i32), ("pooled_off", c_i32), ("seq_id", c_i32), ("seq_off", c_i32), ("group", c_i32),
+                ("inv_wsum", c_vp)]
+
+
+class GatherDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("n_features", c_i32), ("feat", GatherFeature * DMT_MAX_FEATURES), ("n_seq", c_i32),
+                ("seq_out", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("pos", c_vp * DMT_MAX_SEQS),
+                ("tar_out", c_vp), ("d_model", c_i32), ("seq_scale", c_f32), ("pooled", c_vp), ("ld_pooled", c_i64),
+                ("dense", c_vp), ("n_dense", c_i32), ("out_dtype", c_i32)]
+
+
+class EmbGradDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("n_features", c_i32), ("feat", GatherFeature * DMT_MAX_FEATURES),
+                ("row_base", c_i32 * DMT_MAX_FEATURES), ("entry_base", c_i32 * (DMT_MAX_FEATURES + 1)),
+                ("total_rows", c_i32), ("dseq", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("dtar", c_vp),
+                ("dpooled", c_vp), ("ld_pooled", c_i64), ("d_model", c_i32), ("seq_scale", c_f32), ("grad_dtype", c_i32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("in_dtype", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+                ("A", c_vp), ("a_rs", c_i64), ("a_cs", c_i64), ("B", c_vp), ("b_rs", c_i64), ("b_cs", c_i64),
+                ("C", c_vp), ("ldc", c_i64), ("bias", c_vp), ("act_ncols", c_i32), ("gate", c_vp), ("ldg", c_i64),
+                ("resid", c_vp), ("ldr", c_i64), ("a_ones_row", c_i32), ("c_last", c_vp), ("split_k", c_i32),
+                ("batch", c_i32), ("a_bs", c_i64), ("b_bs", c_i64), ("c_bs", c_i64), ("bias_bs", c_i64),
+                ("gate_bs", c_i64), ("resid_bs", c_i64), ("clast_bs", c_i64)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("dtype", c_i32), ("B", c_i32), ("H", c_i32), ("dh", c_i32), ("Tq", c_i32), ("Tk", c_i32),
+                ("Q", c_vp), ("q_bs", c_i64), ("q_rs", c_i64), ("K", c_vp), ("k_bs", c_i64), ("k_rs", c_i64),
+                ("V", c_vp), ("v_bs", c_i64), ("v_rs", c_i64), ("q_lens", c_vp), ("k_lens", c_vp),
+                ("resid", c_vp), ("r_bs", c_i64), ("r_rs", c_i64), ("out", c_vp), ("o_bs", c_i64), ("o_rs", c_i64)]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = [("f", AttnDesc), ("dout", c_vp), ("do_bs", c_i64), ("do_rs", c_i64), ("dQ", c_vp), ("dq_bs", c_i64),
+                ("dq_rs", c_i64), ("dK", c_vp), ("dk_bs", c_i64), ("dk_rs", c_i64), ("dV", c_vp), ("dv_bs", c_i64),
+                ("dv_rs", c_i64)]
+
+
+class TableMap(C.Structure):
+    _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
+                ("elem_off", c_i64 * DMT_MAX_TABLES)]
+
+
+_SIGS = {
+    "dmt_gather_fwd": [C.POINTER(GatherDesc), c_vp],
+    "dmt_embgrad_keys": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp],
+    "dmt_sort_pairs": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, C.POINTER(C.c_uint64), c_vp],
+    "dmt_segment_heads": [c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_vp, c_vp, C.POINTER(C.c_uint64), c_vp],
+    "dmt_embgrad_reduce": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
+    "dmt_rows_reduce": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
+    "dmt_gemm": [C.POINTER(GemmDesc), c_vp],
+    "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
+    "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
+    "dmt_ln_fwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp],
+    "dmt_ln_bwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "dmt_mmoe_mix_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "dmt_mmoe_mix_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp],
+    "dmt_relu_bwd": [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "dmt_loss_unbias": [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
+                        c_vp, c_vp, c_vp, c_vp],
+    "dmt_adam_begin_step": [c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_vp],
+    "dmt_adam_end_step": [c_vp, c_f32, c_f32, c_vp],
+    "dmt_adam_dense": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp],
+    "dmt_adam_sparse_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
+                             c_vp, c_f32, c_f32, c_f32, c_vp],
+    "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
+    "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
+    "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
+    "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
+}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials"])
+
+_lib = None
+
+
+def load():
+    """Load libdmt_hip.so; fail loudly when it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libdmt_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cikm2020_dmt_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_i32
+    lib.dmt_last_error.restype = C.c_char_p
+    lib.dmt_last_error.argtypes = []
+    lib.dmt_build_arch.restype = C.c_char_p
+    lib.dmt_version.restype = c_i32
+    lib.dmt_ln_bwd_partials.restype = c_i32
+    lib.dmt_ln_bwd_partials.argtypes = [c_i64]
+    _lib = lib
+    return lib
+
+
+class DmtError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dmt_last_error().decode("utf-8", "replace")
+        raise DmtError("%s failed (%d): %s" % (what or "libdmt_hip call", rc, msg))
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args), name)

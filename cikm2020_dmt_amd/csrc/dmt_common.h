@@ -1,0 +1,57 @@
+// Shared device/host helpers for libdmt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dmt_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+void dmt_set_error(const char* fmt, ...);
+
+#define DMT_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      dmt_set_error(__VA_ARGS__);           \
+      return DMT_ERR_ARG;                   \
+    }                                       \
+  } while (0)
+
+#define DMT_CHECK_LAUNCH(what)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      dmt_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));          \
+      return DMT_ERR_LAUNCH;                                                         \
+    }                                                                                \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

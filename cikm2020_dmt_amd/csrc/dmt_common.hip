@@ -1,0 +1,29 @@
+// Error string + version entry points.
+#include "dmt_common.h"
+
+static thread_local char g_err[512] = "";
+
+void dmt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dmt_last_error(void) { return g_err; }
+extern "C" int dmt_version(void) { return 1; }
+extern "C" const char* dmt_build_arch(void) { return "gfx950"; }
+
+// sizeof() of every ABI struct, so bindings in other languages can verify their layout (tests/test_abi.py).
+extern "C" int dmt_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(dmt_gather_feature);
+    case 1: return (int)sizeof(dmt_gather_desc);
+    case 2: return (int)sizeof(dmt_embgrad_desc);
+    case 3: return (int)sizeof(dmt_gemm_desc);
+    case 4: return (int)sizeof(dmt_attn_desc);
+    case 5: return (int)sizeof(dmt_attn_bwd_desc);
+    case 6: return (int)sizeof(dmt_table_map);
+    default: return -1;
+  }
+}

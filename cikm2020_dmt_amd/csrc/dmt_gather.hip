@@ -1,0 +1,528 @@
+// Embedding gather + concat + mean-pool (forward) and the sparse embedding gradient (backward).
+// HBM-bound byte work: coalesced index reads staged in LDS, 16-byte row-chunk loads, vector stores of
+// the sequence rows; no GEMM reshaping.
+#include "dmt_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+
+namespace {
+
+constexpr int GT = 256;          // threads per workgroup
+constexpr int MAX_GF = 8;        // features per group
+
+struct GFeat {
+  const float* table;
+  int rows, dim;
+  const int32_t* idx;
+  const float* wts;
+  const int32_t* lens;
+  int T;
+  int pooled_off;
+  int seq_off;      // <0: no sequence output
+  float* inv_wsum;
+};
+
+struct GGroup {
+  int B, nfeat;
+  GFeat f[MAX_GF];
+  void* seq_out;    // [B, seq_T, d_model] (or tar_out with seq_T == 1)
+  int seq_T;
+  const float* pos;
+  int d_model;
+  float scale;
+  void* pooled;
+  long long ld;
+  const float* dense;
+  int n_dense;
+  int Tmax;         // LDS staging width
+  int npc;          // pooled chunks per example
+  int CP;           // power-of-two chunk slots per reduction row
+};
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<1> { using type = float; };
+
+template <int VEC> __device__ __forceinline__ void ld_row(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    float4 x = *reinterpret_cast<const float4*>(p);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <typename OutT, int VEC> __device__ __forceinline__ void st_vec(OutT* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    if constexpr (sizeof(OutT) == 4) {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      ushort4 o;
+      o.x = f2bf(v[0]); o.y = f2bf(v[1]); o.z = f2bf(v[2]); o.w = f2bf(v[3]);
+      *reinterpret_cast<ushort4*>(p) = o;
+    }
+  } else {
+    stf<OutT>(p, v[0]);
+  }
+}
+
+// One workgroup per (example, feature group).
+template <typename OutT, int VEC>
+__global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nf = g.nfeat;
+  const int Tmax = g.Tmax;
+  int* s_idx = reinterpret_cast<int*>(smem_raw);                       // [nf][Tmax]
+  float* s_w = reinterpret_cast<float*>(s_idx + nf * Tmax);            // [nf][Tmax]
+  float* s_wsum = s_w + nf * Tmax;                                     // [MAX_GF]
+  int* s_colfeat = reinterpret_cast<int*>(s_wsum + MAX_GF);            // [d_model / VEC]
+  int* s_chunkfeat = s_colfeat + (g.d_model / VEC + 1);                // [npc]
+  int* s_chunkcol = s_chunkfeat + (g.npc + 1);                         // [npc]
+  float* s_red = reinterpret_cast<float*>(s_chunkcol + (g.npc + 1));   // [R][CP][VEC]
+
+  // ---- stage indices and weights (coalesced over t)
+  for (int i = tid; i < nf * Tmax; i += GT) {
+    const int f = i / Tmax, t = i - f * Tmax;
+    const GFeat& F = g.f[f];
+    int len = F.lens ? F.lens[b] : F.T;
+    len = len < F.T ? len : F.T;
+    int id = 0;
+    float w = 0.f;
+    if (t < len) {
+      id = F.idx[(long long)b * F.T + t];
+      id = id < 0 ? 0 : (id >= F.rows ? F.rows - 1 : id);
+      w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
+    }
+    s_idx[i] = id;
+    s_w[i] = w;
+  }
+  // ---- column -> feature maps
+  if (tid < nf) {
+    const GFeat& F = g.f[tid];
+    if (F.seq_off >= 0)
+      for (int c = 0; c < F.dim / VEC; ++c) s_colfeat[F.seq_off / VEC + c] = tid;
+  }
+  if (tid == 0) {
+    int c = 0;
+    for (int f = 0; f < nf; ++f) {
+      if (g.f[f].pooled_off < 0) continue;
+      for (int k = 0; k < g.f[f].dim / VEC; ++k) { s_chunkfeat[c] = f; s_chunkcol[c] = k * VEC; ++c; }
+    }
+  }
+  __syncthreads();
+  if (tid < nf) {
+    float s = 0.f;
+    for (int t = 0; t < Tmax; ++t) s += s_w[tid * Tmax + t];
+    s_wsum[tid] = s;
+    if (g.f[tid].inv_wsum) g.f[tid].inv_wsum[b] = (s != 0.f) ? 1.f / s : 0.f;
+  }
+
+  // ---- sequence rows: out[b,t,:] = scale * [0;E][idx] + pos[t]
+  if (g.seq_out) {
+    OutT* out = reinterpret_cast<OutT*>(g.seq_out) + (long long)b * g.seq_T * g.d_model;
+    const int nch = g.d_model / VEC;
+    const int items = g.seq_T * nch;
+    for (int it = tid; it < items; it += GT) {
+      const int t = it / nch, c = it - t * nch;
+      const int f = s_colfeat[c];
+      const GFeat& F = g.f[f];
+      const int col = c * VEC;
+      const int id = (t < Tmax) ? s_idx[f * Tmax + t] : 0;
+      float v[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[k] = 0.f;
+      if (id > 0) ld_row<VEC>(F.table + (long long)(id - 1) * F.dim + (col - F.seq_off), v);
+      float p[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) p[k] = 0.f;
+      if (g.pos) ld_row<VEC>(g.pos + (long long)t * g.d_model + col, p);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) v[k] = g.scale * v[k] + p[k];
+      st_vec<OutT, VEC>(out + (long long)t * g.d_model + col, v);
+    }
+  }
+
+  // ---- mean-pooled rows: pooled[b, off:off+dim] = sum_t w E[idx] / sum_t w
+  if (g.npc > 0) {
+    OutT* prow = reinterpret_cast<OutT*>(g.pooled) + (long long)b * g.ld;
+    const int CP = g.CP;
+    const int R = GT / CP;            // CP <= GT
+    for (int cbase = 0; cbase < g.npc; cbase += CP) {
+      const int c = cbase + (tid % CP);
+      const int r = tid / CP;
+      float acc[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+      int f = 0;
+      if (c < g.npc && r < R) {
+        f = s_chunkfeat[c];
+        const GFeat& F = g.f[f];
+        const int cc = s_chunkcol[c];
+        const int Tf = F.T < Tmax ? F.T : Tmax;
+        for (int t = r; t < Tf; t += R) {
+          const float w = s_w[f * Tmax + t];
+          if (w != 0.f) {
+            float v[VEC];
+            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + t] * F.dim + cc, v);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += w * v[k];
+          }
+        }
+      }
+      __syncthreads();
+      if (r < R) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) s_red[(r * CP + (tid % CP)) * VEC + k] = acc[k];
+      }
+      __syncthreads();
+      if (r == 0 && c < g.npc) {
+        const GFeat& F = g.f[f];
+        const float ws = s_wsum[f];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          float s = 0.f;
+          for (int rr = 0; rr < R; ++rr) s += s_red[(rr * CP + (tid % CP)) * VEC + k];
+          stf<OutT>(prow + F.pooled_off + s_chunkcol[c] + k, ws != 0.f ? s / ws : 0.f);
+        }
+      }
+    }
+  }
+  // ---- dense 'features' copied in front
+  if (g.dense) {
+    OutT* prow = reinterpret_cast<OutT*>(g.pooled) + (long long)b * g.ld;
+    for (int i = tid; i < g.n_dense; i += GT) stf<OutT>(prow + i, g.dense[(long long)b * g.n_dense + i]);
+  }
+}
+
+template <typename OutT>
+int launch_group(const GGroup& g, bool vec4, hipStream_t st) {
+  const int VECc = vec4 ? 4 : 1;
+  size_t lds = (size_t)g.nfeat * g.Tmax * 8 + MAX_GF * 4 + (g.d_model / VECc + 1) * 4 + (size_t)(g.npc + 1) * 8 +
+               (size_t)GT * VECc * 4 + 64;
+  dim3 grid(g.B), block(GT);
+  if (vec4)
+    hipLaunchKernelGGL((gather_group_kernel<OutT, 4>), grid, block, lds, st, g);
+  else
+    hipLaunchKernelGGL((gather_group_kernel<OutT, 1>), grid, block, lds, st, g);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ backward
+struct KeysArgs {
+  dmt_embgrad_desc d;
+};
+
+__global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_desc d, uint32_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ vals, long long n) {
+  __shared__ int s_base[DMT_MAX_FEATURES + 1];
+  if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
+  __syncthreads();
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  int f = 0;
+  while (f + 1 < d.n_features && e >= s_base[f + 1]) ++f;
+  const dmt_gather_feature& F = d.feat[f];
+  long long r = e - s_base[f];
+  const long long per = (long long)d.B * F.T;
+  int kind = 0;
+  if (F.pooled_off >= 0) {
+    if (r >= per) { kind = 1; r -= per; }
+  } else {
+    kind = 1;
+  }
+  const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
+  int len = F.lens ? F.lens[b] : F.T;
+  uint32_t key = (uint32_t)d.total_rows;
+  if (t < len) {
+    int id = F.idx[(long long)b * F.T + t];
+    id = id < 0 ? 0 : (id >= F.rows ? F.rows - 1 : id);
+    if (kind == 0)
+      key = (uint32_t)(d.row_base[f] + id);
+    else if (id > 0)
+      key = (uint32_t)(d.row_base[f] + id - 1);
+  }
+  keys[e] = key;
+  vals[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t* __restrict__ k, long long n, int* __restrict__ flag) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  flag[e] = (e == 0 || k[e] != k[e - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void finish_heads_kernel(const uint32_t* __restrict__ k, long long n, uint32_t invalid,
+                                                           int* __restrict__ seg, uint32_t* __restrict__ uniq,
+                                                           int* __restrict__ n_uniq) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int s = seg[e] - 1;     // inclusive scan of flags is 1-based
+  seg[e] = s;
+  const bool head = (e == 0 || k[e] != k[e - 1]);
+  if (head) uniq[s] = k[e];
+  if (e == n - 1) n_uniq[0] = (k[e] >= invalid) ? s : s + 1;
+}
+
+// One wavefront per chunk of 64 sorted entries; lane j owns element j of the (<= 64 wide) row.
+template <typename GT_>
+__global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_desc d, const uint32_t* __restrict__ skeys,
+                                                             const uint32_t* __restrict__ svals, const int* __restrict__ seg,
+                                                             long long n, float* __restrict__ grad_rows, int max_dim) {
+  __shared__ int s_base[DMT_MAX_FEATURES + 1];
+  if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long e0 = wave * 64;
+  if (e0 >= n) return;
+  const long long e = e0 + lane;
+  uint32_t my_key = (e < n) ? skeys[e] : (uint32_t)d.total_rows;
+  uint32_t my_val = (e < n) ? svals[e] : 0u;
+  int my_seg = (e < n) ? seg[e] : -1;
+  const int cnt = (int)((n - e0) < 64 ? (n - e0) : 64);
+  float acc = 0.f;
+  int cur_seg = -1, cur_dim = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const uint32_t key = __shfl(my_key, i, 64);
+    if (key >= (uint32_t)d.total_rows) break;      // invalid keys sort last
+    const uint32_t ev = __shfl(my_val, i, 64);
+    const int sg = __shfl(my_seg, i, 64);
+    int f = 0;
+    while (f + 1 < d.n_features && (long long)ev >= s_base[f + 1]) ++f;
+    const dmt_gather_feature& F = d.feat[f];
+    long long r = (long long)ev - s_base[f];
+    const long long per = (long long)d.B * F.T;
+    int kind = 0;
+    if (F.pooled_off >= 0) {
+      if (r >= per) { kind = 1; r -= per; }
+    } else {
+      kind = 1;
+    }
+    const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
+    if (sg != cur_seg) {
+      if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
+      acc = 0.f;
+      cur_seg = sg;
+      cur_dim = F.dim;
+    }
+    if (lane < F.dim) {
+      float gv, sc;
+      if (kind == 0) {
+        const float w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
+        sc = w * F.inv_wsum[b];
+        gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dpooled) + (long long)b * d.ld_pooled + F.pooled_off + lane);
+      } else {
+        sc = d.seq_scale;
+        if (F.seq_id == DMT_SEQ_TARGET)
+          gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + F.seq_off + lane);
+        else
+          gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) +
+                        ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off + lane);
+      }
+      acc += sc * gv;
+    }
+  }
+  if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
+}
+
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                                                          const int* __restrict__ seg, long long n, uint32_t invalid,
+                                                          const float* __restrict__ in_rows, float* __restrict__ out_rows,
+                                                          int max_dim) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long e0 = wave * 64;
+  if (e0 >= n) return;
+  const long long e = e0 + lane;
+  uint32_t my_key = (e < n) ? skeys[e] : invalid;
+  uint32_t my_val = (e < n) ? svals[e] : 0u;
+  int my_seg = (e < n) ? seg[e] : -1;
+  const int cnt = (int)((n - e0) < 64 ? (n - e0) : 64);
+  for (int j0 = 0; j0 < max_dim; j0 += 64) {
+    const int j = j0 + lane;
+    float acc = 0.f;
+    int cur_seg = -1;
+    for (int i = 0; i < cnt; ++i) {
+      const uint32_t key = __shfl(my_key, i, 64);
+      if (key >= invalid) break;
+      const uint32_t ev = __shfl(my_val, i, 64);
+      const int sg = __shfl(my_seg, i, 64);
+      if (sg != cur_seg) {
+        if (cur_seg >= 0 && j < max_dim) atomicAdd(&out_rows[(long long)cur_seg * max_dim + j], acc);
+        acc = 0.f;
+        cur_seg = sg;
+      }
+      if (j < max_dim) acc += in_rows[(long long)ev * max_dim + j];
+    }
+    if (cur_seg >= 0 && j < max_dim) atomicAdd(&out_rows[(long long)cur_seg * max_dim + j], acc);
+  }
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
+  DMT_CHECK_ARG(d != nullptr, "dmt_gather_fwd: null descriptor");
+  DMT_CHECK_ARG(d->B > 0 && d->n_features > 0 && d->n_features <= DMT_MAX_FEATURES, "dmt_gather_fwd: bad B/n_features");
+  DMT_CHECK_ARG(d->out_dtype == DMT_F32 || d->out_dtype == DMT_BF16, "dmt_gather_fwd: bad out_dtype");
+  hipStream_t st = (hipStream_t)stream;
+  // collect group ids in order of first appearance
+  int gids[DMT_MAX_FEATURES];
+  int ng = 0;
+  for (int i = 0; i < d->n_features; ++i) {
+    bool seen = false;
+    for (int k = 0; k < ng; ++k) seen |= (gids[k] == d->feat[i].group);
+    if (!seen) gids[ng++] = d->feat[i].group;
+  }
+  bool dense_done = (d->dense == nullptr);
+  for (int gi = 0; gi < ng; ++gi) {
+    GGroup g;
+    g.B = d->B;
+    g.nfeat = 0;
+    g.seq_out = nullptr;
+    g.seq_T = 0;
+    g.pos = nullptr;
+    g.d_model = d->d_model > 0 ? d->d_model : 4;
+    g.scale = d->seq_scale;
+    g.pooled = d->pooled;
+    g.ld = d->ld_pooled;
+    g.dense = nullptr;
+    g.n_dense = 0;
+    g.Tmax = 1;
+    g.npc = 0;
+    bool vec4 = (g.d_model % 4 == 0);
+    int seq_id = -1;
+    for (int i = 0; i < d->n_features; ++i) {
+      const dmt_gather_feature& F = d->feat[i];
+      if (F.group != gids[gi]) continue;
+      DMT_CHECK_ARG(g.nfeat < MAX_GF, "dmt_gather_fwd: more than %d features in group %d", MAX_GF, F.group);
+      DMT_CHECK_ARG(F.table && F.idx && F.T > 0 && F.dim > 0 && F.rows > 0, "dmt_gather_fwd: feature %d incomplete", i);
+      GFeat& o = g.f[g.nfeat++];
+      o.table = F.table; o.rows = F.rows; o.dim = F.dim; o.idx = F.idx; o.wts = F.wts; o.lens = F.lens; o.T = F.T;
+      o.pooled_off = F.pooled_off;
+      o.seq_off = (F.seq_id >= 0) ? F.seq_off : -1;
+      o.inv_wsum = F.inv_wsum;
+      if (F.seq_id >= 0) {
+        DMT_CHECK_ARG(seq_id < 0 || seq_id == F.seq_id, "dmt_gather_fwd: group %d feeds two sequence outputs", F.group);
+        seq_id = F.seq_id;
+      }
+      if (F.dim % 4 != 0 || (F.seq_id >= 0 && F.seq_off % 4 != 0)) vec4 = false;
+      if (((uintptr_t)F.table) % 16 != 0) vec4 = false;
+      if (F.T > g.Tmax) g.Tmax = F.T;
+      DMT_CHECK_ARG(F.pooled_off < 0 || d->pooled != nullptr, "dmt_gather_fwd: pooled output missing");
+    }
+    if (seq_id == DMT_SEQ_TARGET) {
+      DMT_CHECK_ARG(d->tar_out != nullptr, "dmt_gather_fwd: tar_out missing");
+      g.seq_out = d->tar_out; g.seq_T = 1; g.pos = nullptr;
+    } else if (seq_id >= 0) {
+      DMT_CHECK_ARG(seq_id < d->n_seq && d->seq_out[seq_id] != nullptr, "dmt_gather_fwd: seq_out[%d] missing", seq_id);
+      g.seq_out = d->seq_out[seq_id]; g.seq_T = d->seq_T[seq_id]; g.pos = d->pos[seq_id];
+      if (g.seq_T > g.Tmax) g.Tmax = g.seq_T;
+      if (g.pos && ((uintptr_t)g.pos) % 16 != 0) vec4 = false;
+    }
+    if (g.seq_out) {
+      // every column of the d_model-wide row must be covered by exactly the group's features
+      int covered = 0;
+      for (int k = 0; k < g.nfeat; ++k) if (g.f[k].seq_off >= 0) covered += g.f[k].dim;
+      DMT_CHECK_ARG(covered == g.d_model, "dmt_gather_fwd: group %d covers %d of %d sequence columns", gids[gi], covered, g.d_model);
+      const int esz = d->out_dtype == DMT_F32 ? 4 : 2;
+      if (((uintptr_t)g.seq_out) % (4 * esz) != 0) vec4 = false;
+    }
+    const int V = vec4 ? 4 : 1;
+    for (int k = 0; k < g.nfeat; ++k) if (g.f[k].pooled_off >= 0) g.npc += g.f[k].dim / V;
+    g.CP = 1;
+    while (g.CP < g.npc && g.CP < GT) g.CP <<= 1;
+    if (!dense_done) { g.dense = d->dense; g.n_dense = d->n_dense; dense_done = true; }
+    if (d->out_dtype == DMT_F32) launch_group<float>(g, vec4, st); else launch_group<bf16_t>(g, vec4, st);
+    DMT_CHECK_LAUNCH("dmt_gather_fwd");
+  }
+  return DMT_OK;
+}
+
+extern "C" int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, void* stream) {
+  DMT_CHECK_ARG(d && keys && vals, "dmt_embgrad_keys: null argument");
+  DMT_CHECK_ARG(d->n_features > 0 && d->n_features <= DMT_MAX_FEATURES, "dmt_embgrad_keys: bad n_features");
+  const long long n = d->entry_base[d->n_features];
+  if (n == 0) return DMT_OK;
+  hipLaunchKernelGGL(embgrad_keys_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, *d, keys, vals, n);
+  DMT_CHECK_LAUNCH("dmt_embgrad_keys");
+  return DMT_OK;
+}
+
+extern "C" int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                              int64_t n, int32_t end_bit, void* ws, uint64_t* ws_bytes, void* stream) {
+  DMT_CHECK_ARG(ws_bytes != nullptr, "dmt_sort_pairs: ws_bytes is null");
+  DMT_CHECK_ARG(end_bit > 0 && end_bit <= 32, "dmt_sort_pairs: bad end_bit");
+  size_t need = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                           (unsigned)end_bit, (hipStream_t)stream);
+  if (e != hipSuccess) { dmt_set_error("dmt_sort_pairs: size query failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
+  if (ws == nullptr) { *ws_bytes = need; return DMT_OK; }
+  DMT_CHECK_ARG(*ws_bytes >= need, "dmt_sort_pairs: workspace too small (%llu < %llu)", (unsigned long long)*ws_bytes,
+                (unsigned long long)need);
+  size_t have = (size_t)*ws_bytes;
+  e = rocprim::radix_sort_pairs(ws, have, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) { dmt_set_error("dmt_sort_pairs: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
+  return DMT_OK;
+}
+
+extern "C" int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_key, int32_t* seg_id,
+                                 uint32_t* uniq_keys, int32_t* n_uniq, void* ws, uint64_t* ws_bytes, void* stream) {
+  DMT_CHECK_ARG(ws_bytes != nullptr, "dmt_segment_heads: ws_bytes is null");
+  size_t scan_need = 0;
+  hipError_t e = rocprim::inclusive_scan(nullptr, scan_need, (int*)nullptr, (int*)nullptr, (size_t)n, rocprim::plus<int>(),
+                                         (hipStream_t)stream);
+  if (e != hipSuccess) { dmt_set_error("dmt_segment_heads: size query failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
+  const size_t flags_bytes = (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;
+  const size_t need = flags_bytes + scan_need + 256;
+  if (ws == nullptr) { *ws_bytes = need; return DMT_OK; }
+  DMT_CHECK_ARG(*ws_bytes >= need, "dmt_segment_heads: workspace too small");
+  DMT_CHECK_ARG(sorted_keys && seg_id && uniq_keys && n_uniq && n > 0, "dmt_segment_heads: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  int* flags = reinterpret_cast<int*>(ws);
+  void* scan_ws = reinterpret_cast<unsigned char*>(ws) + flags_bytes;
+  const unsigned nb = (unsigned)cdiv64(n, 256);
+  hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, sorted_keys, (long long)n, flags);
+  e = rocprim::inclusive_scan(scan_ws, scan_need, flags, seg_id, (size_t)n, rocprim::plus<int>(), st);
+  if (e != hipSuccess) { dmt_set_error("dmt_segment_heads: scan failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
+  hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, st, sorted_keys, (long long)n, invalid_key, seg_id, uniq_keys, n_uniq);
+  DMT_CHECK_LAUNCH("dmt_segment_heads");
+  return DMT_OK;
+}
+
+extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
+                                  const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream) {
+  DMT_CHECK_ARG(d && sorted_keys && sorted_vals && seg_id && grad_rows, "dmt_embgrad_reduce: null argument");
+  DMT_CHECK_ARG(max_dim > 0 && max_dim <= 64, "dmt_embgrad_reduce: max_dim must be in [1,64]");
+  for (int f = 0; f < d->n_features; ++f) {
+    DMT_CHECK_ARG(d->feat[f].dim <= max_dim, "dmt_embgrad_reduce: feature %d dim %d > max_dim %d", f, d->feat[f].dim, max_dim);
+    DMT_CHECK_ARG(d->feat[f].pooled_off < 0 || d->feat[f].inv_wsum != nullptr, "dmt_embgrad_reduce: feature %d lacks inv_wsum", f);
+  }
+  if (n == 0) return DMT_OK;
+  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->grad_dtype == DMT_F32)
+    hipLaunchKernelGGL((embgrad_reduce_kernel<float>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                       (long long)n, grad_rows, max_dim);
+  else
+    hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                       (long long)n, grad_rows, max_dim);
+  DMT_CHECK_LAUNCH("dmt_embgrad_reduce");
+  return DMT_OK;
+}
+
+extern "C" int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
+                               uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream) {
+  DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows && out_rows, "dmt_rows_reduce: null argument");
+  if (n == 0) return DMT_OK;
+  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
+  hipLaunchKernelGGL(rows_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
+                     (long long)n, invalid_key, in_rows, out_rows, max_dim);
+  DMT_CHECK_LAUNCH("dmt_rows_reduce");
+  return DMT_OK;
+}

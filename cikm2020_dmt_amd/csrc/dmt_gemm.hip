@@ -1,0 +1,308 @@
+// MFMA GEMM with fused epilogue (bias / relu / relu-gradient gate / residual), batched, split-K.
+//   bf16 operands: v_mfma_f32_32x32x16_bf16      fp32 operands: v_mfma_f32_32x32x2_f32 (exact fma chain)
+// Workgroup = 4 wavefronts (2x2), tile 128x128, each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 fp32 acc VGPRs).
+// Operands are staged global -> registers -> LDS as [row][k] (k contiguous, row stride BK + one 16-byte pad
+// so ds_read_b128 fragment reads are bank-conflict free); the next K tile's global loads are in flight
+// while the current one is multiplied.  Either operand may be k-contiguous (vector LDS writes) or
+// row-contiguous (transposed on the LDS write, lanes along k => conflict-free 2-byte writes), so the same
+// kernel serves Y = X W^T-shadow, dX = dY W and dW = X^T dY (reduction over the strided dim of both).
+#include "dmt_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> { static constexpr int EPV = 8, BK = 32, LDK = 40; };
+template <> struct Cfg<float>  { static constexpr int EPV = 4, BK = 16, LDK = 20; };
+
+struct GemmArgs {
+  int M, N, K;
+  const void* A; long long a_rs, a_cs;
+  const void* B; long long b_rs, b_cs;
+  void* C; long long ldc;
+  const float* bias;
+  int act_ncols;
+  const void* gate; long long ldg;
+  const void* resid; long long ldr;
+  int a_ones_row;
+  float* c_last;
+  int split_k, batch;
+  long long a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs;
+  int a_mode, b_mode;   // 0: k-contiguous vectors, 1: row-contiguous vectors, 2: scalar
+  int k_per_split;
+  int out_f32;
+};
+
+union Vec16 {
+  uint4 u;
+  float f[4];
+  bf16_t h[8];
+};
+
+template <typename T> __device__ __forceinline__ T one_val();
+template <> __device__ __forceinline__ float one_val<float>() { return 1.0f; }
+template <> __device__ __forceinline__ bf16_t one_val<bf16_t>() { return (bf16_t)0x3F80; }
+
+template <typename T> __device__ __forceinline__ void vset(Vec16& v, int i, T x);
+template <> __device__ __forceinline__ void vset<float>(Vec16& v, int i, float x) { v.f[i] = x; }
+template <> __device__ __forceinline__ void vset<bf16_t>(Vec16& v, int i, bf16_t x) { v.h[i] = x; }
+template <typename T> __device__ __forceinline__ T vget(const Vec16& v, int i);
+template <> __device__ __forceinline__ float vget<float>(const Vec16& v, int i) { return v.f[i]; }
+template <> __device__ __forceinline__ bf16_t vget<bf16_t>(const Vec16& v, int i) { return v.h[i]; }
+
+// Load this thread's two 16-byte pieces of a [128 rows] x [BK] operand tile.
+//   elem(r, k) = P[r*rs + k*cs];  rows >= R_real read as 0 (or 1 for the ones row), k >= k_end read as 0.
+template <typename T>
+__device__ __forceinline__ void load_tile(Vec16 (&reg)[2], const T* __restrict__ P, long long rs, long long cs, int mode,
+                                          int row0, int k0, int R_real, int k_end, int ones_row, int tid) {
+  constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int v = tid + p * NT;
+    Vec16 x;
+    x.u = make_uint4(0u, 0u, 0u, 0u);
+    if (mode == 0) {
+      const int r = row0 + v / (BK / EPV);
+      const int k = k0 + (v % (BK / EPV)) * EPV;
+      if (r < R_real) {
+        const T* src = P + (long long)r * rs + k;
+        if (k + EPV <= k_end) {
+          x.u = *reinterpret_cast<const uint4*>(src);
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPV; ++i)
+            if (k + i < k_end) vset<T>(x, i, src[i]);
+        }
+      } else if (r == ones_row) {
+#pragma unroll
+        for (int i = 0; i < EPV; ++i)
+          if (k + i < k_end) vset<T>(x, i, one_val<T>());
+      }
+    } else if (mode == 1) {
+      const int k = k0 + (v % BK);
+      const int r = row0 + (v / BK) * EPV;
+      if (k < k_end) {
+        const T* src = P + (long long)k * cs + r;
+        if (r + EPV <= R_real) {
+          x.u = *reinterpret_cast<const uint4*>(src);
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPV; ++i)
+            if (r + i < R_real) vset<T>(x, i, src[i]);
+        }
+        if (ones_row >= r && ones_row < r + EPV) vset<T>(x, ones_row - r, one_val<T>());
+      }
+    } else {
+      const int r = row0 + v / (BK / EPV);
+      const int k = k0 + (v % (BK / EPV)) * EPV;
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) {
+        if (k + i < k_end) {
+          if (r < R_real) vset<T>(x, i, P[(long long)r * rs + (long long)(k + i) * cs]);
+          else if (r == ones_row) vset<T>(x, i, one_val<T>());
+        }
+      }
+    }
+    reg[p] = x;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)[2], int mode, int tid) {
+  constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int v = tid + p * NT;
+    if (mode == 1) {
+      const int k = v % BK;
+      const int r = (v / BK) * EPV;
+#pragma unroll
+      for (int i = 0; i < EPV; ++i) S[(r + i) * LDK + k] = vget<T>(reg[p], i);
+    } else {
+      const int r = v / (BK / EPV);
+      const int k = (v % (BK / EPV)) * EPV;
+      *reinterpret_cast<uint4*>(S + r * LDK + k) = reg[p].u;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
+  constexpr int BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
+  __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bz = blockIdx.z;
+  const int bt = bz / g.split_k;
+  const int ks = bz - bt * g.split_k;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = ks * g.k_per_split;
+  const int k_end = (k_begin + g.k_per_split < g.K) ? (k_begin + g.k_per_split) : g.K;
+
+  const T* A = reinterpret_cast<const T*>(g.A) + (long long)bt * g.a_bs;
+  const T* Bp = reinterpret_cast<const T*>(g.B) + (long long)bt * g.b_bs;
+  const int M_real = g.a_ones_row ? g.M - 1 : g.M;
+  const int ones_row = g.a_ones_row ? g.M - 1 : -1;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Vec16 ra[2], rb[2];
+  if (k_begin < k_end) {
+    load_tile<T>(ra, A, g.a_rs, g.a_cs, g.a_mode, m0, k_begin, M_real, k_end, ones_row, tid);
+    // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
+    load_tile<T>(rb, Bp, g.b_cs, g.b_rs, g.b_mode, n0, k_begin, g.N, k_end, -1, tid);
+  }
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    store_tile<T>(As, ra, g.a_mode, tid);
+    store_tile<T>(Bs, rb, g.b_mode, tid);
+    __syncthreads();
+    if (k0 + BK < k_end) {
+      load_tile<T>(ra, A, g.a_rs, g.a_cs, g.a_mode, m0, k0 + BK, M_real, k_end, ones_row, tid);
+      load_tile<T>(rb, Bp, g.b_cs, g.b_rs, g.b_mode, n0, k0 + BK, g.N, k_end, -1, tid);
+    }
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        bf16x8_t af[2], bfv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfv[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wn * 64 + j * 32 + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float af[2], bfv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = As[(wm * 64 + i * 32 + (lane & 31)) * LDK + kk + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfv[j] = Bs[(wn * 64 + j * 32 + (lane & 31)) * LDK + kk + (lane >> 5)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (k_begin >= k_end && g.split_k > 1) return;
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const float* bias = g.bias ? g.bias + (long long)bt * g.bias_bs : nullptr;
+  const T* gate = g.gate ? reinterpret_cast<const T*>(g.gate) + (long long)bt * g.gate_bs : nullptr;
+  const bool add_bias = (bias != nullptr) && (ks == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = add_bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float x = acc[i][j][r] + bv;
+        if (col < g.act_ncols) x = fmaxf(x, 0.f);
+        if (gate) {
+          if (!(ldf<T>(gate + (long long)row * g.ldg + col) > 0.f)) x = 0.f;
+        }
+        if (row == ones_row) {
+          float* cl = g.c_last + (long long)bt * g.clast_bs;
+          if (g.split_k > 1) atomicAdd(cl + col, x); else cl[col] = x;
+          continue;
+        }
+        if (g.out_f32) {
+          float* Cp = reinterpret_cast<float*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
+          if (g.resid && ks == 0)
+            x += reinterpret_cast<const float*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col];
+          if (g.split_k > 1) atomicAdd(Cp, x); else *Cp = x;
+        } else {
+          bf16_t* Cp = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
+          if (g.resid)
+            x += bf2f(reinterpret_cast<const bf16_t*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col]);
+          *Cp = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+int pick_mode(const void* P, long long rs, long long cs, int esz, int epv) {
+  const bool aligned = (((uintptr_t)P) % 16 == 0);
+  if (cs == 1 && aligned && (rs % epv == 0)) return 0;
+  if (rs == 1 && aligned && (cs % epv == 0)) return 1;
+  (void)esz;
+  return 2;
+}
+
+}  // namespace
+
+extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
+  DMT_CHECK_ARG(d != nullptr, "dmt_gemm: null descriptor");
+  DMT_CHECK_ARG(d->in_dtype == DMT_F32 || d->in_dtype == DMT_BF16, "dmt_gemm: bad in_dtype");
+  DMT_CHECK_ARG(d->out_dtype == DMT_F32 || d->out_dtype == DMT_BF16, "dmt_gemm: bad out_dtype");
+  DMT_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "dmt_gemm: M, N, K must be positive (%d %d %d)", d->M, d->N, d->K);
+  DMT_CHECK_ARG(d->A && d->B && d->C, "dmt_gemm: null operand");
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  const int batch = d->batch > 1 ? d->batch : 1;
+  DMT_CHECK_ARG(split == 1 || d->out_dtype == DMT_F32, "dmt_gemm: split_k needs an fp32 C");
+  DMT_CHECK_ARG(split == 1 || (d->act_ncols == 0 && d->gate == nullptr), "dmt_gemm: split_k cannot fuse relu / gate");
+  DMT_CHECK_ARG(!d->a_ones_row || d->c_last != nullptr, "dmt_gemm: a_ones_row needs c_last");
+  DMT_CHECK_ARG(!d->a_ones_row || d->M >= 2, "dmt_gemm: a_ones_row needs M >= 2");
+  DMT_CHECK_ARG(d->in_dtype == d->out_dtype || d->out_dtype == DMT_F32, "dmt_gemm: bf16 output needs bf16 operands");
+  GemmArgs g;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.A = d->A; g.a_rs = d->a_rs; g.a_cs = d->a_cs;
+  g.B = d->B; g.b_rs = d->b_rs; g.b_cs = d->b_cs;
+  g.C = d->C; g.ldc = d->ldc;
+  g.bias = d->bias; g.act_ncols = d->act_ncols;
+  g.gate = d->gate; g.ldg = d->ldg; g.resid = d->resid; g.ldr = d->ldr;
+  g.a_ones_row = d->a_ones_row ? 1 : 0; g.c_last = d->c_last;
+  g.split_k = split; g.batch = batch;
+  g.a_bs = d->a_bs; g.b_bs = d->b_bs; g.c_bs = d->c_bs; g.bias_bs = d->bias_bs; g.gate_bs = d->gate_bs;
+  g.resid_bs = d->resid_bs; g.clast_bs = d->clast_bs;
+  g.out_f32 = (d->out_dtype == DMT_F32);
+  const int esz = d->in_dtype == DMT_F32 ? 4 : 2;
+  const int epv = 16 / esz;
+  const int bk = d->in_dtype == DMT_F32 ? 16 : 32;
+  g.a_mode = pick_mode(d->A, d->a_rs, d->a_cs, esz, epv);
+  if (g.a_mode != 2 && batch > 1 && (d->a_bs % epv != 0)) g.a_mode = 2;
+  // B rows in LDS are n: row stride b_cs, k stride b_rs
+  g.b_mode = pick_mode(d->B, d->b_cs, d->b_rs, esz, epv);
+  if (g.b_mode != 2 && batch > 1 && (d->b_bs % epv != 0)) g.b_mode = 2;
+  long long kps = (d->K + split - 1) / split;
+  kps = ((kps + bk - 1) / bk) * bk;
+  g.k_per_split = (int)kps;
+  dim3 grid((unsigned)((d->N + BN - 1) / BN), (unsigned)((d->M + BM - 1) / BM), (unsigned)(batch * split));
+  DMT_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "dmt_gemm: grid too large (M=%d batch*split=%d)", d->M, batch * split);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->in_dtype == DMT_F32)
+    hipLaunchKernelGGL((gemm_kernel<float>), grid, dim3(NT), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<bf16_t>), grid, dim3(NT), 0, st, g);
+  DMT_CHECK_LAUNCH("dmt_gemm");
+  return DMT_OK;
+}

@@ -1,0 +1,163 @@
+// tf.train.AdamOptimizer arithmetic: dense sweep and exact lazy (catch-up) sparse-row update.
+// Both paths go through adam_update() with explicit fmaf so the lazy replay of zero-gradient steps is
+// bit-identical to the dense sweep it replaces (tests/test_gpu_adam.py checks this bitwise).
+#include "dmt_common.h"
+
+namespace {
+
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float a, float c1, float c2, float eps) {
+  m = fmaf(g - m, c1, m);               // m += (g - m) * (1 - beta1)
+  v = fmaf(fmaf(g, g, -v), c2, v);      // v += (g*g - v) * (1 - beta2)
+  p = p - (m * a) / (sqrtf(v) + eps);   // var -= lr_t * m / (sqrt(v) + eps)
+}
+
+__global__ void adam_begin_kernel(float* state, float* lr_hist, int cap, float lr, float b1, float b2) {
+  const float b1p = state[0], b2p = state[1];
+  const float a = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+  int* istate = reinterpret_cast<int*>(state);
+  const int step = istate[3] + 1;
+  state[2] = a;
+  istate[3] = step;
+  if (lr_hist && step < cap) lr_hist[step] = a;
+  (void)b1; (void)b2;
+}
+
+__global__ void adam_end_kernel(float* state, float b1, float b2) {
+  state[0] = state[0] * b1;
+  state[1] = state[1] * b2;
+}
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(long long n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                         const float* __restrict__ g, float gscale, const float* __restrict__ state,
+                                                         float b1, float b2, float eps, bf16_t* __restrict__ lp) {
+  const float a = state[2];
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float pv = p[i], mv = m[i], vv = v[i];
+    adam_update(pv, mv, vv, g[i] * gscale, a, c1, c2, eps);
+    p[i] = pv; m[i] = mv; v[i] = vv;
+    if (lp) lp[i] = f2bf(pv);
+  }
+}
+
+__device__ __forceinline__ void catch_up(float& pv, float& mv, float& vv, int from_step, int to_step, const float* __restrict__ lr_hist,
+                                         float c1, float c2, float eps) {
+  int s = from_step;
+  for (; s <= to_step; ++s) {
+    if (mv == 0.f) break;                       // p no longer moves; only v keeps decaying
+    adam_update(pv, mv, vv, 0.f, lr_hist[s], c1, c2, eps);
+  }
+  for (; s <= to_step; ++s) {
+    if (vv == 0.f) break;
+    vv = fmaf(fmaf(0.f, 0.f, -vv), c2, vv);
+  }
+}
+
+__device__ __forceinline__ int find_table(const dmt_table_map& tm, int row) {
+  int t = 0;
+  while (t + 1 < tm.n_tables && row >= tm.row_base[t + 1]) ++t;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
+                                                          float* __restrict__ v, int* __restrict__ last_step,
+                                                          const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
+                                                          const float* __restrict__ grad_rows, int max_dim, float gscale,
+                                                          const float* __restrict__ state, const float* __restrict__ lr_hist,
+                                                          float b1, float b2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_uniq[0]) return;
+  const int row = (int)uniq[u];
+  const int t = find_table(tm, row);
+  const int dim = tm.dim[t];
+  const int step = reinterpret_cast<const int*>(state)[3];
+  const int last = last_step[row];
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  for (int j = lane; j < dim; j += 64) {
+    const long long off = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim + j;
+    float pv = p[off], mv = m[off], vv = v[off];
+    catch_up(pv, mv, vv, last + 1, step - 1, lr_hist, c1, c2, eps);
+    adam_update(pv, mv, vv, grad_rows[u * max_dim + j] * gscale, state[2], c1, c2, eps);
+    p[off] = pv; m[off] = mv; v[off] = vv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) last_step[row] = step;
+}
+
+__global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, int* __restrict__ last_step,
+                                                         const float* __restrict__ state, const float* __restrict__ lr_hist,
+                                                         float b1, float b2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= tm.row_base[tm.n_tables]) return;
+  const int step = reinterpret_cast<const int*>(state)[3];
+  const int last = last_step[row];
+  if (last >= step) return;
+  const int t = find_table(tm, (int)row);
+  const int dim = tm.dim[t];
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  for (int j = lane; j < dim; j += 64) {
+    const long long off = tm.elem_off[t] + (row - tm.row_base[t]) * dim + j;
+    float pv = p[off], mv = m[off], vv = v[off];
+    if (mv != 0.f || vv != 0.f) {
+      catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
+      p[off] = pv; m[off] = mv; v[off] = vv;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) last_step[row] = step;
+}
+
+}  // namespace
+
+extern "C" int dmt_adam_begin_step(float* state, float* lr_hist, int32_t lr_hist_cap, float lr, float beta1, float beta2,
+                                   void* stream) {
+  DMT_CHECK_ARG(state != nullptr, "dmt_adam_begin_step: null state");
+  hipLaunchKernelGGL(adam_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr_hist, lr_hist_cap, lr, beta1, beta2);
+  DMT_CHECK_LAUNCH("dmt_adam_begin_step");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_end_step(float* state, float beta1, float beta2, void* stream) {
+  DMT_CHECK_ARG(state != nullptr, "dmt_adam_end_step: null state");
+  hipLaunchKernelGGL(adam_end_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+  DMT_CHECK_LAUNCH("dmt_adam_end_step");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, float grad_scale, const float* state,
+                              float beta1, float beta2, float eps, void* lp_bf16, void* stream) {
+  DMT_CHECK_ARG(n > 0 && p && m && v && g && state, "dmt_adam_dense: bad argument");
+  long long nb = cdiv64(n, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)n, p, m, v, g, grad_scale,
+                     state, beta1, beta2, eps, (bf16_t*)lp_bf16);
+  DMT_CHECK_LAUNCH("dmt_adam_dense");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                                    const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* grad_rows,
+                                    int32_t max_dim, float grad_scale, const float* state, const float* lr_hist, float beta1,
+                                    float beta2, float eps, void* stream) {
+  DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && grad_rows && state && lr_hist, "dmt_adam_sparse_rows: null argument");
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_sparse_rows: bad table map / max_uniq");
+  const unsigned nb = (unsigned)cdiv64(max_uniq, 4);
+  hipLaunchKernelGGL(adam_sparse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
+                     grad_rows, max_dim, grad_scale, state, lr_hist, beta1, beta2, eps);
+  DMT_CHECK_LAUNCH("dmt_adam_sparse_rows");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                                   const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
+  DMT_CHECK_ARG(tm && p && m && v && last_step && state && lr_hist, "dmt_adam_flush_rows: null argument");
+  const long long rows = tm->row_base[tm->n_tables];
+  const unsigned nb = (unsigned)cdiv64(rows, 4);
+  hipLaunchKernelGGL(adam_flush_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, state, lr_hist, beta1,
+                     beta2, eps);
+  DMT_CHECK_LAUNCH("dmt_adam_flush_rows");
+  return DMT_OK;
+}

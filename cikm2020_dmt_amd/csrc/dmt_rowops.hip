@@ -1,0 +1,504 @@
+// Row-wise kernels: LayerNorm fwd/bwd, MMoE gate softmax + mixture fwd/bwd, unbias loss fwd+bwd,
+// relu gradient mask, column sums, bf16 shadow casts, AUC confusion histogram.
+#include "dmt_common.h"
+
+#include <type_traits>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// One wavefront per row; lane owns columns lane, lane+64, ...  (coalesced for any alignment / ld).
+template <typename T, int NE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(long long rows, int d, const T* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, T* __restrict__ y, long long ldy, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long long w0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nw = (long long)gridDim.x * 4;
+  float gm[NE], bt[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = (c < d) ? gamma[c] : 0.f;
+    bt[i] = (c < d) ? beta[c] : 0.f;
+  }
+  for (long long r = w0; r < rows; r += nw) {
+    float v[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < d) ? ldf<T>(x + r * ldx + c) : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = lane + 64 * i;
+      const float t = (c < d) ? (v[i] - mean) : 0.f;
+      q += t * t;
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float den = sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) stf<T>(y + r * ldy + c, gm[i] * ((v[i] - mean) / den) + bt[i]);
+    }
+    if (stats && lane == 0) { stats[2 * r] = mean; stats[2 * r + 1] = 1.f / den; }
+  }
+}
+
+template <typename T, int NE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(long long rows, int d, const T* __restrict__ x, long long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                     const T* __restrict__ dy, long long lddy, T* __restrict__ dx, long long lddx,
+                                                     float* __restrict__ partials) {
+  __shared__ float s_part[4][2][NE * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long w0 = (long long)blockIdx.x * 4 + wave;
+  const long long nw = (long long)gridDim.x * 4;
+  float gm[NE], dg[NE], db[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = (c < d) ? gamma[c] : 0.f;
+    dg[i] = 0.f;
+    db[i] = 0.f;
+  }
+  for (long long r = w0; r < rows; r += nw) {
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float xh[NE], g[NE];
+    float a = 0.f, bq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = lane + 64 * i;
+      const float xv = (c < d) ? ldf<T>(x + r * ldx + c) : 0.f;
+      const float dv = (c < d) ? ldf<T>(dy + r * lddy + c) : 0.f;
+      xh[i] = (c < d) ? (xv - mean) * rstd : 0.f;
+      g[i] = dv * gm[i];
+      a += g[i];
+      bq += g[i] * xh[i];
+      dg[i] += dv * xh[i];
+      db[i] += dv;
+    }
+    a = wave_sum(a) / (float)d;
+    bq = wave_sum(bq) / (float)d;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) stf<T>(dx + r * lddx + c, rstd * (g[i] - a - xh[i] * bq));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) { s_part[wave][0][i * 64 + lane] = dg[i]; s_part[wave][1][i * 64 + lane] = db[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * NE * 64; c += 256) {
+    const int which = c / (NE * 64), cc = c % (NE * 64);
+    if (cc < d) {
+      const float s = s_part[0][which][cc] + s_part[1][which][cc] + s_part[2][which][cc] + s_part[3][which][cc];
+      partials[(long long)blockIdx.x * 2 * d + which * d + cc] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(int nblk, int d, const float* __restrict__ partials,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * d) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partials[(long long)b * 2 * d + c];
+  if (c < d) dgamma[c] += s; else dbeta[c - d] += s;
+}
+
+// ------------------------------------------------------------------------------------------ MMoE mix
+template <typename T>
+__global__ __launch_bounds__(128) void mix_fwd_kernel(int B, int E, int U, int nt, const T* __restrict__ expert, long long lde,
+                                                      const T* __restrict__ glogit, long long ldg, float* __restrict__ gates,
+                                                      T* __restrict__ mix) {
+  __shared__ float s_g[64];
+  const int b = blockIdx.x;
+  if (threadIdx.x < nt) {
+    const int t = threadIdx.x;
+    float m = -3.0e38f;
+    for (int e = 0; e < E; ++e) m = fmaxf(m, ldf<T>(glogit + (long long)b * ldg + t * E + e));
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) { const float v = expf(ldf<T>(glogit + (long long)b * ldg + t * E + e) - m); s_g[t * E + e] = v; s += v; }
+    for (int e = 0; e < E; ++e) { const float v = s_g[t * E + e] / s; s_g[t * E + e] = v; gates[((long long)t * B + b) * E + e] = v; }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < U; j += blockDim.x) {
+    for (int t = 0; t < nt; ++t) {
+      float acc = 0.f;
+      for (int e = 0; e < E; ++e) acc = fmaf(s_g[t * E + e], ldf<T>(expert + (long long)b * lde + e * U + j), acc);
+      stf<T>(mix + ((long long)t * B + b) * U + j, acc);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void mix_bwd_kernel(int B, int E, int U, int nt, const T* __restrict__ expert, long long lde,
+                                                      const float* __restrict__ gates, const T* __restrict__ dmix,
+                                                      T* __restrict__ dexpert, long long ldde, T* __restrict__ dglogit, long long lddg,
+                                                      int relu_mask) {
+  __shared__ float s_g[64];
+  __shared__ float s_dg[2][64];
+  const int b = blockIdx.x;
+  const int ng = nt * E;
+  if (threadIdx.x < ng) s_g[threadIdx.x] = gates[((long long)(threadIdx.x / E) * B + b) * E + (threadIdx.x % E)];
+  __syncthreads();
+  float part[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[i] = 0.f;
+  for (int j = threadIdx.x; j < U; j += blockDim.x) {
+    float dm[4];
+    for (int t = 0; t < nt; ++t) dm[t] = ldf<T>(dmix + ((long long)t * B + b) * U + j);
+    for (int e = 0; e < E; ++e) {
+      const float ev = ldf<T>(expert + (long long)b * lde + e * U + j);
+      float de = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        de = fmaf(s_g[t * E + e], dm[t], de);
+        if (t * E + e < 16) part[t * E + e] = fmaf(ev, dm[t], part[t * E + e]);
+      }
+      if (relu_mask && !(ev > 0.f)) de = 0.f;
+      stf<T>(dexpert + (long long)b * ldde + e * U + j, de);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float s = wave_sum(part[i]);
+    if (lane == 0 && i < ng) s_dg[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < nt) {
+    const int t = threadIdx.x;
+    float dot = 0.f;
+    for (int e = 0; e < E; ++e) dot += s_g[t * E + e] * (s_dg[0][t * E + e] + s_dg[1][t * E + e]);
+    for (int e = 0; e < E; ++e) {
+      const float dg = s_dg[0][t * E + e] + s_dg[1][t * E + e];
+      stf<T>(dglogit + (long long)b * lddg + t * E + e, s_g[t * E + e] * (dg - dot));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ loss
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// keras sparse_categorical_crossentropy on [1-p, p] with clipping (inference_mlp.py:162-168):
+//   x = log(q0 + q1) - log(q_y),  q = clip([1-p, p], eps, 1-eps);  returns x and dx/dp
+__device__ __forceinline__ void xent_clip(float p, int y, float& x, float& dxdp) {
+  const float eps = 1e-7f, hi = 1.f - 1e-7f;
+  const float r0 = 1.f - p, r1 = p;
+  const float q0 = fminf(fmaxf(r0, eps), hi), q1 = fminf(fmaxf(r1, eps), hi);
+  const float d0 = (r0 > eps && r0 < hi) ? -1.f : 0.f;   // dq0/dp
+  const float d1 = (r1 > eps && r1 < hi) ? 1.f : 0.f;    // dq1/dp
+  const float qs = q0 + q1;
+  const float qy = y ? q1 : q0;
+  const float dy = y ? d1 : d0;
+  x = logf(qs) - logf(qy);
+  dxdp = (d0 + d1) / qs - dy / qy;
+}
+
+__global__ __launch_bounds__(1024) void loss_unbias_kernel(int B, const float* __restrict__ click, const float* __restrict__ order,
+                                                           const float* __restrict__ ybias, const float* __restrict__ mask5,
+                                                           const float* __restrict__ w_ctr, const float* __restrict__ w_ecvr,
+                                                           float lw_clk, float lw_ord, int method, int ctr_rel, float gscale,
+                                                           float* __restrict__ loss, float* __restrict__ p_ctr_o,
+                                                           float* __restrict__ p_cvr_o, float* __restrict__ d_click,
+                                                           float* __restrict__ d_order, float* __restrict__ d_bias) {
+  __shared__ float s_red[16];
+  float lsum = 0.f;
+  const float invB = 1.f / (float)B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float c = click[b], o = order[b], yb = ybias[b];
+    const float* mk = mask5 + (long long)b * 5;
+    float wc = 0.f, wo = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { wc += mk[k] * w_ctr[k]; wo += mk[k] * w_ecvr[k]; }
+    const int y_clk = (int)(mk[1] + mk[2] + mk[3] + mk[4]);
+    const int y_ord = (int)(mk[3] + mk[4]);
+    float p_ctr, p_cvr, dpc_dc, dpc_db, dpv_do, dpv_db;
+    const float sc = sigmoidf_(c), so = sigmoidf_(o);
+    if (method == 1) {
+      const float sb = sigmoidf_(yb);
+      p_ctr = sc * sb; p_cvr = so * sb;
+      dpc_dc = sc * (1.f - sc) * sb; dpc_db = sc * sb * (1.f - sb);
+      dpv_do = so * (1.f - so) * sb; dpv_db = so * sb * (1.f - sb);
+    } else {
+      p_ctr = sigmoidf_(c + yb); p_cvr = sigmoidf_(o + yb);
+      dpc_dc = dpc_db = p_ctr * (1.f - p_ctr);
+      dpv_do = dpv_db = p_cvr * (1.f - p_cvr);
+    }
+    float x1, g1, x2, g2;
+    xent_clip(p_ctr, y_clk, x1, g1);
+    xent_clip(p_cvr, y_ord, x2, g2);
+    float xc = x1, xo = x2;
+    float dc = g1 * dpc_dc, dbb = wc * lw_clk * g1 * dpc_db + wo * lw_ord * g2 * dpv_db, dd = g2 * dpv_do;
+    if (ctr_rel) {
+      float x3, g3, x4, g4;
+      xent_clip(sc, y_clk, x3, g3);
+      xent_clip(so, y_ord, x4, g4);
+      xc += x3; xo += x4;
+      dc += g3 * sc * (1.f - sc);
+      dd += g4 * so * (1.f - so);
+    }
+    lsum += lw_clk * wc * xc + lw_ord * wo * xo;
+    if (p_ctr_o) p_ctr_o[b] = p_ctr;
+    if (p_cvr_o) p_cvr_o[b] = p_cvr;
+    if (d_click) d_click[b] = gscale * invB * lw_clk * wc * dc;
+    if (d_order) d_order[b] = gscale * invB * lw_ord * wo * dd;
+    if (d_bias) d_bias[b] = gscale * invB * dbb;
+  }
+  lsum = wave_sum(lsum);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += s_red[w];
+    loss[0] = s * invB;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ misc
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(long long rows, long long cols, const T* __restrict__ dy, long long lddy,
+                                                       const T* __restrict__ y, long long ldy, T* __restrict__ dz, long long lddz) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long long r = i / cols, c = i - r * cols;
+  const float g = ldf<T>(dy + r * lddy + c);
+  stf<T>(dz + r * lddz + c, (ldf<T>(y + r * ldy + c) > 0.f) ? g : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(long long rows, long long cols, const T* __restrict__ x, long long ldx,
+                                                     float scale, float* __restrict__ out, int rows_per_block) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  for (long long r = r0; r < r1; ++r) s += ldf<T>(x + r * ldx + c);
+  atomicAdd(out + c, s * scale);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = f2bf(src[i]);
+}
+
+// 32x32 LDS-tiled transpose: dst_plain[r][c] = dst_t[c][r] = bf16(src[r][c])
+__global__ __launch_bounds__(256) void cast_transpose_kernel(int rows, int cols, const float* __restrict__ src, long long ld,
+                                                             bf16_t* __restrict__ dp, long long ldp, bf16_t* __restrict__ dt, long long ldt) {
+  __shared__ bf16_t tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < rows && c < cols) {
+      v = f2bf(src[(long long)r * ld + c]);
+      if (dp) dp[(long long)r * ldp + c] = v;
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  if (dt) {
+    for (int cc = ty; cc < 32; cc += 8) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (r < rows && c < cols) dt[(long long)c * ldt + r] = tile[tx][cc];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void auc_hist_kernel(int B, const float* __restrict__ pred, const float* __restrict__ label, int n_thr,
+                                                       unsigned long long* __restrict__ hist) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float p = pred[b];
+  // thresholds: t_0 = -1e-7, t_i = i/(n_thr-1) (0 < i < n_thr-1), t_last = 1 + 1e-7;  bin = #{i : p > t_i}
+  int lo = 0;
+  if (p > -1e-7f) {
+    lo = 1;
+    const float step = 1.0f / (float)(n_thr - 1);
+    int guess = (int)floorf(p / step);
+    guess = guess < 0 ? 0 : (guess > n_thr - 2 ? n_thr - 2 : guess);
+    // exact comparison against the float32 thresholds around the guess
+    int cnt = 1;
+    for (int i = (guess > 2 ? guess - 2 : 1); i <= n_thr - 2 && i <= guess + 2; ++i) {
+      if (i < 1) continue;
+      const float ti = (float)((double)i / (double)(n_thr - 1));
+      if (p > ti) cnt = i + 1;
+    }
+    lo = cnt;
+    if (p > 1.0f + 1e-7f) lo = n_thr;
+  }
+  const int pos = label[b] > 0.5f ? 1 : 0;
+  atomicAdd(&hist[(long long)pos * (n_thr + 1) + lo], 1ULL);
+}
+
+template <typename T, typename F>
+int ln_dispatch(int d, F&& f) {
+  const int ne = (d + 63) / 64;
+  if (ne <= 2) return f(std::integral_constant<int, 2>());
+  if (ne <= 5) return f(std::integral_constant<int, 5>());
+  if (ne <= 8) return f(std::integral_constant<int, 8>());
+  if (ne <= 16) return f(std::integral_constant<int, 16>());
+  return -1;
+}
+
+}  // namespace
+
+extern "C" int dmt_ln_fwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
+                          const float* beta, float eps, void* y, int64_t ldy, float* stats, void* stream) {
+  DMT_CHECK_ARG(rows > 0 && d > 0 && x && y && gamma && beta, "dmt_ln_fwd: bad argument");
+  DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_ln_fwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  long long nb = cdiv64(rows, 4);
+  if (nb > 4096) nb = 4096;
+  int rc;
+  if (dtype == DMT_F32)
+    rc = ln_dispatch<float>(d, [&](auto ne) {
+      hipLaunchKernelGGL((ln_fwd_kernel<float, decltype(ne)::value>), dim3((unsigned)nb), dim3(256), 0, st, (long long)rows, d,
+                         (const float*)x, (long long)ldx, gamma, beta, eps, (float*)y, (long long)ldy, stats);
+      return 0; });
+  else
+    rc = ln_dispatch<bf16_t>(d, [&](auto ne) {
+      hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, decltype(ne)::value>), dim3((unsigned)nb), dim3(256), 0, st, (long long)rows, d,
+                         (const bf16_t*)x, (long long)ldx, gamma, beta, eps, (bf16_t*)y, (long long)ldy, stats);
+      return 0; });
+  if (rc != 0) { dmt_set_error("dmt_ln_fwd: d=%d > 1024 unsupported", d); return DMT_ERR_UNSUPPORTED; }
+  DMT_CHECK_LAUNCH("dmt_ln_fwd");
+  return DMT_OK;
+}
+
+extern "C" int32_t dmt_ln_bwd_partials(int64_t rows) {
+  long long nb = cdiv64(rows, 4);
+  if (nb > 1024) nb = 1024;
+  return (int32_t)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
+                          const float* stats, const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma,
+                          float* dbeta, float* partials, void* stream) {
+  DMT_CHECK_ARG(rows > 0 && d > 0 && x && gamma && stats && dy && dx && dgamma && dbeta && partials, "dmt_ln_bwd: bad argument");
+  DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_ln_bwd: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = dmt_ln_bwd_partials(rows);
+  int rc;
+  if (dtype == DMT_F32)
+    rc = ln_dispatch<float>(d, [&](auto ne) {
+      hipLaunchKernelGGL((ln_bwd_kernel<float, decltype(ne)::value>), dim3(nb), dim3(256), 0, st, (long long)rows, d, (const float*)x,
+                         (long long)ldx, gamma, stats, (const float*)dy, (long long)lddy, (float*)dx, (long long)lddx, partials);
+      return 0; });
+  else
+    rc = ln_dispatch<bf16_t>(d, [&](auto ne) {
+      hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, decltype(ne)::value>), dim3(nb), dim3(256), 0, st, (long long)rows, d, (const bf16_t*)x,
+                         (long long)ldx, gamma, stats, (const bf16_t*)dy, (long long)lddy, (bf16_t*)dx, (long long)lddx, partials);
+      return 0; });
+  if (rc != 0) { dmt_set_error("dmt_ln_bwd: d=%d > 1024 unsupported", d); return DMT_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
+  DMT_CHECK_LAUNCH("dmt_ln_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_mmoe_mix_fwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_tasks, const void* expert,
+                                int64_t ld_expert, const void* glogit, int64_t ld_glogit, float* gates, void* mix, void* stream) {
+  DMT_CHECK_ARG(B > 0 && E > 0 && U > 0 && n_tasks > 0 && n_tasks <= 4 && n_tasks * E <= 16, "dmt_mmoe_mix_fwd: bad dims (n_tasks*E <= 16)");
+  DMT_CHECK_ARG(expert && glogit && gates && mix, "dmt_mmoe_mix_fwd: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((mix_fwd_kernel<float>), dim3(B), dim3(128), 0, st, B, E, U, n_tasks, (const float*)expert, (long long)ld_expert,
+                       (const float*)glogit, (long long)ld_glogit, gates, (float*)mix);
+  else
+    hipLaunchKernelGGL((mix_fwd_kernel<bf16_t>), dim3(B), dim3(128), 0, st, B, E, U, n_tasks, (const bf16_t*)expert, (long long)ld_expert,
+                       (const bf16_t*)glogit, (long long)ld_glogit, gates, (bf16_t*)mix);
+  DMT_CHECK_LAUNCH("dmt_mmoe_mix_fwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_mmoe_mix_bwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_tasks, const void* expert,
+                                int64_t ld_expert, const float* gates, const void* dmix, void* dexpert, int64_t ld_dexpert,
+                                void* dglogit, int64_t ld_dglogit, int32_t relu_mask, void* stream) {
+  DMT_CHECK_ARG(B > 0 && E > 0 && U > 0 && n_tasks > 0 && n_tasks <= 4 && n_tasks * E <= 16, "dmt_mmoe_mix_bwd: bad dims (n_tasks*E <= 16)");
+  DMT_CHECK_ARG(expert && gates && dmix && dexpert && dglogit, "dmt_mmoe_mix_bwd: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((mix_bwd_kernel<float>), dim3(B), dim3(128), 0, st, B, E, U, n_tasks, (const float*)expert, (long long)ld_expert, gates,
+                       (const float*)dmix, (float*)dexpert, (long long)ld_dexpert, (float*)dglogit, (long long)ld_dglogit, relu_mask);
+  else
+    hipLaunchKernelGGL((mix_bwd_kernel<bf16_t>), dim3(B), dim3(128), 0, st, B, E, U, n_tasks, (const bf16_t*)expert, (long long)ld_expert, gates,
+                       (const bf16_t*)dmix, (bf16_t*)dexpert, (long long)ld_dexpert, (bf16_t*)dglogit, (long long)ld_dglogit, relu_mask);
+  DMT_CHECK_LAUNCH("dmt_mmoe_mix_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_loss_unbias(int32_t B, const float* click, const float* order, const float* ybias, const float* mask5,
+                               const float* w_ctr, const float* w_ecvr, float lw_clk, float lw_ord, int32_t method,
+                               int32_t ctr_rel, float grad_scale, float* loss, float* p_ctr, float* p_cvr, float* d_click,
+                               float* d_order, float* d_bias, void* stream) {
+  DMT_CHECK_ARG(B > 0 && click && order && ybias && mask5 && w_ctr && w_ecvr && loss, "dmt_loss_unbias: null argument");
+  hipLaunchKernelGGL(loss_unbias_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, click, order, ybias, mask5, w_ctr, w_ecvr,
+                     lw_clk, lw_ord, method, ctr_rel, grad_scale, loss, p_ctr, p_cvr, d_click, d_order, d_bias);
+  DMT_CHECK_LAUNCH("dmt_loss_unbias");
+  return DMT_OK;
+}
+
+extern "C" int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const void* dy, int64_t lddy, const void* y, int64_t ldy,
+                            void* dz, int64_t lddz, void* stream) {
+  DMT_CHECK_ARG(rows > 0 && cols > 0 && dy && y && dz, "dmt_relu_bwd: bad argument");
+  const unsigned nb = (unsigned)cdiv64(rows * cols, 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (long long)rows, (long long)cols, (const float*)dy,
+                       (long long)lddy, (const float*)y, (long long)ldy, (float*)dz, (long long)lddz);
+  else
+    hipLaunchKernelGGL((relu_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)dy,
+                       (long long)lddy, (const bf16_t*)y, (long long)ldy, (bf16_t*)dz, (long long)lddz);
+  DMT_CHECK_LAUNCH("dmt_relu_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
+                          void* stream) {
+  DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum: bad argument");
+  const int rpb = 64;
+  dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
+  DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (long long)rows, (long long)cols, (const float*)x, (long long)ldx, scale, out, rpb);
+  else
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)x, (long long)ldx, scale, out, rpb);
+  DMT_CHECK_LAUNCH("dmt_colsum");
+  return DMT_OK;
+}
+
+extern "C" int dmt_cast_bf16(int64_t n, const float* src, void* dst, void* stream) {
+  DMT_CHECK_ARG(n > 0 && src && dst, "dmt_cast_bf16: bad argument");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (long long)n, src, (bf16_t*)dst);
+  DMT_CHECK_LAUNCH("dmt_cast_bf16");
+  return DMT_OK;
+}
+
+extern "C" int dmt_cast_transpose_bf16(int32_t rows, int32_t cols, const float* src, int64_t ld_src, void* dst_plain,
+                                       int64_t ld_plain, void* dst_t, int64_t ld_t, void* stream) {
+  DMT_CHECK_ARG(rows > 0 && cols > 0 && src && (dst_plain || dst_t), "dmt_cast_transpose_bf16: bad argument");
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, src, (long long)ld_src,
+                     (bf16_t*)dst_plain, (long long)ld_plain, (bf16_t*)dst_t, (long long)ld_t);
+  DMT_CHECK_LAUNCH("dmt_cast_transpose_bf16");
+  return DMT_OK;
+}
+
+extern "C" int dmt_auc_hist(int32_t B, const float* pred, const float* label, int32_t n_thr, long long* hist, void* stream) {
+  DMT_CHECK_ARG(B > 0 && pred && label && hist && n_thr >= 3, "dmt_auc_hist: bad argument");
+  hipLaunchKernelGGL(auc_hist_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, pred, label, n_thr,
+                     (unsigned long long*)hist);
+  DMT_CHECK_LAUNCH("dmt_auc_hist");
+  return DMT_OK;
+}

@@ -1,0 +1,407 @@
+"""Execution engine of the DMT hot path on one MI355X: batches in HBM, gather plan, forward graph.
+
+The reference-shaped classes under cikm2020_dmt_amd/model/ are thin facades over this module; every
+compute step is a libdmt_hip.so kernel reached through cikm2020_dmt_amd/ops.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import F32, Weight
+from .spec import mmoe_input_width, trans_prefix
+from .variables import VariableStore
+
+
+# ------------------------------------------------------------------------------------------------ batch
+class FeatureColumn:
+    __slots__ = ("idx", "wts", "lens", "T")
+
+    def __init__(self, idx, wts, lens, T):
+        self.idx, self.wts, self.lens, self.T = idx, wts, lens, T
+
+
+class DeviceBatch:
+    """One batch at the post-vocabulary-lookup boundary, resident in HBM as padded int32 columns."""
+
+    def __init__(self, B, feats: Dict[str, FeatureColumn], dense, mask=None, label=None):
+        self.B, self.feats, self.dense, self.mask, self.label = B, feats, dense, mask, label
+
+    @staticmethod
+    def from_inputs(inputs: dict, spec: dict, device, mask=None, label=None, pad_to: Optional[Dict[str, int]] = None) -> "DeviceBatch":
+        """inputs: {'features': float[B,F], f: SparseTensorValue(int ids), f+'Wts': SparseTensorValue(float)} --
+        what tfrecord_mask.parse_single_line + LookupTables.transform_id2index hand to Inference.inference."""
+        dense = torch.as_tensor(np.ascontiguousarray(inputs["features"], dtype=np.float32)).to(device)
+        B = dense.shape[0]
+        names = [f for (_n, _r, _d, f, _s) in spec["embedding_list"]] + [f for (_n, _r, _d, f, _s) in spec["embedding_list_bias"]]
+        feats = {}
+        for f in names:
+            if f in feats:
+                continue
+            sp = inputs[f]
+            T = sp.dense_shape[1]
+            if pad_to and f in pad_to:
+                T = max(T, pad_to[f])
+            T = max(T, 1)
+            idx_np, lens_np = sp.to_padded(T)
+            wts = None
+            wsp = inputs.get(f + "Wts")
+            if wsp is not None and len(wsp.values) and not np.all(np.asarray(wsp.values) == 1.0):
+                w_np, _ = wsp.to_padded(T)
+                wts = torch.as_tensor(w_np.astype(np.float32)).to(device)
+            feats[f] = FeatureColumn(torch.as_tensor(idx_np.astype(np.int32)).to(device), wts,
+                                     torch.as_tensor(lens_np.astype(np.int32)).to(device), T)
+        m = torch.as_tensor(np.asarray(mask, dtype=np.float32)).to(device) if mask is not None else None
+        lb = torch.as_tensor(np.asarray(label, dtype=np.float32)).to(device) if label is not None else None
+        return DeviceBatch(B, feats, dense, m, lb)
+
+
+# ------------------------------------------------------------------------------------------------ gather
+class _GatherPlan:
+    """Static description of every (table, id column) pair: output offsets, groups, global rows."""
+
+    def __init__(self, spec: dict, store: VariableStore):
+        self.spec = spec
+        d = spec["d_model"]
+        self.items = []          # dicts: feature, table tf_name, dim, rows, pooled_off, seq_id, seq_off, group
+        pooled_off = spec["feature_dimension"]
+        seq_of, off_in_seq = {}, {}
+        for s, pairs in enumerate(spec["attention_embed_pairs"]):
+            col = 0
+            dim_of = {f: dm for (_n, _r, dm, f, _s) in spec["embedding_list"]}
+            for (uf, itf) in pairs:
+                seq_of[uf], off_in_seq[uf] = s, col
+                seq_of[itf], off_in_seq[itf] = L.DMT_SEQ_TARGET, col
+                col += dim_of[uf]
+            if col != d:
+                raise ValueError("sequence %d field widths sum to %d, d_model is %d" % (s, col, d))
+        group_of = {}
+        for s, pairs in enumerate(spec["attention_embed_pairs"]):
+            for (uf, _itf) in pairs:
+                group_of[uf] = 1 + s
+            if spec["attention_embed_seq_ts"]:
+                group_of[spec["attention_embed_seq_ts"][s]] = 1 + s
+        for (name, rows, dim, feat, _side) in spec["embedding_list"]:
+            self.items.append(dict(feature=feat, table="embedding_trans/%s/embedding" % name, dim=dim, rows=rows,
+                                   pooled_off=pooled_off, seq_id=seq_of.get(feat, -1), seq_off=off_in_seq.get(feat, 0),
+                                   group=group_of.get(feat, 0)))
+            pooled_off += dim
+        self.K = mmoe_input_width(spec)
+        self.interest_off = pooled_off
+        assert self.interest_off + len(spec["attention_embed_pairs"]) * d == self.K
+        self.bias_off = (self.K + 3) // 4 * 4
+        boff = self.bias_off
+        for (name, rows, dim, feat, _side) in spec["embedding_list_bias"]:
+            self.items.append(dict(feature=feat, table="%s/embedding" % name, dim=dim, rows=rows, pooled_off=boff, seq_id=-1,
+                                   seq_off=0, group=50))
+            boff += dim
+        self.bias_width = boff - self.bias_off
+        self.ldz = (boff + 7) // 8 * 8
+        self.max_dim = max(it["dim"] for it in self.items)
+        if len(self.items) > L.DMT_MAX_FEATURES:
+            raise ValueError("too many embedding features (%d > %d)" % (len(self.items), L.DMT_MAX_FEATURES))
+        for it in self.items:
+            it["row_base"] = store.table_rows[it["table"]][0]
+
+
+class GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, batch, *pos_leaves):
+        plan, store, spec = engine.plan, engine.store, engine.spec
+        dev, cdt = store.device, store.compute_dtype
+        B, d = batch.B, spec["d_model"]
+        n_seq = len(spec["attention_embed_pairs"])
+        seq_T = []
+        for pairs in spec["attention_embed_pairs"]:
+            seq_T.append(max(batch.feats[uf].T for (uf, _i) in pairs))
+        X = [torch.empty((B, seq_T[s], d), dtype=cdt, device=dev) for s in range(n_seq)]
+        tar = torch.empty((B, d), dtype=cdt, device=dev)
+        zbuf = torch.zeros((B, plan.ldz), dtype=cdt, device=dev)
+        desc = L.GatherDesc()
+        desc.B, desc.n_features = B, len(plan.items)
+        inv = torch.empty((len(plan.items), B), dtype=F32, device=dev)
+        for i, it in enumerate(plan.items):
+            col = batch.feats[it["feature"]]
+            f = desc.feat[i]
+            f.table = store.table[it["table"]].data_ptr()
+            f.rows, f.dim = it["rows"], it["dim"]
+            f.idx = col.idx.data_ptr()
+            f.wts = col.wts.data_ptr() if col.wts is not None else None
+            f.lens = col.lens.data_ptr()
+            f.T = col.T
+            f.pooled_off, f.seq_id, f.seq_off, f.group = it["pooled_off"], it["seq_id"], it["seq_off"], it["group"]
+            f.inv_wsum = inv[i].data_ptr()
+        desc.n_seq = n_seq
+        for s in range(n_seq):
+            desc.seq_out[s] = X[s].data_ptr()
+            desc.seq_T[s] = seq_T[s]
+            desc.pos[s] = pos_leaves[s].data_ptr()
+            if seq_T[s] > pos_leaves[s].shape[0]:
+                raise ValueError("sequence %d length %d exceeds the learned position table (%d rows)" % (s, seq_T[s], pos_leaves[s].shape[0]))
+        desc.tar_out = tar.data_ptr()
+        desc.d_model = d
+        desc.seq_scale = float(d) ** 0.5
+        desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
+        desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
+        desc.out_dtype = ops.dt_code(cdt)
+        L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
+        ctx.engine, ctx.batch, ctx.inv, ctx.seq_T = engine, batch, inv, seq_T
+        ctx.pos_shapes = [tuple(pl.shape) for pl in pos_leaves]
+        return (*X, tar, zbuf)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        engine, batch = ctx.engine, ctx.batch
+        spec = engine.spec
+        n_seq = len(spec["attention_embed_pairs"])
+        dX = [g.contiguous() if g is not None else None for g in grads[:n_seq]]
+        dtar, dz = grads[n_seq], grads[n_seq + 1]
+        B, d = batch.B, spec["d_model"]
+        dev, cdt = engine.store.device, engine.store.compute_dtype
+        for s in range(n_seq):
+            if dX[s] is None:
+                dX[s] = torch.zeros((B, ctx.seq_T[s], d), dtype=cdt, device=dev)
+        dtar = dtar.contiguous() if dtar is not None else torch.zeros((B, d), dtype=cdt, device=dev)
+        dz = dz.contiguous() if dz is not None else torch.zeros((B, engine.plan.ldz), dtype=cdt, device=dev)
+        # learned positions: dP[t] = sum_b dX[b, t]   (lookup by range(T), TransformerModel_util.py:296-306)
+        dpos = []
+        for s in range(n_seq):
+            g = torch.zeros(ctx.pos_shapes[s], dtype=F32, device=dev)
+            ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
+            dpos.append(g)
+        engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz)
+        return (None, None, *dpos)
+
+
+class AssembleFn(torch.autograd.Function):
+    """z[:, off_s : off_s + d] = u_s  -- the tf.concat([features, interest_state]) of embedding_trans
+    (mmoe_transformer_unbias.py:226-233), done in place on the gather output."""
+
+    @staticmethod
+    def forward(ctx, zbuf, off, d, *us):
+        for s, u in enumerate(us):
+            zbuf[:, off + s * d: off + (s + 1) * d].copy_(u)
+        ctx.mark_dirty(zbuf)
+        ctx.off, ctx.d, ctx.n = off, d, len(us)
+        return zbuf
+
+    @staticmethod
+    def backward(ctx, dz):
+        off, d = ctx.off, ctx.d
+        return (dz, None, None, *[dz[:, off + s * d: off + (s + 1) * d] for s in range(ctx.n)])
+
+
+# ------------------------------------------------------------------------------------------------ engine
+class DMTEngine:
+    def __init__(self, spec: dict, store: VariableStore):
+        self.spec, self.store = spec, store
+        self.plan = _GatherPlan(spec, store)
+        self.sparse = None           # (uniq_keys, n_uniq, grad_rows) of the last backward
+        self._ws = {}
+        dev = store.device
+        self.w_ctr = torch.tensor(spec["weight_ctr"], dtype=F32, device=dev)
+        self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
+        self.intermediates = {}
+
+    # ---- small helpers
+    def _w(self, name) -> Weight:
+        return self.store.weight[name]
+
+    def _lf(self, name):
+        return self.store.leaf[name]
+
+    @staticmethod
+    def _wslice(w: Weight, a, b) -> Weight:
+        return Weight(w.f32[:, a:b], w.lp[:, a:b] if w.lp is not None else None, w.lp_t[a:b, :] if w.lp_t is not None else None)
+
+    # ---- stages
+    def gather(self, batch: DeviceBatch):
+        pos = [self._lf(trans_prefix(i) + "positional_encoding_k_position_learn/embedding_position_learn")
+               for i in range(len(self.spec["attention_embed_pairs"]))]
+        outs = GatherFn.apply(self, batch, *pos)
+        n = len(pos)
+        return list(outs[:n]), outs[n], outs[n + 1]
+
+    def mha_self(self, x, lens, blk):
+        """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
+        d, H = self.spec["d_model"], self.spec["num_heads"]
+        a = blk + "self-attention/"
+        qkv = ops.linear(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"))
+        s1 = ops.AttnFn.apply(qkv, None, x, lens, lens, H, d, True)
+        return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
+
+    def mha_cross(self, q_in, mem, q_lens, k_lens, blk):
+        """multihead_attention(q, mem, mem, q_lens, k_lens) with scope 'vanilla_attention'."""
+        d, H = self.spec["d_model"], self.spec["num_heads"]
+        a = blk + "vanilla_attention/"
+        wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
+        q = ops.linear(q_in, wl[:, :d], bl[:d], self._wslice(w, 0, d))
+        kv = ops.linear(mem, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d))
+        s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False)
+        return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
+
+    def ff(self, x, ffs):
+        """ff(inputs, [d_ff, d_model]) (TransformerModel_util.py:212-235)."""
+        s = ops.FFNFn.apply(x, self._lf(ffs + "dense/kernel"), self._lf(ffs + "dense/bias"), self._lf(ffs + "dense_1/kernel"),
+                            self._lf(ffs + "dense_1/bias"), self._w(ffs + "dense/kernel"), self._w(ffs + "dense_1/kernel"))
+        return ops.layer_norm(s, self._lf(ffs + "ln/gamma"), self._lf(ffs + "ln/beta"))
+
+    def encode_prepared(self, x, lens, i):
+        """TransformerModel.encode after the input prep (x = sqrt(d)*seq_emb + P, fused into the gather)."""
+        blk = trans_prefix(i) + "num_blocks_0/"
+        x = self.mha_self(x, lens, blk)
+        return self.ff(x, blk + "positionwise_feedforward/")
+
+    def decode_prepared(self, y, mem, lens, i):
+        """TransformerModel.decode after the input prep (y = sqrt(d)*tar[:,None,:])."""
+        blk = trans_prefix(i) + "num_blocks_0/"
+        y = self.mha_cross(y, mem, None, lens, blk)
+        ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
+        return self.ff(y, blk + ffs)
+
+    def embedding_trans(self, batch: DeviceBatch):
+        X, tar, zbuf = self.gather(batch)
+        us = []
+        for i, pairs in enumerate(self.spec["attention_embed_pairs"]):
+            lens = batch.feats[pairs[-1][0]].lens          # mask / lens come from the LAST pair (mmoe_transformer.py:137-142)
+            mem = self.encode_prepared(X[i], lens, i)
+            y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
+            us.append(y.squeeze(1))
+            self.intermediates["memory_%d" % i] = mem
+        z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *us)
+        self.intermediates["zbuf"] = z
+        return z
+
+    def expert_gate(self, z):
+        sp = self.spec
+        E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
+        K = self.plan.K
+        g1 = ops.linear(z[:, :K], self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
+                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0])
+        outs = []
+        for e in range(E):
+            h = g1[:, e * units[0]:(e + 1) * units[0]]
+            for li in range(1, len(units)):
+                nm = "mmoe_layers/expert-%d/expert-layer-%d/" % (e, li)
+                h = ops.linear(h, self._lf(nm + "weights"), self._lf(nm + "biases"), self._w(nm + "weights"), relu=True)
+            outs.append(h)
+        expert = torch.cat(outs, dim=1)
+        glogit = g1[:, E * units[0]: E * units[0] + T * E]
+        mix, gates = ops.MixFn.apply(expert, glogit, E, units[-1], T)
+        self.intermediates["gates"] = gates
+        return [mix[t] for t in range(T)]
+
+    def build_tower(self, x, name):
+        sp = self.spec
+        h = x
+        for li in range(len(sp["hidden_units_task"])):
+            nm = "%s/%s-fc-%d/" % (name, name, li)
+            h = ops.linear(h, self._lf(nm + "weights"), self._lf(nm + "biases"), self._w(nm + "weights"), relu=True)
+        nm = "%s/%s-output/" % (name, name)
+        return ops.linear(h, self._lf(nm + "weights"), self._lf(nm + "biases"), self._w(nm + "weights"), out_dtype=F32)
+
+    def embedding_mlp_bias(self, z):
+        sp = self.spec
+        h = z[:, self.plan.bias_off: self.plan.bias_off + self.plan.bias_width]
+        n = len(sp["hidden_units_bias"])
+        for li in range(n):
+            nm = "layer_bias%d/" % li
+            h = ops.linear(h, self._lf(nm + "kernel"), self._lf(nm + "bias"), self._w(nm + "kernel"), relu=True)
+        nm = "layer_bias%d/" % n
+        return ops.linear(h, self._lf(nm + "kernel"), self._lf(nm + "bias"), self._w(nm + "kernel"), out_dtype=F32)
+
+    def inference(self, batch: DeviceBatch, is_predict=False):
+        z = self.embedding_trans(batch)
+        tasks = self.expert_gate(z)
+        logits = tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
+        if is_predict:
+            return logits
+        return logits, self.embedding_mlp_bias(z)
+
+    def loss_unbias(self, out, mask, method=None, ctr_rel=None):
+        (c, o), yb = out
+        sp = self.spec
+        method = sp["loss_unbias_method"] if method is None else method
+        ctr_rel = sp["loss_ctr_rel_method"] if ctr_rel is None else ctr_rel
+        loss, pc, pv = ops.LossUnbiasFn.apply(c, o, yb, mask, self.w_ctr, self.w_ecvr, sp["loss_weight"],
+                                              1 if method == "two_head_multiply" else 0, 1 if ctr_rel == "ctr_rel" else 0)
+        return loss, pc, pv
+
+    # ---- sparse embedding gradient
+    def _buf(self, key, shape, dtype):
+        t = self._ws.get(key)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(n, dtype=dtype, device=self.store.device)
+            self._ws[key] = t
+        return t[:n].view(shape)
+
+    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz):
+        plan, store, spec = self.plan, self.store, self.spec
+        desc = L.EmbGradDesc()
+        desc.B, desc.n_features = batch.B, len(plan.items)
+        ebase = 0
+        for i, it in enumerate(plan.items):
+            col = batch.feats[it["feature"]]
+            f = desc.feat[i]
+            f.rows, f.dim = it["rows"], it["dim"]
+            f.idx = col.idx.data_ptr()
+            f.wts = col.wts.data_ptr() if col.wts is not None else None
+            f.lens = col.lens.data_ptr()
+            f.T = col.T
+            f.pooled_off, f.seq_id, f.seq_off, f.group = it["pooled_off"], it["seq_id"], it["seq_off"], it["group"]
+            f.inv_wsum = inv[i].data_ptr()
+            desc.row_base[i] = it["row_base"]
+            desc.entry_base[i] = ebase
+            kinds = (1 if it["pooled_off"] >= 0 else 0) + (1 if it["seq_id"] >= 0 else 0)
+            ebase += kinds * batch.B * col.T
+        desc.entry_base[len(plan.items)] = ebase
+        desc.total_rows = store.total_rows
+        for s in range(len(dX)):
+            desc.dseq[s] = dX[s].data_ptr()
+            desc.seq_T[s] = seq_T[s]
+        desc.dtar = dtar.data_ptr()
+        desc.dpooled, desc.ld_pooled = dz.data_ptr(), dz.stride(0)
+        desc.d_model = spec["d_model"]
+        desc.seq_scale = float(spec["d_model"]) ** 0.5
+        desc.grad_dtype = ops.dt_code(dz.dtype)
+        n = ebase
+        st = ops.stream_ptr()
+        keys = self._buf("keys", (n,), torch.int32)
+        vals = self._buf("vals", (n,), torch.int32)
+        keys_s = self._buf("keys_s", (n,), torch.int32)
+        vals_s = self._buf("vals_s", (n,), torch.int32)
+        L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), ops.p(vals), st)
+        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n)
+        # at most min(n, total_rows) distinct rows
+        cap = min(n, store.total_rows)
+        grad_rows = self._buf("grad_rows", (cap, plan.max_dim), F32)
+        grad_rows.zero_()
+        L.call("dmt_embgrad_reduce", C.byref(desc), ops.p(keys_s), ops.p(vals_s), ops.p(seg), n, ops.p(grad_rows), plan.max_dim, st)
+        self.sparse = (uniq, n_uniq, grad_rows, cap)
+
+    def sort_segments(self, keys, vals, keys_s, vals_s, n):
+        """Stable sort of (row, entry) pairs + segment ids of equal rows."""
+        store = self.store
+        st = ops.stream_ptr()
+        end_bit = max(1, int(store.total_rows).bit_length())
+        need = C.c_uint64(0)
+        L.call("dmt_sort_pairs", ops.p(keys), ops.p(keys_s), ops.p(vals), ops.p(vals_s), n, end_bit, None, C.byref(need), st)
+        ws = self._buf("sort_ws", (max(int(need.value), 16),), torch.uint8)
+        have = C.c_uint64(ws.numel())
+        L.call("dmt_sort_pairs", ops.p(keys), ops.p(keys_s), ops.p(vals), ops.p(vals_s), n, end_bit, ops.p(ws), C.byref(have), st)
+        seg = self._buf("seg", (n,), torch.int32)
+        uniq = self._buf("uniq", (n,), torch.int32)
+        n_uniq = self._buf("n_uniq", (1,), torch.int32)
+        need2 = C.c_uint64(0)
+        L.call("dmt_segment_heads", ops.p(keys_s), n, store.total_rows, ops.p(seg), ops.p(uniq), ops.p(n_uniq), None, C.byref(need2), st)
+        ws2 = self._buf("heads_ws", (max(int(need2.value), 16),), torch.uint8)
+        have2 = C.c_uint64(ws2.numel())
+        L.call("dmt_segment_heads", ops.p(keys_s), n, store.total_rows, ops.p(seg), ops.p(uniq), ops.p(n_uniq), ops.p(ws2), C.byref(have2), st)
+        return uniq, n_uniq, seg

@@ -1,0 +1,382 @@
+"""Thin PyTorch plumbing over the C ABI: tensor -> (pointer, stride) marshalling and autograd Functions.
+
+Every compute step is a libdmt_hip.so kernel; torch supplies device memory, the current HIP stream and
+the autograd tape only.  Nothing here falls back to torch math: a missing library or a failed launch
+raises (cikm2020_dmt_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt_code(t: torch.dtype) -> int:
+    if t == F32:
+        return L.DMT_F32
+    if t == BF16:
+        return L.DMT_BF16
+    raise TypeError("unsupported dtype %s" % t)
+
+
+def p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _row_major2d(t: torch.Tensor, what: str):
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("%s must be a 2-D view with unit inner stride, got shape %s strides %s" % (what, tuple(t.shape), t.stride()))
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libdmt_hip kernels need device tensors (got a %s tensor); there is no CPU path" % t.device)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_ncols=0, gate=None, ldg=0, resid=None,
+         ldr=0, ones_row=False, c_last=None, split_k=1, batch=1, a_bs=0, b_bs=0, c_bs=0, bias_bs=0, gate_bs=0,
+         resid_bs=0, clast_bs=0):
+    require_cuda(A, Bm, out)
+    d = L.GemmDesc()
+    d.in_dtype = dt_code(A.dtype)
+    if Bm.dtype != A.dtype:
+        raise TypeError("gemm operands differ in dtype: %s vs %s" % (A.dtype, Bm.dtype))
+    d.out_dtype = dt_code(out.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_rs, d.a_cs = A.data_ptr(), a_rs, a_cs
+    d.B, d.b_rs, d.b_cs = Bm.data_ptr(), b_rs, b_cs
+    d.C, d.ldc = out.data_ptr(), ldc
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act_ncols = act_ncols
+    d.gate, d.ldg = (gate.data_ptr(), ldg) if gate is not None else (None, 0)
+    d.resid, d.ldr = (resid.data_ptr(), ldr) if resid is not None else (None, 0)
+    d.a_ones_row = 1 if ones_row else 0
+    d.c_last = c_last.data_ptr() if c_last is not None else None
+    d.split_k, d.batch = split_k, batch
+    d.a_bs, d.b_bs, d.c_bs, d.bias_bs, d.gate_bs, d.resid_bs, d.clast_bs = a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs
+    L.call("dmt_gemm", C.byref(d), stream_ptr())
+
+
+def _pick_split(tiles: int, red: int) -> int:
+    s = max(1, min(1024 // max(tiles, 1), red // 512))
+    return int(max(1, min(s, 512)))
+
+
+class Weight:
+    """A 2-D dense weight as the kernels see it: fp32 master view + (bf16 mode) plain and transposed shadows."""
+    __slots__ = ("f32", "lp", "lp_t")
+
+    def __init__(self, f32, lp=None, lp_t=None):
+        self.f32, self.lp, self.lp_t = f32, lp, lp_t
+
+
+def linear_forward(x, w: Weight, bias, act_ncols=0, resid=None, out=None, out_dtype=None):
+    """y[M,N] = epi(x[M,K] @ W[K,N]).  x: 2-D row-major view (any row stride)."""
+    M, K = x.shape
+    N = w.f32.shape[1]
+    ldx = _row_major2d(x, "x")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
+    ldc = _row_major2d(out, "out")
+    ldr = _row_major2d(resid, "resid") if resid is not None else 0
+    if x.dtype == BF16:
+        wt = w.lp_t                                  # [N, K], k contiguous
+        gemm(x, ldx, 1, wt, 1, wt.stride(0), M, N, K, out, ldc, bias=bias, act_ncols=act_ncols, resid=resid, ldr=ldr)
+    else:
+        wf = w.f32
+        gemm(x, ldx, 1, wf, wf.stride(0), 1, M, N, K, out, ldc, bias=bias, act_ncols=act_ncols, resid=resid, ldr=ldr)
+    return out
+
+
+def linear_backward_input(dz, w: Weight, gate=None, resid=None, out=None):
+    """dx[M,K] = (dz[M,N] @ W^T) * (gate > 0) + resid."""
+    M, N = dz.shape
+    K = w.f32.shape[0]
+    ldz = _row_major2d(dz, "dz")
+    if out is None:
+        out = torch.empty((M, K), dtype=dz.dtype, device=dz.device)
+    ldc = _row_major2d(out, "out")
+    wm = w.lp if dz.dtype == BF16 else w.f32          # [K, N]: B(k=n, n'=k') = W[k'*ld + n]
+    gemm(dz, ldz, 1, wm, 1, wm.stride(0), M, K, N, out, ldc,
+         gate=gate, ldg=_row_major2d(gate, "gate") if gate is not None else 0,
+         resid=resid, ldr=_row_major2d(resid, "resid") if resid is not None else 0)
+    return out
+
+
+def linear_backward_weight(x, dz, want_bias=True):
+    """dW[K,N] = x^T dz, db[N] = colsum(dz) (ones row), fp32, split over the (long) row dimension."""
+    M, K = x.shape
+    N = dz.shape[1]
+    ldx, ldz = _row_major2d(x, "x"), _row_major2d(dz, "dz")
+    dW = torch.zeros((K, N), dtype=F32, device=x.device)
+    db = torch.zeros((N,), dtype=F32, device=x.device) if want_bias else None
+    rows = K + 1 if want_bias else K
+    tiles = ((rows + 127) // 128) * ((N + 127) // 128)
+    split = _pick_split(tiles, M)
+    gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, dW, N, ones_row=want_bias, c_last=db, split_k=split)
+    return dW, db
+
+
+def relu_bwd_(dy, y, ncols=None):
+    """In place: dy[:, :ncols] *= (y[:, :ncols] > 0)."""
+    rows, cols = dy.shape
+    cols = cols if ncols is None else ncols
+    L.call("dmt_relu_bwd", dt_code(dy.dtype), rows, cols, p(dy), _row_major2d(dy, "dy"), p(y), _row_major2d(y, "y"),
+           p(dy), _row_major2d(dy, "dy"), stream_ptr())
+    return dy
+
+
+class LinearFn(torch.autograd.Function):
+    """y = relu?(x W + b) (+ resid), the op behind base.dense_layer / tf.layers.dense call sites."""
+
+    @staticmethod
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, act_ncols, out_dtype):
+        x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+        y = linear_forward(x2, w, b_leaf, act_ncols=act_ncols, out_dtype=out_dtype)
+        ctx.w = w
+        ctx.act_ncols = act_ncols
+        ctx.xshape = x.shape
+        ctx.has_bias = b_leaf is not None
+        ctx.save_for_backward(x2, y if act_ncols > 0 else None)
+        return y.reshape(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y = ctx.saved_tensors
+        dz = dy.reshape(-1, dy.shape[-1])
+        if dz.dtype != x2.dtype:
+            dz = dz.to(x2.dtype)
+        if ctx.act_ncols > 0:
+            dz = relu_bwd_(dz.clone() if dz.data_ptr() == dy.data_ptr() else dz, y.to(dz.dtype) if y.dtype != dz.dtype else y,
+                           ctx.act_ncols)
+        elif dz.stride(-1) != 1:
+            dz = dz.contiguous()
+        dx = linear_backward_input(dz, ctx.w) if ctx.needs_input_grad[0] else None
+        dW, db = linear_backward_weight(x2, dz, want_bias=ctx.has_bias)
+        if dx is not None:
+            dx = dx.reshape(ctx.xshape)
+        return dx, dW, db, None, None, None
+
+
+def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=None):
+    n = w.f32.shape[1]
+    a = (n if relu else 0) if act_ncols is None else act_ncols
+    return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype)
+
+
+class FFNFn(torch.autograd.Function):
+    """s = relu(x W1 + b1) W2 + b2 + x  (TransformerModel_util.py:222-230 before the LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, w1_leaf, b1_leaf, w2_leaf, b2_leaf, w1: Weight, w2: Weight):
+        x2 = x.reshape(-1, x.shape[-1])
+        h = linear_forward(x2, w1, b1_leaf, act_ncols=w1.f32.shape[1])
+        s = linear_forward(h, w2, b2_leaf, resid=x2)
+        ctx.w1, ctx.w2 = w1, w2
+        ctx.save_for_backward(x2, h)
+        ctx.xshape = x.shape
+        return s.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, ds):
+        x2, h = ctx.saved_tensors
+        ds2 = ds.reshape(-1, ds.shape[-1])
+        if ds2.stride(-1) != 1:
+            ds2 = ds2.contiguous()
+        dh = linear_backward_input(ds2, ctx.w2, gate=h)          # (ds W2^T) * (h > 0)
+        dW2, db2 = linear_backward_weight(h, ds2)
+        dx = linear_backward_input(dh, ctx.w1, resid=ds2)        # dh W1^T + ds (residual branch)
+        dW1, db1 = linear_backward_weight(x2, dh)
+        return dx.reshape(ctx.xshape), dW1, db1, dW2, db2, None, None
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out):
+    d = L.AttnDesc()
+    d.dtype, d.B, d.H, d.dh, d.Tq, d.Tk = dt_code(dtype), B, H, dh, Tq, Tk
+    d.Q, d.q_bs, d.q_rs = q.data_ptr(), q.stride(0), q.stride(1)
+    d.K, d.k_bs, d.k_rs = k.data_ptr(), k.stride(0), k.stride(1)
+    d.V, d.v_bs, d.v_rs = v.data_ptr(), v.stride(0), v.stride(1)
+    d.q_lens = q_lens.data_ptr() if q_lens is not None else None
+    d.k_lens = k_lens.data_ptr() if k_lens is not None else None
+    if resid is not None:
+        d.resid, d.r_bs, d.r_rs = resid.data_ptr(), resid.stride(0), resid.stride(1)
+    if out is not None:
+        d.out, d.o_bs, d.o_rs = out.data_ptr(), out.stride(0), out.stride(1)
+    return d
+
+
+def _chk3(t, name):
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("%s must be [B,T,*] with unit inner stride" % name)
+
+
+class AttnFn(torch.autograd.Function):
+    """out = concat_h softmax(mask(QK^T/sqrt(dh))) V + resid.  q,k,v may be column slices of packed projections;
+    their gradients are written straight into one packed buffer per distinct base tensor (`pack`)."""
+
+    @staticmethod
+    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn):
+        # self_attn: packed_q is [B,T,3d] = (Q|K|V), packed_kv is None.
+        # cross:     packed_q is [B,Tq,d] = Q, packed_kv is [B,Tk,2d] = (K|V).
+        if self_attn:
+            _chk3(packed_q, "qkv")
+            q, k, v = packed_q[..., :d], packed_q[..., d:2 * d], packed_q[..., 2 * d:]
+        else:
+            _chk3(packed_q, "q"); _chk3(packed_kv, "kv")
+            q, k, v = packed_q, packed_kv[..., :d], packed_kv[..., d:]
+        B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+        out = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
+        desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
+        L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+        ctx.save_for_backward(packed_q, packed_kv, q_lens, k_lens)
+        ctx.H, ctx.d, ctx.self_attn = H, d, self_attn
+        ctx.has_resid = resid is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        packed_q, packed_kv, q_lens, k_lens = ctx.saved_tensors
+        H, d = ctx.H, ctx.d
+        if dout.stride(2) != 1:
+            dout = dout.contiguous()
+        if ctx.self_attn:
+            q, k, v = packed_q[..., :d], packed_q[..., d:2 * d], packed_q[..., 2 * d:]
+            dpq = torch.empty_like(packed_q)
+            dq, dk, dv = dpq[..., :d], dpq[..., d:2 * d], dpq[..., 2 * d:]
+            dpkv = None
+        else:
+            q, k, v = packed_q, packed_kv[..., :d], packed_kv[..., d:]
+            dpq = torch.empty_like(packed_q)
+            dpkv = torch.empty_like(packed_kv)
+            dq, dk, dv = dpq, dpkv[..., :d], dpkv[..., d:]
+        B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
+        bd = L.AttnBwdDesc()
+        bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
+        bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
+        bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
+        bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
+        bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
+        L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+class LNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        rows, d = x2.shape
+        y = torch.empty((rows, d), dtype=x.dtype, device=x.device)
+        stats = torch.empty((rows, 2), dtype=F32, device=x.device)
+        L.call("dmt_ln_fwd", dt_code(x.dtype), rows, d, p(x2), _row_major2d(x2, "x"), p(gamma), p(beta), float(eps), p(y), d,
+               p(stats), stream_ptr())
+        ctx.save_for_backward(x2, gamma, stats)
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, stats = ctx.saved_tensors
+        rows, d = x2.shape
+        dy2 = dy.reshape(-1, d)
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        dx = torch.empty((rows, d), dtype=x2.dtype, device=x2.device)
+        dg = torch.zeros((d,), dtype=F32, device=x2.device)
+        db = torch.zeros((d,), dtype=F32, device=x2.device)
+        npart = L.load().dmt_ln_bwd_partials(rows)
+        partials = torch.empty((npart, 2 * d), dtype=F32, device=x2.device)
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        L.call("dmt_ln_bwd", dt_code(x2.dtype), rows, d, p(x2), _row_major2d(x2, "x"), p(gamma), p(stats), p(dy2),
+               _row_major2d(dy2, "dy"), p(dx), d, p(dg), p(db), p(partials), stream_ptr())
+        return dx.reshape(ctx.xshape), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-8):
+    return LNFn.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------------ MMoE mixture
+class MixFn(torch.autograd.Function):
+    """gates = softmax(glogit per task); mix[t] = sum_e gates[t][:, e] * expert[:, e*U:(e+1)*U]."""
+
+    @staticmethod
+    def forward(ctx, expert, glogit, E, U, n_tasks):
+        Bn = expert.shape[0]
+        gates = torch.empty((n_tasks, Bn, E), dtype=F32, device=expert.device)
+        mix = torch.empty((n_tasks, Bn, U), dtype=expert.dtype, device=expert.device)
+        L.call("dmt_mmoe_mix_fwd", dt_code(expert.dtype), Bn, E, U, n_tasks, p(expert), _row_major2d(expert, "expert"), p(glogit),
+               _row_major2d(glogit, "glogit"), p(gates), p(mix), stream_ptr())
+        ctx.save_for_backward(expert, gates)
+        ctx.dims = (E, U, n_tasks)
+        ctx.mark_non_differentiable(gates)
+        return mix, gates
+
+    @staticmethod
+    def backward(ctx, dmix, _dgates):
+        expert, gates = ctx.saved_tensors
+        E, U, nt = ctx.dims
+        Bn = expert.shape[0]
+        dmix = dmix.contiguous()
+        dexp = torch.empty((Bn, E * U), dtype=expert.dtype, device=expert.device)
+        dgl = torch.empty((Bn, nt * E), dtype=expert.dtype, device=expert.device)
+        L.call("dmt_mmoe_mix_bwd", dt_code(expert.dtype), Bn, E, U, nt, p(expert), _row_major2d(expert, "expert"), p(gates), p(dmix),
+               p(dexp), E * U, p(dgl), nt * E, 0, stream_ptr())
+        return dexp, dgl, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class LossUnbiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, click, order, ybias, mask5, w_ctr, w_ecvr, lw, method, ctr_rel):
+        Bn = click.numel()
+        c, o, yb = (t.reshape(-1).to(F32).contiguous() for t in (click, order, ybias))
+        loss = torch.empty((1,), dtype=F32, device=c.device)
+        pc = torch.empty((Bn,), dtype=F32, device=c.device)
+        pv = torch.empty((Bn,), dtype=F32, device=c.device)
+        dc, do, db = (torch.empty((Bn,), dtype=F32, device=c.device) for _ in range(3))
+        L.call("dmt_loss_unbias", Bn, p(c), p(o), p(yb), p(mask5), p(w_ctr), p(w_ecvr), float(lw[0]), float(lw[1]), int(method),
+               int(ctr_rel), 1.0, p(loss), p(pc), p(pv), p(dc), p(do), p(db), stream_ptr())
+        ctx.save_for_backward(dc, do, db)
+        ctx.shapes = (click.shape, order.shape, ybias.shape, click.dtype, order.dtype, ybias.dtype)
+        ctx.mark_non_differentiable(pc, pv)
+        return loss.reshape(()), pc, pv
+
+    @staticmethod
+    def backward(ctx, gloss, _a, _b):
+        dc, do, db = ctx.saved_tensors
+        s0, s1, s2, t0, t1, t2 = ctx.shapes
+        return ((dc * gloss).reshape(s0).to(t0), (do * gloss).reshape(s1).to(t1), (db * gloss).reshape(s2).to(t2),
+                None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------ misc
+def cast_shadow(src_f32_2d, dst_plain, dst_t):
+    rows, cols = src_f32_2d.shape
+    L.call("dmt_cast_transpose_bf16", rows, cols, p(src_f32_2d), src_f32_2d.stride(0), p(dst_plain),
+           dst_plain.stride(0) if dst_plain is not None else 0, p(dst_t), dst_t.stride(0) if dst_t is not None else 0, stream_ptr())
+
+
+def colsum(x2d, scale=1.0, out=None):
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.zeros((cols,), dtype=F32, device=x2d.device)
+    L.call("dmt_colsum", dt_code(x2d.dtype), rows, cols, p(x2d), _row_major2d(x2d, "x"), float(scale), p(out), stream_ptr())
+    return out

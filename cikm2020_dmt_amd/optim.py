@@ -1,0 +1,95 @@
+"""tf.train.AdamOptimizer semantics on the flat arenas (dense sweep for the 3.4 M dense parameters, exact lazy
+row updates for the embedding tables).
+
+Reference: model/inference_mlp.py:264-273 (get_optimizer -> tf.train.AdamOptimizer(lr)), applied to the averaged
+tower gradients by run_dnn.py:203-207; learning rate = tf.train.piecewise_constant(global_step, step_boundary,
+learning_rate) (run_dnn.py:125-126, dmt.conf:79-80).
+The reference densifies the IndexedSlices embedding gradients (run_dnn.py:45-80) so TF sweeps all 167 M table
+parameters every step; `dmt_adam_sparse_rows` reproduces that arithmetic bit-for-bit but only touches rows when
+they are next read (zero-gradient steps are replayed on the way in), see DESIGN.md §Adam.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+class TFAdam:
+    def __init__(self, store, learning_rate=(0.001, 0.0001), step_boundary=(300000000,), beta1=0.9, beta2=0.999, epsilon=1e-8,
+                 max_steps=1 << 20):
+        self.store = store
+        self.lrs = list(learning_rate) if isinstance(learning_rate, (list, tuple)) else [float(learning_rate)]
+        self.bounds = list(step_boundary)[: len(self.lrs) - 1]
+        self.b1, self.b2, self.eps = float(beta1), float(beta2), float(epsilon)
+        dev = store.device
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.state[0], self.state[1] = self.b1, self.b2
+        self.lr_hist = torch.zeros(max_steps, dtype=torch.float32, device=dev)
+        self.max_steps = max_steps
+        self.global_step = 0
+        names, row_base, dims, offs = store.table_map()
+        tm = L.TableMap()
+        tm.n_tables = len(names)
+        for i in range(len(names)):
+            tm.row_base[i], tm.dim[i], tm.elem_off[i] = row_base[i], dims[i], offs[i]
+        tm.row_base[len(names)] = store.total_rows
+        self.tm = tm
+
+    def current_lr(self) -> float:
+        # tf.train.piecewise_constant: values[i] while step <= boundaries[i]
+        for b, lr in zip(self.bounds, self.lrs):
+            if self.global_step <= b:
+                return lr
+        return self.lrs[-1]
+
+    def begin(self):
+        if self.global_step + 1 >= self.max_steps:
+            raise RuntimeError("lr history capacity exhausted (%d steps)" % self.max_steps)
+        L.call("dmt_adam_begin_step", ops.p(self.state), ops.p(self.lr_hist), self.max_steps, float(self.current_lr()), self.b1,
+               self.b2, ops.stream_ptr())
+
+    def end(self):
+        L.call("dmt_adam_end_step", ops.p(self.state), self.b1, self.b2, ops.stream_ptr())
+        self.global_step += 1
+
+    def apply_dense(self, grad_scale: float = 1.0):
+        s = self.store
+        L.call("dmt_adam_dense", s.P, ops.p(s.params), ops.p(s.adam_m), ops.p(s.adam_v), ops.p(s.grads), float(grad_scale),
+               ops.p(self.state), self.b1, self.b2, self.eps, None, ops.stream_ptr())
+
+    def apply_sparse(self, sparse, grad_scale: float = 1.0):
+        s = self.store
+        uniq, n_uniq, grad_rows, cap = sparse
+        L.call("dmt_adam_sparse_rows", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.shape[1]), float(grad_scale),
+               ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, ops.stream_ptr())
+
+    def step(self, sparse=None, grad_scale: float = 1.0):
+        """One optimizer step over store.grads (dense) and `sparse` = (uniq_keys, n_uniq, grad_rows, cap)."""
+        self.begin()
+        self.apply_dense(grad_scale)
+        if sparse is not None:
+            self.apply_sparse(sparse, grad_scale)
+        self.end()
+        self.store.refresh_shadows()
+
+    def flush_tables(self):
+        """Replay pending zero-gradient updates on every table row (before checkpoint / full-table export)."""
+        s = self.store
+        L.call("dmt_adam_flush_rows", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, ops.stream_ptr())
+
+    def apply_dense_tables(self, dense_grads: dict, grad_scale: float = 1.0):
+        """Dense sweep over whole tables with the same kernel as the dense parameters (what TF does literally).
+        Test hook for the bitwise lazy == dense property; `dense_grads`: table tf_name -> fp32 [rows, dim] tensor.
+        Call between begin() and end()."""
+        s = self.store
+        for name, g in dense_grads.items():
+            info = s.tables[name]
+            sl = slice(info.offset, info.offset + info.numel)
+            L.call("dmt_adam_dense", info.numel, ops.p(s.tab_p[sl]), ops.p(s.tab_m[sl]), ops.p(s.tab_v[sl]), ops.p(g), float(grad_scale),
+                   ops.p(self.state), self.b1, self.b2, self.eps, None, ops.stream_ptr())

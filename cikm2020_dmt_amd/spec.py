@@ -1,0 +1,76 @@
+"""Model specification of the DMT hot path: plain-dict form of dmt.conf's hyper-parameters.
+
+`default_spec()` states the values of /root/reference/DMT_code/conf/settings/dmt.conf:15-129 (the shipped
+default, model_type = mmoe_transformer_unbias); `e64_spec()` is BASELINE.json configs[1] ("emb_dim=64":
+every id field 64 wide -> d_model 320, d_ff 1280, 4 heads of 80).
+`cikm2020_dmt_amd.conf.recsys_conf.Conf(...).to_spec()` builds the same dict from an INI file.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List, Tuple
+
+ITEM_FIELDS = [("Sku", "item_fea_sku"), ("Cid2", "item_c2"), ("Cid3", "item_c3"), ("Brand", "item_brand"), ("Shopid", "item_shop")]
+SEQ_GROUPS = [("clk", "7d_50", "TimeClick"), ("ord", "12m_50", "TimeOrder"), ("cart", "12m_10", "TimeCart")]
+REF_ROWS = {"Sku": 5000000, "Cid2": 500, "Cid3": 12000, "Brand": 190000, "Shopid": 230000, "TimeClick": 23, "TimeOrder": 23, "TimeCart": 23}
+REF_DIMS = {"Sku": 32, "Cid2": 8, "Cid3": 8, "Brand": 16, "Shopid": 16, "TimeClick": 8, "TimeOrder": 8, "TimeCart": 8}
+FIELD_OF_TABLE = {"Sku": "sku", "Cid2": "c2", "Cid3": "c3", "Brand": "brand", "Shopid": "shop"}
+
+
+def build_spec(rows: Dict[str, int], dims: Dict[str, int], d_ff_mult: int = 4, num_heads: int = 4, ord_suffix: str = "12m_50",
+               maxlen_k: int = 50) -> dict:
+    emb: List[Tuple[str, int, int, str, str]] = []
+    for (tab, feat) in ITEM_FIELDS:
+        emb.append((tab, rows[tab], dims[tab], feat, "i"))
+    pairs, ts_feats = [], []
+    for (seq, suffix, ttab) in SEQ_GROUPS:
+        suf = ord_suffix if seq == "ord" else suffix
+        grp = []
+        # dmt.conf order inside one sequence: sku, ts, c2, c3, brand, shop
+        emb.append(("Sku", rows["Sku"], dims["Sku"], "%s_seq_sku_%s" % (seq, suf), "u"))
+        emb.append((ttab, rows[ttab], dims[ttab], "%s_seq_ts_%s" % (seq, suf), "u"))
+        for tab in ("Cid2", "Cid3", "Brand", "Shopid"):
+            emb.append((tab, rows[tab], dims[tab], "%s_seq_%s_%s" % (seq, FIELD_OF_TABLE[tab], suf), "u"))
+        for (tab, item_feat) in ITEM_FIELDS:
+            grp.append(("%s_seq_%s_%s" % (seq, FIELD_OF_TABLE[tab], suf), item_feat))
+        pairs.append(grp)
+        ts_feats.append("%s_seq_ts_%s" % (seq, suf))
+    bias = [("Cid2", rows["Cid2"], 5, "item_c2", "i"), ("Cid3", rows["Cid3"], 5, "item_c3", "i"),
+            ("Cid2", rows["Cid2"], 5, "near_expo_seq_c2", "u"), ("Cid3", rows["Cid3"], 5, "near_expo_seq_c3", "u")]
+    d_model = sum(dims[t] for (t, _f) in ITEM_FIELDS)
+    return dict(
+        embedding_list=emb, embedding_list_bias=bias, attention_embed_pairs=pairs, attention_embed_seq_ts=ts_feats,
+        feature_dimension=615, d_model=d_model, d_ff=d_ff_mult * d_model, num_heads=num_heads, maxlen_k=maxlen_k,
+        num_blocks_encode=1, num_blocks_decode=1,
+        hidden_units_bottom=[512, 256, 128], hidden_units_task=[32], num_experts=4, num_tasks=2,
+        hidden_units_bias=[32, 16], output_units=1,
+        weight_ctr=[1.0, 15.0, 15.0, 15.0, 15.0], weight_ecvr=[1.0, 1.0, 1.0, 400.0, 400.0],
+        loss_weight=[1.0, 1.0], loss_unbias_method="two_head_add", loss_ctr_rel_method="ctr_rel",
+        tie_ffn=True, dropout_rate=0.1, dropout_rate_bias=[0.5, 0.5],
+    )
+
+
+def default_spec(ord_suffix: str = "12m_50") -> dict:
+    return build_spec(REF_ROWS, REF_DIMS, ord_suffix=ord_suffix)
+
+
+def e64_spec(rows: Dict[str, int] = None) -> dict:
+    dims = {k: 64 for k in REF_DIMS}
+    return build_spec(rows or REF_ROWS, dims)
+
+
+def scaled_spec(spec: dict, rows: Dict[str, int]) -> dict:
+    s = copy.deepcopy(spec)
+    s["embedding_list"] = [(n, rows.get(n, r), d, f, side) for (n, r, d, f, side) in spec["embedding_list"]]
+    s["embedding_list_bias"] = [(n, rows.get(n, r), d, f, side) for (n, r, d, f, side) in spec["embedding_list_bias"]]
+    return s
+
+
+def mmoe_input_width(spec) -> int:
+    w = spec["feature_dimension"] + sum(d for (_n, _r, d, _f, _s) in spec["embedding_list"])
+    return w + len(spec["attention_embed_pairs"]) * spec["d_model"]
+
+
+def trans_prefix(i: int) -> str:
+    # scopes opened at mmoe_transformer_unbias.py:193, TransformerModel.py:52 and :89/:136
+    return "embedding_trans/trans_sequence_%d/encode_decode_sequence_%d/encode_decode_sequence_%d/" % (i, i, i)

@@ -1,0 +1,84 @@
+"""The train step of run_dnn.train()'s tower body (run_dnn.py:148-207), one process per GPU.
+
+    logits = inf.inference(features, is_train=True)            -> DMTEngine.inference
+    loss   = inf.loss_multi_task_unbias(logits, labels, mask)  -> DMTEngine.loss_unbias
+    grads  = opt.compute_gradients(loss)                       -> loss.backward() (dense arena + sparse rows)
+    grads  = average_gradients(tower_grads)                    -> parallel.allreduce_dense_ / merge of sparse rows
+    opt.apply_gradients(grads)                                 -> TFAdam.step
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops, parallel
+from .engine import DeviceBatch, DMTEngine
+from .optim import TFAdam
+from .variables import VariableStore
+
+
+class Trainer:
+    def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
+                 step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init)
+        self.engine = DMTEngine(spec, self.store)
+        self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
+        self.last = {}
+
+    def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
+        return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
+
+    def forward_backward(self, batch: DeviceBatch):
+        self.store.zero_grad()
+        out = self.engine.inference(batch)
+        loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
+        loss.backward()
+        self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
+        return loss.detach()
+
+    def merge_sparse(self, sparse):
+        """average_gradients for the IndexedSlices: concatenate every rank's (row, grad) pairs in rank order and
+        reduce rows again with the same stable sort + segment reduce."""
+        rank, W = parallel.world()
+        if W == 1:
+            return sparse
+        uniq, n_uniq, grad_rows, _cap = sparse
+        n = int(n_uniq.item())
+        eng, st = self.engine, self.store
+        all_k, all_r, cap = parallel.allgather_sparse(uniq, grad_rows, n, st.total_rows)
+        N = all_k.numel()
+        vals = torch.arange(N, dtype=torch.int32, device=all_k.device)
+        keys_s = eng._buf("m_keys_s", (N,), torch.int32)
+        vals_s = eng._buf("m_vals_s", (N,), torch.int32)
+        uniq2, n_uniq2, seg = eng.sort_segments(all_k, vals, keys_s, vals_s, N)
+        uniq2, n_uniq2 = uniq2.clone(), n_uniq2.clone()
+        capm = min(N, st.total_rows)
+        out_rows = eng._buf("m_rows", (capm, grad_rows.shape[1]), torch.float32)
+        out_rows.zero_()
+        L.call("dmt_rows_reduce", ops.p(keys_s), ops.p(vals_s), ops.p(seg), N, st.total_rows, ops.p(all_r), ops.p(out_rows),
+               int(grad_rows.shape[1]), ops.stream_ptr())
+        return (uniq2, n_uniq2, out_rows, capm)
+
+    def train_step(self, batch: DeviceBatch):
+        loss = self.forward_backward(batch)
+        rank, W = parallel.world()
+        sparse = self.engine.sparse
+        if W > 1:
+            work = parallel.allreduce_dense_(self.store.grads, async_op=True)
+            sparse = self.merge_sparse(sparse)
+            work.wait()
+            loss = parallel.mean_scalar(loss)
+        self.opt.step(sparse, grad_scale=1.0 / W)
+        return loss
+
+    @torch.no_grad()
+    def predict(self, batch: DeviceBatch):
+        """run_dnn.predict scoring (run_dnn.py:663-687): sigmoid(logit + y_bias)."""
+        with torch.enable_grad():
+            out = self.engine.inference(batch)
+        (c, o), yb = out
+        return torch.sigmoid(c + yb).detach(), torch.sigmoid(o + yb).detach()

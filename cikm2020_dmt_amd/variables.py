@@ -1,0 +1,253 @@
+"""Parameter storage: flat fp32 arenas in HBM with TF-named views.
+
+The reference creates variables lazily by scoped name under `DnnModel/`; those names are
+its checkpoint surface.  Here every dense parameter lives in ONE flat fp32 arena (params / grads / Adam m, v
+share the layout, so the data-parallel gradient exchange is a single RCCL all-reduce of one buffer and the
+optimizer is one kernel launch), packed so that matrices the kernels want fused are contiguous:
+    self/vanilla attention  dense|dense_1|dense_2 kernels -> one [d, 3d] leaf (+ [3d] bias)
+    expert-{e}/expert-layer-0 weights + gates-{t} weights  -> one [K, E*512 + T*E] leaf
+Embedding tables live in a second arena (p / m / v + per-row `last_step` for the exact lazy Adam).
+TF-named variables are (leaf, slice) views used by state_dict()/load_state().
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import Weight
+from .spec import mmoe_input_width, trans_prefix
+
+
+class LeafInfo:
+    __slots__ = ("name", "shape", "offset", "numel")
+
+    def __init__(self, name, shape, offset):
+        self.name, self.shape, self.offset = name, tuple(shape), offset
+        self.numel = int(np.prod(shape))
+
+
+class ViewInfo:
+    __slots__ = ("tf_name", "leaf", "index", "init", "shape")
+
+    def __init__(self, tf_name, leaf, index, init, shape):
+        self.tf_name, self.leaf, self.index, self.init, self.shape = tf_name, leaf, index, init, tuple(shape)
+
+
+def _init_array(init: str, shape, rng) -> np.ndarray:
+    """Initialisers of the reference by distribution: xavier/glorot uniform (base.py:86, tf.layers.dense),
+    truncated normal sigma 0.1 (base.py:32), constants (base.py:36), zeros/ones (LayerNorm)."""
+    if init == "xavier":
+        lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+    if init == "trunc_normal":
+        v = rng.normal(0.0, 0.1, size=shape)
+        bad = np.abs(v) > 0.2
+        while bad.any():
+            v[bad] = rng.normal(0.0, 0.1, size=int(bad.sum()))
+            bad = np.abs(v) > 0.2
+        return v.astype(np.float32)
+    if init.startswith("const:"):
+        return np.full(shape, float(init.split(":")[1]), dtype=np.float32)
+    if init == "ones":
+        return np.ones(shape, dtype=np.float32)
+    return np.zeros(shape, dtype=np.float32)
+
+
+class VariableStore:
+    def __init__(self, spec: dict, device, compute_dtype=torch.float32, seed: int = 0, init: bool = True):
+        self.spec = spec
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        self.leaves: Dict[str, LeafInfo] = {}
+        self.views: Dict[str, ViewInfo] = {}
+        self.tables: Dict[str, LeafInfo] = {}       # tf_name -> info (offset in table arena)
+        self.table_rows: Dict[str, Tuple[int, int]] = {}   # tf_name -> (row_base, rows)
+        self._dense_size = 0
+        self._table_size = 0
+        self._total_rows = 0
+        self._declare_all()
+        self._allocate()
+        if init:
+            self.initialize(seed)
+
+    # ------------------------------------------------------------------ declaration
+    def _leaf(self, name, shape):
+        off = (self._dense_size + 63) // 64 * 64          # 256-byte aligned leaves
+        self.leaves[name] = LeafInfo(name, shape, off)
+        self._dense_size = off + int(np.prod(shape))
+
+    def _view(self, tf_name, leaf, index, init, shape):
+        self.views[tf_name] = ViewInfo(tf_name, leaf, index, init, shape)
+
+    def _simple(self, tf_name, shape, init):
+        self._leaf(tf_name, shape)
+        self._view(tf_name, tf_name, (slice(None),) * len(shape), init, shape)
+
+    def _table(self, tf_name, rows, dim):
+        if tf_name in self.tables:
+            return
+        off = (self._table_size + 63) // 64 * 64
+        self.tables[tf_name] = LeafInfo(tf_name, (rows, dim), off)
+        self._table_size = off + rows * dim
+        self.table_rows[tf_name] = (self._total_rows, rows)
+        self._total_rows += rows
+
+    def _declare_all(self):
+        sp = self.spec
+        d, dff = sp["d_model"], sp["d_ff"]
+        for (name, rows, dim, _f, _s) in sp["embedding_list"]:
+            self._table("embedding_trans/%s/embedding" % name, rows, dim)
+        for (name, rows, dim, _f, _s) in sp["embedding_list_bias"]:
+            self._table("%s/embedding" % name, rows, dim)
+        for i in range(len(sp["attention_embed_pairs"])):
+            pre = trans_prefix(i)
+            self._simple(pre + "positional_encoding_k_position_learn/embedding_position_learn", (sp["maxlen_k"], d), "xavier")
+            blk = pre + "num_blocks_0/"
+            for att in ("self-attention", "vanilla_attention"):
+                wq, bq = blk + att + "/qkv_kernel", blk + att + "/qkv_bias"
+                self._leaf(wq, (d, 3 * d))
+                self._leaf(bq, (3 * d,))
+                for j, dn in enumerate(("dense", "dense_1", "dense_2")):
+                    self._view(blk + "%s/%s/kernel" % (att, dn), wq, (slice(None), slice(j * d, (j + 1) * d)), "xavier", (d, d))
+                    self._view(blk + "%s/%s/bias" % (att, dn), bq, (slice(j * d, (j + 1) * d),), "zeros", (d,))
+                self._simple(blk + att + "/ln/beta", (d,), "zeros")
+                self._simple(blk + att + "/ln/gamma", (d,), "ones")
+            ffs = [blk + "positionwise_feedforward/"]
+            if not sp.get("tie_ffn", True):
+                ffs.append(blk + "positionwise_feedforward_dec/")
+            for ff in ffs:
+                self._simple(ff + "dense/kernel", (d, dff), "xavier")
+                self._simple(ff + "dense/bias", (dff,), "zeros")
+                self._simple(ff + "dense_1/kernel", (dff, d), "xavier")
+                self._simple(ff + "dense_1/bias", (d,), "zeros")
+                self._simple(ff + "ln/beta", (d,), "zeros")
+                self._simple(ff + "ln/gamma", (d,), "ones")
+        # MMoE: layer-0 of all experts and the gates share the input -> one fused [K, E*u0 + T*E] matrix
+        K = mmoe_input_width(sp)
+        E, T = sp["num_experts"], sp["num_tasks"]
+        units = sp["hidden_units_bottom"]
+        ncat = E * units[0] + T * E
+        self._leaf("mmoe_layers/l0_cat_weights", (K, ncat))
+        self._leaf("mmoe_layers/l0_cat_biases", (ncat,))
+        for e in range(E):
+            c0 = e * units[0]
+            self._view("mmoe_layers/expert-%d/expert-layer-0/weights" % e, "mmoe_layers/l0_cat_weights",
+                       (slice(None), slice(c0, c0 + units[0])), "trunc_normal", (K, units[0]))
+            self._view("mmoe_layers/expert-%d/expert-layer-0/biases" % e, "mmoe_layers/l0_cat_biases", (slice(c0, c0 + units[0]),),
+                       "const:0.1", (units[0],))
+            prev = units[0]
+            for li in range(1, len(units)):
+                self._simple("mmoe_layers/expert-%d/expert-layer-%d/weights" % (e, li), (prev, units[li]), "trunc_normal")
+                self._simple("mmoe_layers/expert-%d/expert-layer-%d/biases" % (e, li), (units[li],), "const:0.1")
+                prev = units[li]
+        for t in range(T):
+            c0 = E * units[0] + t * E
+            self._view("mmoe_layers/gates-%d/gates-layer-0/weights" % t, "mmoe_layers/l0_cat_weights",
+                       (slice(None), slice(c0, c0 + E)), "trunc_normal", (K, E))
+            self._view("mmoe_layers/gates-%d/gates-layer-0/biases" % t, "mmoe_layers/l0_cat_biases", (slice(c0, c0 + E),), "const:0.1", (E,))
+        for name in ("click", "order")[:T]:
+            prev = units[-1]
+            for li, size in enumerate(sp["hidden_units_task"]):
+                self._simple("%s/%s-fc-%d/weights" % (name, name, li), (prev, size), "trunc_normal")
+                self._simple("%s/%s-fc-%d/biases" % (name, name, li), (size,), "const:0.1")
+                prev = size
+            self._simple("%s/%s-output/weights" % (name, name), (prev, 1), "trunc_normal")
+            self._simple("%s/%s-output/biases" % (name, name), (1,), "const:0.1")
+        prev = sum(dim for (_n, _r, dim, _f, _s) in sp["embedding_list_bias"])
+        for li, size in enumerate(list(sp["hidden_units_bias"]) + [sp["output_units"]]):
+            self._simple("layer_bias%d/kernel" % li, (prev, size), "xavier")
+            self._simple("layer_bias%d/bias" % li, (size,), "zeros")
+            prev = size
+
+    # ------------------------------------------------------------------ allocation
+    def _allocate(self):
+        dev = self.device
+        P = (self._dense_size + 63) // 64 * 64
+        self.P = P
+        self.params = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(P, dtype=torch.float32, device=dev)
+        TS = (self._table_size + 63) // 64 * 64
+        self.tab_p = torch.zeros(TS, dtype=torch.float32, device=dev)
+        self.tab_m = torch.zeros(TS, dtype=torch.float32, device=dev)
+        self.tab_v = torch.zeros(TS, dtype=torch.float32, device=dev)
+        self.last_step = torch.zeros(self._total_rows, dtype=torch.int32, device=dev)
+        self.total_rows = self._total_rows
+        self.leaf: Dict[str, torch.Tensor] = {}
+        self.weight: Dict[str, Weight] = {}
+        bf = self.compute_dtype == torch.bfloat16
+        self.lp = torch.zeros(P, dtype=torch.bfloat16, device=dev) if bf else None
+        self._w2d: List[str] = []
+        for name, info in self.leaves.items():
+            t = self.params[info.offset: info.offset + info.numel].view(info.shape).detach()
+            t.requires_grad_(True)
+            t.grad = self.grads[info.offset: info.offset + info.numel].view(info.shape)
+            self.leaf[name] = t
+            if len(info.shape) == 2:
+                lp = self.lp[info.offset: info.offset + info.numel].view(info.shape) if bf else None
+                lp_t = torch.zeros((info.shape[1], info.shape[0]), dtype=torch.bfloat16, device=dev) if bf else None
+                self.weight[name] = Weight(t.detach(), lp, lp_t)
+                self._w2d.append(name)
+        self.table: Dict[str, torch.Tensor] = {}
+        for name, info in self.tables.items():
+            self.table[name] = self.tab_p[info.offset: info.offset + info.numel].view(info.shape)
+
+    # ------------------------------------------------------------------ values
+    def initialize(self, seed: int = 0):
+        rng = np.random.default_rng(seed)
+        state = {}
+        for tf_name in sorted(self.views):
+            v = self.views[tf_name]
+            state[tf_name] = _init_array(v.init, v.shape, rng)
+        for tf_name in sorted(self.tables):
+            state[tf_name] = _init_array("xavier", self.tables[tf_name].shape, rng)
+        self.load_state(state)
+
+    def load_state(self, state: Dict[str, np.ndarray]):
+        """state: TF variable name (Appendix B, no 'DnnModel/' prefix) -> array."""
+        with torch.no_grad():
+            for tf_name, arr in state.items():
+                a = torch.as_tensor(np.asarray(arr, dtype=np.float32))
+                if tf_name in self.views:
+                    v = self.views[tf_name]
+                    self.leaf[v.leaf][v.index].copy_(a.to(self.device))
+                elif tf_name in self.tables:
+                    self.table[tf_name].copy_(a.to(self.device))
+                else:
+                    raise KeyError("unknown variable %s" % tf_name)
+        self.refresh_shadows()
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        out = {}
+        for tf_name, v in self.views.items():
+            out[tf_name] = self.leaf[v.leaf].detach()[v.index].float().cpu().numpy().copy()
+        for tf_name in self.tables:
+            out[tf_name] = self.table[tf_name].float().cpu().numpy().copy()
+        return out
+
+    def grad_dict(self) -> Dict[str, np.ndarray]:
+        out = {}
+        for tf_name, v in self.views.items():
+            out[tf_name] = self.leaf[v.leaf].grad[v.index].float().cpu().numpy().copy()
+        return out
+
+    def refresh_shadows(self):
+        """fp32 masters -> bf16 plain + transposed shadows (after init / load / every optimizer step)."""
+        if self.compute_dtype != torch.bfloat16:
+            return
+        for name in self._w2d:
+            w = self.weight[name]
+            ops.cast_shadow(w.f32, w.lp, w.lp_t)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def table_map(self):
+        """(names, row_base[], dim[], elem_off[]) in global-row order for the sparse optimizer."""
+        names = sorted(self.tables, key=lambda n: self.table_rows[n][0])
+        return names, [self.table_rows[n][0] for n in names], [self.tables[n].shape[1] for n in names], [self.tables[n].offset for n in names]

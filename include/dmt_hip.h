@@ -1,0 +1,295 @@
+/*
+ * dmt_hip.h -- C ABI of libdmt_hip.so: the MI355X (gfx950) kernels behind the DMT train-step hot path.
+ *
+ * The reference (guyulongcs/CIKM2020_DMT) has no FFI: the hot path is TensorFlow-1.12 graph ops called
+ * from plain Python.  Each entry point below therefore replaces the TF op group that one
+ * reference Python function emits; the comment on every function cites that function
+ * (paths relative to /root/reference/DMT_code/).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, POD arguments only; every pointer is a DEVICE pointer unless named h_*;
+ *   - the caller owns every buffer (incl. workspaces); the library allocates nothing, keeps no global
+ *     mutable state except the thread-local error string, never synchronises, and launches only on
+ *     the `stream` argument (a hipStream_t passed as void*);
+ *   - return 0 on success, <0 on error (message: dmt_last_error()); no C++ exception crosses the ABI;
+ *   - dtype codes: DMT_F32 = 0, DMT_BF16 = 1.  Accumulation is always fp32.  Parameters that are
+ *     vectors (bias, LayerNorm gamma/beta) and all embedding tables are fp32 masters in both modes.
+ */
+#ifndef DMT_HIP_H
+#define DMT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMT_F32 0
+#define DMT_BF16 1
+
+#define DMT_OK 0
+#define DMT_ERR_ARG (-1)
+#define DMT_ERR_LAUNCH (-2)
+#define DMT_ERR_UNSUPPORTED (-3)
+
+#define DMT_MAX_FEATURES 32
+#define DMT_MAX_SEQS 4
+#define DMT_MAX_TABLES 32
+
+const char* dmt_last_error(void);
+int dmt_version(void);
+/* gfx arch string the device code was built for ("gfx950"). */
+const char* dmt_build_arch(void);
+/* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
+ * 5 attn_bwd_desc, 6 table_map (lets a binding verify its struct layout). */
+int dmt_struct_size(int which);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding gather + concat + mean-pool (forward).
+ * Replaces: mmoe_transformer_unbias.generate_data (model/net/mmoe_transformer_unbias.py:130-186),
+ *           base.embedding / base.embedding_combiner (model/net/base.py:81-134), the input prep of
+ *           TransformerModel.encode/decode (model/net/TransformerModel.py:96-100,146-147: *sqrt(d_model)
+ *           + learned positions) and the tf.concat that assembles the MMoE input
+ *           (mmoe_transformer_unbias.py:226-233).
+ * One feature = one (table, id column) pair of dmt.conf's `emb` list.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* table;   /* fp32 [rows, dim] embedding variable (NO zero row prepended)              */
+  int32_t rows, dim;
+  const int32_t* idx;   /* [B, T] left-aligned, padded with 0                                      */
+  const float* wts;     /* [B, T] sp_weights or NULL (== 1.0)                                      */
+  const int32_t* lens;  /* [B] number of valid entries                                             */
+  int32_t T;            /* padded length == row stride of idx / wts                                */
+  int32_t pooled_off;   /* column of the mean-pooled embedding in `pooled` (<0: not pooled)        */
+  int32_t seq_id;       /* sequence output this feature feeds (0..n_seq-1), DMT_SEQ_TARGET, or <0  */
+  int32_t seq_off;      /* column inside the d_model-wide sequence / target row                    */
+  int32_t group;        /* features with equal group are processed by the same workgroup           */
+  float* inv_wsum;      /* [B] out: 1/sum(w) per example (0 when empty), needed by backward; or NULL */
+} dmt_gather_feature;
+
+#define DMT_SEQ_TARGET 100
+
+typedef struct {
+  int32_t B;
+  int32_t n_features;
+  dmt_gather_feature feat[DMT_MAX_FEATURES];
+  int32_t n_seq;
+  void* seq_out[DMT_MAX_SEQS];      /* [B, seq_T[s], d_model]  = seq_scale * [0;E][idx] + pos[s][t]  */
+  int32_t seq_T[DMT_MAX_SEQS];
+  const float* pos[DMT_MAX_SEQS];   /* fp32 [>=seq_T, d_model] learned positions or NULL             */
+  void* tar_out;                    /* [B, d_model] = seq_scale * [0;E][item idx]  (or NULL)         */
+  int32_t d_model;
+  float seq_scale;                  /* sqrt(d_model) (TransformerModel.py:96) or 1.0 for raw output  */
+  void* pooled;                     /* [B, ld_pooled]: dense | pooled embeddings (MMoE input z)      */
+  int64_t ld_pooled;
+  const float* dense;               /* fp32 [B, n_dense] 'features' or NULL                          */
+  int32_t n_dense;                  /* copied to pooled[:, 0:n_dense]                                */
+  int32_t out_dtype;                /* dtype of seq_out / tar_out / pooled                           */
+} dmt_gather_desc;
+
+int dmt_gather_fwd(const dmt_gather_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding gradient: sparse (row, grad) pairs.
+ * Replaces: the IndexedSlices gradients TF autodiff produces for tf.nn.embedding_lookup /
+ *           embedding_lookup_sparse (call sites base.py:116, mmoe_transformer_unbias.py:155,158).
+ * Entry e of the flattened list  [feature f][kind: 0 pooled, 1 seq][b][t]  contributes
+ *      kind 0: (w[b,t] * inv_wsum[b]) * dpooled[b, pooled_off : +dim]  to table row  idx[b,t]
+ *      kind 1: seq_scale * dseq[seq_id][b, t, seq_off : +dim]          to table row  idx[b,t]-1 (idx>0)
+ * Rows are addressed by a GLOBAL row id = row_base[table] + row (tables concatenated).
+ * Pipeline: dmt_embgrad_keys -> dmt_sort_pairs -> dmt_segment_heads -> dmt_embgrad_reduce.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B;
+  int32_t n_features;
+  dmt_gather_feature feat[DMT_MAX_FEATURES];   /* same list as forward (table ptr unused)            */
+  int32_t row_base[DMT_MAX_FEATURES];          /* global row id of row 0 of this feature's table     */
+  int32_t entry_base[DMT_MAX_FEATURES + 1];    /* first entry of feature f; kinds laid out pooled then seq */
+  int32_t total_rows;                          /* invalid key == total_rows                          */
+  const void* dseq[DMT_MAX_SEQS];              /* grad wrt seq_out[s] [B, seq_T[s], d_model]         */
+  int32_t seq_T[DMT_MAX_SEQS];
+  const void* dtar;                            /* grad wrt tar_out [B, d_model]                      */
+  const void* dpooled;                         /* grad wrt pooled [B, ld_pooled]                     */
+  int64_t ld_pooled;
+  int32_t d_model;
+  float seq_scale;
+  int32_t grad_dtype;
+} dmt_embgrad_desc;
+
+/* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e.            */
+int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, void* stream);
+
+/* Stable LSD radix sort of (key, value) pairs on bits [0, end_bit).  ws_bytes: in/out workspace size;
+ * call with ws == NULL to query.                                                                     */
+int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                   int64_t n, int32_t end_bit, void* ws, uint64_t* ws_bytes, void* stream);
+
+/* From sorted keys: seg_id[e] = rank of key[e] among distinct keys (inclusive scan of head flags - 1);
+ * uniq_keys[seg] = key; n_uniq[0] = number of distinct keys < invalid_key.                            */
+int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_key, int32_t* seg_id,
+                      uint32_t* uniq_keys, int32_t* n_uniq, void* ws, uint64_t* ws_bytes, void* stream);
+
+/* grad_rows[seg, 0:dim_of(table)] += contribution of every entry (row stride = max_dim, fp32).
+ * grad_rows must be zeroed by the caller.                                                            */
+int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
+                       const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream);
+
+/* Same reduction for already-materialised rows (data-parallel merge of per-rank sparse gradients):
+ * out_rows[seg_id[e]] += in_rows[sorted_vals[e]].                                                    */
+int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
+                    uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[m,n] = epi( sum_k A(m,k) * B(k,n) ),  A(m,k) = A[m*a_rs + k*a_cs],
+ * B(k,n) = B[k*b_rs + n*b_cs].  bf16 operands use v_mfma_f32_32x32x16_bf16, fp32 operands
+ * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+ *   epi(x) = ((x + bias[n]) relu-if(n < act_ncols)) * (gate[m,n] > 0 if gate) + resid[m,n]
+ * Replaces: tf.layers.dense / tf.matmul(+b) call sites -- TransformerModel_util.py:188-190 (QKV),
+ *           :224-227 (FFN), base.py:39-68 dense_layer (experts, gates, towers),
+ *           mmoe_transformer_unbias.py:266-287 (bias MLP) -- and their autodiff gradients
+ *           (dX = dY W^T, dW = X^T dY, db = colsum dY via `a_ones_row`).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t in_dtype;            /* dtype of A, B, gate                                               */
+  int32_t out_dtype;           /* dtype of C, resid                                                 */
+  int32_t M, N, K;
+  const void* A; int64_t a_rs, a_cs;
+  const void* B; int64_t b_rs, b_cs;
+  void* C; int64_t ldc;
+  const float* bias;           /* [N] or NULL                                                       */
+  int32_t act_ncols;           /* relu applied to columns n < act_ncols (0: none)                   */
+  const void* gate; int64_t ldg;     /* relu-gradient mask source or NULL                           */
+  const void* resid; int64_t ldr;    /* residual or NULL                                            */
+  int32_t a_ones_row;          /* 1: logical row M-1 of A is all ones; its output row goes to c_last */
+  float* c_last;               /* fp32 [N] (bias gradient) when a_ones_row                          */
+  int32_t split_k;             /* >1: K split over workgroups, fp32 atomicAdd into C (C must be fp32, zeroed) */
+  int32_t batch;               /* >=1 */
+  int64_t a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs;   /* per-batch element strides    */
+} dmt_gemm_desc;
+
+int dmt_gemm(const dmt_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Short-sequence multi-head attention core (one wavefront per (example, head)).
+ *   out[b,q,:] = concat_h softmax(mask(Q_h K_h^T / sqrt(dh))) V_h + resid[b,q,:]
+ * with the reference's masking: invalid keys <- -2^32+1 before softmax; rows of invalid queries
+ * <- -2^32+1 AFTER softmax (TransformerModel_util.py:11-56, 80-108).  No output projection (F8).
+ * Replaces: scaled_dot_product_attention + head split/concat + residual of multihead_attention
+ *           (TransformerModel_util.py:160-205).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;               /* Q, K, V, resid, out (and dout, dq, dk, dv) */
+  int32_t B, H, dh, Tq, Tk;
+  const void* Q; int64_t q_bs, q_rs;       /* Q[b*q_bs + t*q_rs + h*dh + j] */
+  const void* K; int64_t k_bs, k_rs;
+  const void* V; int64_t v_bs, v_rs;
+  const int32_t* q_lens;       /* [B] or NULL (all queries valid) */
+  const int32_t* k_lens;       /* [B] */
+  const void* resid; int64_t r_bs, r_rs;   /* or NULL */
+  void* out; int64_t o_bs, o_rs;
+} dmt_attn_desc;
+
+int dmt_attn_fwd(const dmt_attn_desc* d, void* stream);
+
+/* Backward: given dout (grad wrt out, same layout as out) produce dQ, dK, dV (layouts as Q, K, V;
+ * every element of the (b, t<T, h, j) range is written).  The residual gradient is dout itself.      */
+typedef struct {
+  dmt_attn_desc f;
+  const void* dout; int64_t do_bs, do_rs;
+  void* dQ; int64_t dq_bs, dq_rs;
+  void* dK; int64_t dk_bs, dk_rs;
+  void* dV; int64_t dv_bs, dv_rs;
+} dmt_attn_bwd_desc;
+
+int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim, biased variance, eps inside the sqrt (TransformerModel_util.py:58-78).
+ *   y = gamma * (x - mean) / sqrt(var + eps) + beta ; stats[r] = {mean, rstd}
+ * ------------------------------------------------------------------------------------------------ */
+int dmt_ln_fwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
+               const float* beta, float eps, void* y, int64_t ldy, float* stats, void* stream);
+/* dx written; dgamma/dbeta (fp32 [d]) are ACCUMULATED with atomics-free two-stage reduction through
+ * `partials` (fp32 [n_part, 2*d], n_part = dmt_ln_bwd_partials(rows)).                               */
+int32_t dmt_ln_bwd_partials(int64_t rows);
+int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
+               const float* stats, const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma,
+               float* dbeta, float* partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MMoE mixture: gate softmax + weighted sum of expert outputs and its gradient
+ * (mmoe_transformer_unbias.py:80-105: dense_layer(..., tf.nn.softmax), stack/tile/reduce_sum).
+ *   gates[t][b,:] = softmax(glogit[b, t*E : (t+1)*E]);  mix[t][b,:] = sum_e gates[t][b,e] * expert[b, e*U : (e+1)*U]
+ * ------------------------------------------------------------------------------------------------ */
+int dmt_mmoe_mix_fwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_tasks, const void* expert,
+                     int64_t ld_expert, const void* glogit, int64_t ld_glogit, float* gates /* [n_tasks,B,E] */,
+                     void* mix /* [n_tasks, B, U] */, void* stream);
+int dmt_mmoe_mix_bwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_tasks, const void* expert,
+                     int64_t ld_expert, const float* gates, const void* dmix, void* dexpert, int64_t ld_dexpert,
+                     void* dglogit, int64_t ld_dglogit, int32_t relu_mask /* 1: expert is a relu output, return the
+                     gradient wrt its pre-activation */, void* stream);
+
+/* Gradient of relu given its OUTPUT y: dz = dy * (y > 0)  (tf.nn.relu at base.py:64, TransformerModel_util.py:224). */
+int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const void* dy, int64_t lddy, const void* y, int64_t ldy,
+                 void* dz, int64_t lddz, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss of the unbias model (model/inference_mlp.py:162-223) and its gradient in one pass.
+ *   method: 0 two_head_add, 1 two_head_multiply;  ctr_rel: 1 adds the relevance-only cross entropies.
+ *   loss[0] = scalar loss (batch mean, class weights w_ctr/w_ecvr[5], loss weights lw[2]);
+ *   p_ctr, p_cvr [B] as run_dnn.py:90-101; d_click/d_order/d_bias [B] = dloss/dlogit * grad_scale.
+ *   logits are fp32 [B] (the towers' final 1-wide layer is produced in fp32).
+ * ------------------------------------------------------------------------------------------------ */
+int dmt_loss_unbias(int32_t B, const float* click, const float* order, const float* ybias, const float* mask5,
+                    const float* w_ctr, const float* w_ecvr, float lw_clk, float lw_ord, int32_t method,
+                    int32_t ctr_rel, float grad_scale, float* loss, float* p_ctr, float* p_cvr, float* d_click,
+                    float* d_order, float* d_bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * tf.train.AdamOptimizer arithmetic (model/inference_mlp.py:264-273 -> TF ApplyAdam), see
+ * oracle/dmt_oracle.py:TFAdam.  `state` (device, fp32[4]) = {beta1_power, beta2_power, lr_t, step};
+ * dmt_adam_begin_step computes lr_t for this step and appends it to lr_hist[step] (for lazy rows),
+ * dmt_adam_end_step advances the powers.  Hyper-parameters are passed by value.
+ * ------------------------------------------------------------------------------------------------ */
+int dmt_adam_begin_step(float* state, float* lr_hist, int32_t lr_hist_cap, float lr, float beta1, float beta2,
+                        void* stream);
+int dmt_adam_end_step(float* state, float beta1, float beta2, void* stream);
+/* Dense: p, m, v, g fp32 [n];  optional bf16 shadow written alongside (lp may be NULL).               */
+int dmt_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, float grad_scale, const float* state,
+                   float beta1, float beta2, float eps, void* lp_bf16, void* stream);
+/* Sparse rows with exact lazy catch-up: for every u < n_uniq[0]: row = uniq_keys[u] (global id);
+ * replay the zero-gradient updates of steps last_step[row]+1 .. step-1 (bit-identical to the dense
+ * sweep), then apply step `step` with gradient grad_rows[u].  Tables are described by
+ * (row_base, dim, element offset into the p/m/v arenas).                                             */
+typedef struct {
+  int32_t n_tables;
+  int32_t row_base[DMT_MAX_TABLES + 1];   /* ascending; row_base[n_tables] = total_rows              */
+  int32_t dim[DMT_MAX_TABLES];
+  int64_t elem_off[DMT_MAX_TABLES];       /* offset of the table inside p / m / v                    */
+} dmt_table_map;
+int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                         const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* grad_rows,
+                         int32_t max_dim, float grad_scale, const float* state, const float* lr_hist, float beta1,
+                         float beta2, float eps, void* stream);
+/* Bring every row of every table up to date (before checkpoint / evaluation of untouched rows).      */
+int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                        const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream);
+
+/* fp32 -> bf16 shadow copies of 2-D weights, plain and transposed: dst[n*ld_t + k] = src[k*ld + n].    */
+int dmt_cast_bf16(int64_t n, const float* src, void* dst, void* stream);
+int dmt_cast_transpose_bf16(int32_t rows, int32_t cols, const float* src, int64_t ld_src, void* dst_plain,
+                            int64_t ld_plain, void* dst_t, int64_t ld_t, void* stream);
+
+/* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
+ * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
+int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
+               void* stream);
+
+/* Streaming 200-threshold confusion histogram behind tf.metrics.auc (run_dnn.py:228-241):
+ * hist[(label?1:0) * (n_thr+1) + #thresholds below pred] += 1 (int64).                                */
+int dmt_auc_hist(int32_t B, const float* pred, const float* label, int32_t n_thr, long long* hist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMT_HIP_H */

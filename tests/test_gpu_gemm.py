@@ -1,0 +1,103 @@
+"""dmt_gemm vs a plain fp64 matmul reference: all operand layouts, epilogues, batching, split-K, ones-row."""
+import numpy as np
+import pytest
+import torch
+
+from cikm2020_dmt_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+def _mk(shape, dtype, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g, dtype=torch.float32)
+    xd = x.to(dtype).to(dev)
+    return xd, xd.double().cpu()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 150, 77), (1, 1, 5), (260, 2056, 1199), (64, 80, 320), (513, 33, 16)])
+def test_gemm_layouts(cuda, dtype, M, N, K):
+    x, xr = _mk((M, K), dtype, cuda, 1)
+    w, wr = _mk((K, N), dtype, cuda, 2)
+    b = torch.randn(N, device=cuda)
+    ref = xr @ wr + b.double().cpu()
+    scale = ref.abs().max().item()
+    wt = w.t().contiguous()
+    xt = x.t().contiguous()
+    outs = {}
+    # A k-contiguous, B n-contiguous (row-major W)
+    o = torch.empty((M, N), dtype=dtype, device=cuda); ops.gemm(x, K, 1, w, N, 1, M, N, K, o, N, bias=b); outs["rowmajorW"] = o
+    # A k-contiguous, B k-contiguous (transposed shadow)
+    o = torch.empty((M, N), dtype=dtype, device=cuda); ops.gemm(x, K, 1, wt, 1, K, M, N, K, o, N, bias=b); outs["WT"] = o
+    # A m-contiguous (x^T stored), B n-contiguous
+    o = torch.empty((M, N), dtype=dtype, device=cuda); ops.gemm(xt, 1, M, w, N, 1, M, N, K, o, N, bias=b); outs["xT"] = o
+    # fp32 output from the same operands
+    o = torch.empty((M, N), dtype=torch.float32, device=cuda); ops.gemm(x, K, 1, wt, 1, K, M, N, K, o, N, bias=b); outs["f32out"] = o
+    for k, v in outs.items():
+        err = (v.double().cpu() - ref).abs().max().item() / scale
+        assert err < _tol(dtype), "%s: rel err %g" % (k, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(cuda, dtype):
+    M, N, K = 150, 200, 96
+    x, xr = _mk((M, K), dtype, cuda, 3)
+    w, wr = _mk((K, N), dtype, cuda, 4)
+    r, rr = _mk((M, N), dtype, cuda, 5)
+    gt, gr = _mk((M, N), dtype, cuda, 6)
+    b = torch.randn(N, device=cuda)
+    pre = xr @ wr + b.double().cpu()
+    # relu on the first 120 columns, then residual
+    ref = pre.clone(); ref[:, :120] = ref[:, :120].clamp_min(0); ref = ref + rr
+    o = torch.empty((M, N), dtype=dtype, device=cuda)
+    ops.gemm(x, K, 1, w, N, 1, M, N, K, o, N, bias=b, act_ncols=120, resid=r, ldr=N)
+    assert (o.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < _tol(dtype)
+    # relu-gradient gate
+    ref = (xr @ wr) * (gr > 0)
+    ops.gemm(x, K, 1, w, N, 1, M, N, K, o, N, gate=gt, ldg=N)
+    assert (o.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < _tol(dtype)
+    # strided views (leading dims larger than the logical width)
+    big = torch.zeros((M, K + 24), dtype=dtype, device=cuda); big[:, :K] = x
+    obig = torch.zeros((M, N + 8), dtype=dtype, device=cuda)
+    ops.gemm(big, K + 24, 1, w, N, 1, M, N, K, obig, N + 8)
+    assert (obig[:, :N].double().cpu() - xr @ wr).abs().max().item() / ref.abs().max().item() < _tol(dtype)
+    assert obig[:, N:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,K,N", [(1000, 80, 240), (4096, 1199, 136), (300, 20, 1), (2000, 320, 80)])
+def test_gemm_weight_grad(cuda, dtype, rows, K, N):
+    """dW = x^T dy and db = colsum(dy) through the ones-row, split over the row dimension with fp32 atomics."""
+    x, xr = _mk((rows, K), dtype, cuda, 7)
+    dy, dyr = _mk((rows, N), dtype, cuda, 8)
+    dW, db = ops.linear_backward_weight(x, dy, want_bias=True)
+    ref_w = xr.t() @ dyr
+    ref_b = dyr.sum(0)
+    assert (dW.double().cpu() - ref_w).abs().max().item() / ref_w.abs().max().item() < 3e-5
+    assert (db.double().cpu() - ref_b).abs().max().item() / ref_b.abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched(cuda, dtype):
+    Bt, M, N, K = 4, 100, 64, 48
+    x, xr = _mk((Bt, M, K), dtype, cuda, 9)
+    w, wr = _mk((Bt, K, N), dtype, cuda, 10)
+    b = torch.randn(Bt, N, device=cuda)
+    o = torch.empty((Bt, M, N), dtype=dtype, device=cuda)
+    ops.gemm(x, K, 1, w, N, 1, M, N, K, o, N, bias=b, act_ncols=N, batch=Bt, a_bs=M * K, b_bs=K * N, c_bs=M * N, bias_bs=N)
+    ref = (torch.bmm(xr, wr) + b.double().cpu()[:, None, :]).clamp_min(0)
+    assert (o.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < _tol(dtype)
+
+
+def test_gemm_rejects_bad_args(cuda):
+    from cikm2020_dmt_amd._lib import DmtError
+    x = torch.zeros((4, 4), device=cuda)
+    with pytest.raises(DmtError):
+        ops.gemm(x, 4, 1, x, 4, 1, 0, 4, 4, x, 4)
+    with pytest.raises(DmtError):
+        ops.gemm(x, 4, 1, x, 4, 1, 4, 4, 4, x.to(torch.bfloat16), 4, split_k=2)

@@ -1,0 +1,125 @@
+"""End-to-end parity of the HIP path with the CPU oracle: forward logits, loss, every gradient, train steps.
+
+Tolerances (stated): fp32 path -- logits |d| <= 2e-4 absolute (values are O(1)), loss rel 1e-5,
+gradients rel 2e-3 of the tensor's max magnitude;  bf16 path -- logits 6e-2, loss rel 3e-2, gradients rel 8e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmt_oracle as O
+from oracle import dmt_oracle_torch as OT
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from cikm2020_dmt_amd.train import Trainer
+from tests.util import small_specs, sparse_to_dense_tables, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: dict(logit=2e-4, loss=1e-5, grad=2e-3), torch.bfloat16: dict(logit=6e-2, loss=3e-2, grad=8e-2)}
+
+
+def _setup(cuda, dtype, B=24, seed=5, lengths="ragged", weights="random", seq_lens=None):
+    so, sp = small_specs()
+    P = O.init_params(so, seed=11)
+    # make LayerNorm / bias parameters non-trivial so their gradients and use are exercised
+    rng = np.random.default_rng(3)
+    for k in P:
+        if k.endswith("/gamma"):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+        if k.endswith("/beta") or k.endswith("/bias"):
+            P[k] = P[k] + 0.05 * rng.standard_normal(P[k].shape)
+    inputs, mask, label = make_batch(sp, B, seed=seed, lengths=lengths, weights=weights, seq_lens=seq_lens)
+    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False)
+    tr.store.load_state(P)
+    batch = tr.make_batch(inputs, mask, label)
+    return so, sp, P, inputs, mask, tr, batch
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("lengths,weights", [("ragged", "random"), ("full", "ones")])
+def test_forward_logits_match_oracle(cuda, dtype, lengths, weights):
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype, lengths=lengths, weights=weights)
+    (c_ref, o_ref), yb_ref = O.inference(inputs, P, so)
+    loss_ref = O.loss_multi_task_unbias(((c_ref, o_ref), yb_ref), mask, so)
+    out = tr.engine.inference(batch)
+    loss, pc, pv = tr.engine.loss_unbias(out, batch.mask)
+    (c, o), yb = out
+    t = TOL[dtype]
+    assert np.abs(c.float().cpu().numpy() - c_ref).max() < t["logit"]
+    assert np.abs(o.float().cpu().numpy() - o_ref).max() < t["logit"]
+    assert np.abs(yb.float().cpu().numpy() - yb_ref).max() < t["logit"]
+    assert abs(float(loss) - loss_ref) / abs(loss_ref) < t["loss"]
+    pc_ref, pv_ref = O.cal_ctr_cvr_unbias((c_ref, o_ref), yb_ref)
+    assert np.abs(pc.cpu().numpy() - pc_ref.reshape(-1)).max() < t["logit"]
+    assert np.abs(pv.cpu().numpy() - pv_ref.reshape(-1)).max() < t["logit"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradients_match_oracle(cuda, dtype):
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype)
+    loss_ref, _lg, G = OT.loss_and_grads(P, inputs, mask, so)
+    loss = tr.forward_backward(batch)
+    t = TOL[dtype]
+    assert abs(float(loss) - loss_ref) / abs(loss_ref) < t["loss"]
+    got = tr.store.grad_dict()
+    bad = []
+    for name, g in got.items():
+        ref = G[name]
+        e = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-12)
+        if not e < t["grad"]:
+            bad.append((name, e, float(np.abs(ref).max())))
+    tabs = sparse_to_dense_tables(tr.store, tr.engine.sparse)
+    for name, g in tabs.items():
+        ref = G[name]
+        e = np.abs(g - ref).max() / (np.abs(ref).max() + 1e-12)
+        if not e < t["grad"]:
+            bad.append((name, e, float(np.abs(ref).max())))
+    assert not bad, "gradient mismatches: %s" % bad
+
+
+def test_train_steps_match_oracle_fp32(cuda):
+    """3 optimizer steps (dense Adam + exact lazy rows) against the oracle's dense TFAdam in float64."""
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, torch.float32, B=16)
+    Pn = {k: v.copy() for k, v in P.items()}
+    adam = O.TFAdam(lr=1e-3)
+    batches = [make_batch(sp, 16, seed=100 + i, lengths="ragged", weights="random") for i in range(3)]
+    for (inp, m, _l) in batches:
+        _loss, _lg, G = OT.loss_and_grads(Pn, inp, m, so)
+        adam.apply(Pn, G)
+        tr.train_step(tr.make_batch(inp, m))
+    tr.opt.flush_tables()
+    got = tr.store.state_dict()
+    worst = max((np.abs(got[k] - Pn[k]).max(), k) for k in Pn)
+    # after 3 Adam steps every touched parameter moved by ~3e-3; agreement to 2e-5 absolute
+    assert worst[0] < 2e-5, worst
+
+
+def test_edge_cases_len1_and_unknown_ids(cuda):
+    """All sequences of length 1 with id 0 ('unknow' -> zero vector on the Transformer path, row 0 on the pooled path)."""
+    so, sp = small_specs()
+    P = O.init_params(so, seed=2)
+    inputs, mask, label = make_batch(sp, 5, seed=9, lengths="ragged")
+    from cikm2020_dmt_amd.sparse import SparseTensorValue
+    for grp in sp["attention_embed_pairs"]:
+        for (uf, _i) in grp:
+            inputs[uf] = SparseTensorValue.from_rows([[0]] * 5, np.int64)
+            inputs[uf + "Wts"] = SparseTensorValue.from_rows([[1.0]] * 5, np.float32)
+    for f in sp["attention_embed_seq_ts"]:
+        inputs[f] = SparseTensorValue.from_rows([[0]] * 5, np.int64)
+        inputs[f + "Wts"] = SparseTensorValue.from_rows([[1.0]] * 5, np.float32)
+    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False)
+    tr.store.load_state(P)
+    (c_ref, o_ref), yb_ref = O.inference(inputs, P, so)
+    (c, o), yb = tr.engine.inference(tr.make_batch(inputs, mask))
+    assert np.abs(c.cpu().detach().numpy() - c_ref).max() < 2e-4
+    assert np.abs(o.cpu().detach().numpy() - o_ref).max() < 2e-4
+
+
+def test_padded_batch_equals_tight_batch(cuda):
+    """Padding every sequence column to its maximum length (static shapes) must not change any output."""
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, torch.float32)
+    (c0, o0), y0 = tr.engine.inference(batch)
+    pad = {f: 50 for (_n, _r, _d, f, _s) in sp["embedding_list"] if "seq" in f}
+    b2 = tr.make_batch(inputs, mask, pad_to=pad)
+    (c1, o1), y1 = tr.engine.inference(b2)
+    assert (c0 - c1).abs().max().item() < 1e-5 and (o0 - o1).abs().max().item() < 1e-5

@@ -1,0 +1,154 @@
+"""Per-kernel parity against the oracle's reference functions (attention block, FFN, LayerNorm, loss, AUC, Adam)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmt_oracle as O
+from oracle import dmt_oracle_torch as OT
+from cikm2020_dmt_amd import ops
+from cikm2020_dmt_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,T,H,dh", [(5, 50, 4, 20), (3, 10, 4, 20), (2, 64, 4, 80), (4, 7, 2, 16), (3, 1, 4, 20)])
+def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
+    d = H * dh
+    q = torch.tensor(_rand((B, T, d), 1), dtype=dtype)
+    k = torch.tensor(_rand((B, T, d), 2), dtype=dtype)
+    v = torch.tensor(_rand((B, T, d), 3), dtype=dtype)
+    x = torch.tensor(_rand((B, T, d), 4), dtype=dtype)
+    lens = np.random.default_rng(5).integers(1, T + 1, size=B)
+    qn, kn, vn, xn = (t.double().numpy() for t in (q, k, v, x))
+    Q_ = np.concatenate(np.split(qn, H, axis=2), axis=0)
+    K_ = np.concatenate(np.split(kn, H, axis=2), axis=0)
+    V_ = np.concatenate(np.split(vn, H, axis=2), axis=0)
+    m = O.sequence_mask(lens, T)
+    ref = np.concatenate(np.split(O.scaled_dot_product_attention(Q_, K_, V_, m, m), H, axis=0), axis=2) + xn
+    qkv = torch.cat([q, k, v], dim=-1).to(cuda).requires_grad_(True)
+    xd = x.to(cuda).requires_grad_(True)
+    ld = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    out = ops.AttnFn.apply(qkv, None, xd, ld, ld, H, d, True)
+    got = out.detach().double().cpu().numpy()
+    valid = m[:, :, None]
+    # rows of padded queries hold c * sum(V) with c = -2**32+1 (reference behaviour): compare relatively
+    err = np.abs(got - ref) / (np.abs(ref) + 1.0)
+    assert err.max() < tol, err.max()
+    # gradients (only through valid query rows, as in the model) vs torch autograd of the second oracle
+    w = torch.tensor(_rand((B, T, d), 6) * m[:, :, None], dtype=torch.float64)
+    (out.double() * w.to(cuda)).sum().backward()
+    qt, kt, vt, xt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (qn, kn, vn, xn))
+    Qh = qt.view(B, T, H, dh).transpose(1, 2); Kh = kt.view(B, T, H, dh).transpose(1, 2); Vh = vt.view(B, T, H, dh).transpose(1, 2)
+    S = (Qh @ Kh.transpose(-1, -2)) / dh ** 0.5
+    km = torch.tensor(m)[:, None, None, :]
+    S = torch.where(km, S, torch.full_like(S, OT.PADDING_NUM))
+    A = torch.softmax(S, -1)
+    A = torch.where(torch.tensor(m)[:, None, :, None], A, torch.full_like(A, OT.PADDING_NUM))
+    Oref = (A @ Vh).transpose(1, 2).reshape(B, T, d) + xt
+    (Oref * w).sum().backward()
+    gq = qkv.grad.double().cpu()
+    for name, g, r in (("dq", gq[..., :d], qt.grad), ("dk", gq[..., d:2 * d], kt.grad), ("dv", gq[..., 2 * d:], vt.grad),
+                       ("dx", xd.grad.double().cpu(), xt.grad)):
+        e = (g - r).abs().max().item() / (r.abs().max().item() + 1e-12)
+        assert e < 10 * tol, (name, e)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows,d", [(37, 80), (1000, 320), (5, 7), (64, 1024)])
+def test_layernorm_matches_oracle(cuda, dtype, tol, rows, d):
+    x = torch.tensor(_rand((rows, d), 1, 3.0), dtype=dtype)
+    g = torch.tensor(1.0 + 0.1 * _rand((d,), 2), dtype=torch.float32)
+    b = torch.tensor(0.1 * _rand((d,), 3), dtype=torch.float32)
+    ref = O.ln(x.double().numpy(), g.double().numpy(), b.double().numpy())
+    xd = x.to(cuda).requires_grad_(True)
+    gd = g.to(cuda).requires_grad_(True)
+    bd = b.to(cuda).requires_grad_(True)
+    y = ops.layer_norm(xd, gd, bd, 1e-8)
+    assert np.abs(y.detach().double().cpu().numpy() - ref).max() < tol * 5
+    w = torch.tensor(_rand((rows, d), 4), dtype=torch.float64)
+    (y.double() * w.to(cuda)).sum().backward()
+    xt = x.double().clone().requires_grad_(True); gt = g.double().clone().requires_grad_(True); bt = b.double().clone().requires_grad_(True)
+    (OT._ln(xt, gt, bt) * w).sum().backward()
+    for name, a, r in (("dx", xd.grad, xt.grad), ("dgamma", gd.grad, gt.grad), ("dbeta", bd.grad, bt.grad)):
+        e = (a.double().cpu() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
+        assert e < 20 * tol, (name, e)
+
+
+def test_loss_kernel_matches_oracle(cuda):
+    rng = np.random.default_rng(0)
+    B = 333
+    c = rng.standard_normal(B) * 3; o = rng.standard_normal(B) * 3 - 2; yb = rng.standard_normal(B)
+    c[:4] = [40.0, -40.0, 17.0, -17.0]      # saturate the clip branches of the keras cross entropy
+    cls = rng.integers(0, 5, size=B)
+    mask = np.zeros((B, 5), np.float32); mask[np.arange(B), cls] = 1
+    so = O.default_spec()
+    for method in ("two_head_add", "two_head_multiply"):
+        for rel in ("ctr_rel", "ctr"):
+            ref = O.loss_multi_task_unbias(((c.reshape(-1, 1), o.reshape(-1, 1)), yb.reshape(-1, 1)), mask, so, method, rel)
+            ct, ot, yt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (c, o, yb))
+            lt = OT.loss_unbias(((ct.reshape(-1, 1), ot.reshape(-1, 1)), yt.reshape(-1, 1)), mask, so, method, rel)
+            lt.backward()
+            cd, od, yd = (torch.tensor(a, dtype=torch.float32, device=cuda, requires_grad=True) for a in (c, o, yb))
+            wc = torch.tensor(so["weight_ctr"], dtype=torch.float32, device=cuda)
+            wo = torch.tensor(so["weight_ecvr"], dtype=torch.float32, device=cuda)
+            loss, pc, pv = ops.LossUnbiasFn.apply(cd, od, yd, torch.tensor(mask, device=cuda), wc, wo, so["loss_weight"],
+                                                  1 if method == "two_head_multiply" else 0, 1 if rel == "ctr_rel" else 0)
+            loss.backward()
+            assert abs(float(loss) - ref) / abs(ref) < 2e-5, (method, rel)
+            for a, r in ((cd.grad, ct.grad), (od.grad, ot.grad), (yd.grad, yt.grad)):
+                assert (a.double().cpu() - r).abs().max().item() < 2e-5 * max(1.0, r.abs().max().item())
+
+
+def test_auc_histogram_matches_tf_metrics_auc(cuda):
+    rng = np.random.default_rng(1)
+    B = 5000
+    pred = rng.random(B).astype(np.float32)
+    pred[:50] = np.round(pred[:50] * 199) / 199          # exactly on thresholds
+    label = (rng.random(B) < 0.2 + 0.5 * pred).astype(np.float32)
+    hist = torch.zeros(2 * 201, dtype=torch.int64, device=cuda)
+    L.call("dmt_auc_hist", B, ops.p(torch.tensor(pred, device=cuda)), ops.p(torch.tensor(label, device=cuda)), 200, ops.p(hist), ops.stream_ptr())
+    from cikm2020_dmt_amd.metrics import auc_from_hist
+    got = auc_from_hist(hist.cpu().numpy(), 200)
+    ref = O.tf_metrics_auc(label, pred, 200)
+    assert abs(got - ref) < 1e-9, (got, ref)
+
+
+def test_lazy_adam_is_bitwise_equal_to_dense_sweep(cuda):
+    """Size-independent property: replaying zero-gradient steps lazily == sweeping every row every step."""
+    from cikm2020_dmt_amd.variables import VariableStore
+    from cikm2020_dmt_amd.optim import TFAdam
+    from tests.util import small_specs
+    _so, sp = small_specs()
+    a = VariableStore(sp, cuda, torch.float32, seed=1)
+    b = VariableStore(sp, cuda, torch.float32, seed=1)
+    oa, ob = TFAdam(a), TFAdam(b)
+    rng = np.random.default_rng(0)
+    D = max(t.shape[1] for t in a.table.values())
+    for step in range(12):
+        n = int(rng.integers(1, 400))
+        rows = np.unique(rng.integers(0, a.total_rows, size=n)).astype(np.int32)
+        if step % 3 == 0:
+            rows = rows[rows % 7 == 0] if (rows % 7 == 0).any() else rows[:1]      # leave long gaps for most rows
+        g = rng.standard_normal((len(rows), D)).astype(np.float32) * 0.01
+        uniq = torch.tensor(rows, device=cuda)
+        gr = torch.tensor(g, device=cuda)
+        nu = torch.tensor([len(rows)], dtype=torch.int32, device=cuda)
+        oa.begin(); oa.apply_sparse((uniq, nu, gr, len(rows))); oa.end()
+        dense = {}
+        for name, (base, nr) in b.table_rows.items():
+            dim = b.tables[name].shape[1]
+            gd = np.zeros((nr, dim), np.float32)
+            sel = (rows >= base) & (rows < base + nr)
+            gd[rows[sel] - base] = g[sel][:, :dim]
+            dense[name] = torch.tensor(gd, device=cuda)
+        ob.begin(); ob.apply_dense_tables(dense); ob.end()
+    oa.flush_tables()
+    ob_p, oa_p = b.tab_p.cpu().numpy(), a.tab_p.cpu().numpy()
+    assert np.array_equal(oa_p.view(np.uint32), ob_p.view(np.uint32))
+    assert np.array_equal(a.tab_m.cpu().numpy().view(np.uint32), b.tab_m.cpu().numpy().view(np.uint32))
+    assert np.array_equal(a.tab_v.cpu().numpy().view(np.uint32), b.tab_v.cpu().numpy().view(np.uint32))
