@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Headline benchmark: DMT train step (forward + backward + TF-Adam) throughput in samples/s.
+
+Workload = BASELINE.json configs[1]: full DMT (3 target-as-query Transformers + MMoE + bias tower, 2 tasks), bf16
+compute, "emb_dim=64" (every id field 64 wide -> d_model 320, d_ff 1280, 4 heads of 80; SURVEY.md §8d "E64"),
+batch 4096 per GPU, sequences at full length 50/50/10, Zipf(1.05) ids over the reference vocabularies
+(5 M SKU rows), synthetic data resident in HBM.  A step = one pass of the hot path over one batch: index sort,
+lazy-Adam row catch-up, gather, Transformers, MMoE, heads, loss, backward, gradient exchange, optimizer.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md §Measurement for the roofline and cpu_baseline legs).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--dims", default="e64", choices=["e64", "ref"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--law", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from cikm2020_dmt_amd import ops
+    from cikm2020_dmt_amd import spec as S
+    from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+    from cikm2020_dmt_amd.train import Trainer
+
+    sp = S.e64_spec() if args.dims == "e64" else S.default_spec()
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234)
+    nb = 4
+    batches = []
+    for i in range(nb):
+        inputs, mask, label = make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law)
+        batches.append(tr.make_batch(inputs, mask, label))
+    del inputs
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        b = batches[i % nb]
+        b._prep = None          # every step re-sorts its indices, as a fresh batch would
+        return tr.train_step(b)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+
+    def agg(key):
+        ent = prof.get(key, [])
+        ms = sum(e0.elapsed_time(e1) for (e0, e1, _w) in ent)
+        return len(ent), ms * 1e-3, sum(w for (_a, _b, w) in ent)
+
+    gkey = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
+    n_g, t_g, fl_g = agg(gkey)
+    n_ga, t_ga, by_ga = agg("gather_fwd")
+    peak = 2500.0 if args.dtype == "bf16" else 157.3
+    roofline = {"kernel": "gemm_kernel<%s> (all QKV/FFN/MMoE/tower GEMMs fwd+bwd, %d launches/step)" % (args.dtype, n_g // max(args.steps, 1)),
+                "bound": "mfma", "achieved": round(fl_g / t_g / 1e12, 2) if t_g > 0 else None, "peak": peak, "unit": "TFLOP/s",
+                "frac": round(fl_g / t_g / 1e12 / peak, 4) if t_g > 0 else None, "traffic": None,
+                "avg_launch_us": round(t_g / max(n_g, 1) * 1e6, 2), "time_share": round(t_g / dt, 3)}
+    gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",
+              "achieved": round(by_ga / t_ga / 1e9, 1) if t_ga > 0 else None, "peak": 8000.0, "unit": "GB/s",
+              "frac": round(by_ga / t_ga / 8e12, 4) if t_ga > 0 else None, "avg_launch_us": round(t_ga / max(n_ga, 1) * 1e6, 2),
+              "bytes_per_launch": int(by_ga / max(n_ga, 1))}
+
+    out = {
+        "metric": "train samples/sec", "value": round(args.batch * world * args.steps / dt, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
+                               "per-GPU batch %d, L=50/50/10 full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows)"
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, args.law),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+        "roofline": roofline, "gather_roofline": gather, "final_loss": round(float(loss), 5),
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(sp, args)
+    print(json.dumps(out))
+
+
+def cpu_baseline(sp, args):
+    """The CPU oracle (independent torch restatement, fp32, all host cores) on a bounded sample of the same workload.
+    A reported baseline (stand-in for the TF1.12 CPU path, which cannot run here), not the optimisation target."""
+    from oracle import dmt_oracle as O
+    from oracle import dmt_oracle_torch as OT
+    from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+    import torch as th
+    so = dict(sp)
+    cores = os.cpu_count() or 1
+    th.set_num_threads(cores)
+    P = O.init_params(so, seed=1, dtype=np.float32)
+    trainer = OT.TorchTrainer(P, so, dtype=th.float32)
+    del P
+    inputs, mask, _l = make_batch(sp, args.cpu_batch, seed=7, lengths="full", law=args.law)
+    trainer.step(inputs, mask)           # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        trainer.step(inputs, mask)
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_batch * args.cpu_steps / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of batch %d (same model/dims/ids, fp32 torch-CPU restatement incl. dense TF-Adam over all tables)"
+                      % (args.cpu_steps, args.cpu_batch)}
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,33 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
   if (lane == 0) last_step[row] = step;
 }
 
+__global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
+                                                           float* __restrict__ v, int* __restrict__ last_step,
+                                                           const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
+                                                           const float* __restrict__ state, const float* __restrict__ lr_hist,
+                                                           float b1, float b2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= n_uniq[0]) return;
+  const int row = (int)uniq[u];
+  const int step = reinterpret_cast<const int*>(state)[3];
+  const int last = last_step[row];
+  if (last >= step) return;
+  const int t = find_table(tm, row);
+  const int dim = tm.dim[t];
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
+  for (int j = lane; j < dim; j += 64) {
+    const long long off = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim + j;
+    float pv = p[off], mv = m[off], vv = v[off];
+    if (mv != 0.f || vv != 0.f) {
+      catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
+      p[off] = pv; m[off] = mv; v[off] = vv;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) last_step[row] = step;
+}
+
 __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, int* __restrict__ last_step,
                                                          const float* __restrict__ state, const float* __restrict__ lr_hist,
@@ -148,6 +175,18 @@ extern "C" int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m,
   hipLaunchKernelGGL(adam_sparse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
                      grad_rows, max_dim, grad_scale, state, lr_hist, beta1, beta2, eps);
   DMT_CHECK_LAUNCH("dmt_adam_sparse_rows");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                                     const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* state,
+                                     const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
+  DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && state && lr_hist, "dmt_adam_catchup_rows: null argument");
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_catchup_rows: bad table map / max_uniq");
+  const unsigned nb = (unsigned)cdiv64(max_uniq, 4);
+  hipLaunchKernelGGL(adam_catchup_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
+                     state, lr_hist, beta1, beta2, eps);
+  DMT_CHECK_LAUNCH("dmt_adam_catchup_rows");
   return DMT_OK;
 }
 

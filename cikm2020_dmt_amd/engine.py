@@ -32,6 +32,7 @@ class DeviceBatch:
 
     def __init__(self, B, feats: Dict[str, FeatureColumn], dense, mask=None, label=None):
         self.B, self.feats, self.dense, self.mask, self.label = B, feats, dense, mask, label
+        self._prep = None
 
     @staticmethod
     def from_inputs(inputs: dict, spec: dict, device, mask=None, label=None, pad_to: Optional[Dict[str, int]] = None) -> "DeviceBatch":
@@ -150,7 +151,8 @@ class GatherFn(torch.autograd.Function):
         desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
         desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
         desc.out_dtype = ops.dt_code(cdt)
-        L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
+        with ops._Timed("gather_fwd", engine.gather_bytes(batch, seq_T)):
+            L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
         ctx.engine, ctx.batch, ctx.inv, ctx.seq_T = engine, batch, inv, seq_T
         ctx.pos_shapes = [tuple(pl.shape) for pl in pos_leaves]
         return (*X, tar, zbuf)
@@ -208,6 +210,24 @@ class DMTEngine:
         self.w_ctr = torch.tensor(spec["weight_ctr"], dtype=F32, device=dev)
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
+
+    def gather_bytes(self, batch, seq_T) -> float:
+        """Algorithmic HBM bytes of one gather launch: int32 indices read once, fp32 table rows for
+        the valid ids on both paths, outputs written once in the compute dtype (padded slots excluded)."""
+        esz = 4 if self.store.compute_dtype == F32 else 2
+        B = batch.B
+        total = 0.0
+        for it in self.plan.items:
+            col = batch.feats[it["feature"]]
+            npos = B * col.T
+            kinds = (1 if it["pooled_off"] >= 0 else 0) + (1 if it["seq_id"] >= 0 else 0)
+            total += npos * 4 + npos * it["dim"] * 4 * kinds
+            if it["pooled_off"] >= 0:
+                total += B * it["dim"] * esz
+        d = self.spec["d_model"]
+        total += sum(B * t * d * esz for t in seq_T) + B * d * esz
+        total += B * self.spec["feature_dimension"] * (4 + esz)
+        return total
 
     # ---- small helpers
     def _w(self, name) -> Weight:
@@ -342,7 +362,8 @@ class DMTEngine:
             self._ws[key] = t
         return t[:n].view(shape)
 
-    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz):
+    def _embgrad_desc(self, batch):
+        """Index-only part of the embedding-gradient descriptor (gradient pointers are filled in by backward)."""
         plan, store, spec = self.plan, self.store, self.spec
         desc = L.EmbGradDesc()
         desc.B, desc.n_features = batch.B, len(plan.items)
@@ -356,35 +377,54 @@ class DMTEngine:
             f.lens = col.lens.data_ptr()
             f.T = col.T
             f.pooled_off, f.seq_id, f.seq_off, f.group = it["pooled_off"], it["seq_id"], it["seq_off"], it["group"]
-            f.inv_wsum = inv[i].data_ptr()
             desc.row_base[i] = it["row_base"]
             desc.entry_base[i] = ebase
             kinds = (1 if it["pooled_off"] >= 0 else 0) + (1 if it["seq_id"] >= 0 else 0)
             ebase += kinds * batch.B * col.T
         desc.entry_base[len(plan.items)] = ebase
         desc.total_rows = store.total_rows
+        desc.d_model = spec["d_model"]
+        desc.seq_scale = float(spec["d_model"]) ** 0.5
+        return desc, ebase
+
+    def prepare(self, batch):
+        """Index-only preprocessing of a batch, done BEFORE the forward pass: the (table row, entry) pairs of every
+        id are stably sorted by row and segmented.  The distinct rows are (a) what the exact lazy Adam must catch up
+        before the gather reads them and (b) the segments of the backward reduction."""
+        prep = getattr(batch, "_prep", None)
+        if prep is not None:
+            return prep
+        desc, n = self._embgrad_desc(batch)
+        st = ops.stream_ptr()
+        dev = self.store.device
+        keys = self._buf("keys", (n,), torch.int32)
+        vals = self._buf("vals", (n,), torch.int32)
+        keys_s = torch.empty((n,), dtype=torch.int32, device=dev)
+        vals_s = torch.empty((n,), dtype=torch.int32, device=dev)
+        L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), ops.p(vals), st)
+        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n)
+        cap = min(n, self.store.total_rows)
+        prep = dict(desc=desc, n=n, keys_s=keys_s, vals_s=vals_s, seg=seg.clone(), uniq=uniq[:cap].clone(), n_uniq=n_uniq.clone(), cap=cap)
+        batch._prep = prep
+        return prep
+
+    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz):
+        plan = self.plan
+        prep = self.prepare(batch)
+        desc, n = prep["desc"], prep["n"]
+        for i in range(len(plan.items)):
+            desc.feat[i].inv_wsum = inv[i].data_ptr()
         for s in range(len(dX)):
             desc.dseq[s] = dX[s].data_ptr()
             desc.seq_T[s] = seq_T[s]
         desc.dtar = dtar.data_ptr()
         desc.dpooled, desc.ld_pooled = dz.data_ptr(), dz.stride(0)
-        desc.d_model = spec["d_model"]
-        desc.seq_scale = float(spec["d_model"]) ** 0.5
         desc.grad_dtype = ops.dt_code(dz.dtype)
-        n = ebase
-        st = ops.stream_ptr()
-        keys = self._buf("keys", (n,), torch.int32)
-        vals = self._buf("vals", (n,), torch.int32)
-        keys_s = self._buf("keys_s", (n,), torch.int32)
-        vals_s = self._buf("vals_s", (n,), torch.int32)
-        L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), ops.p(vals), st)
-        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n)
-        # at most min(n, total_rows) distinct rows
-        cap = min(n, store.total_rows)
-        grad_rows = self._buf("grad_rows", (cap, plan.max_dim), F32)
+        grad_rows = self._buf("grad_rows", (prep["cap"], plan.max_dim), F32)
         grad_rows.zero_()
-        L.call("dmt_embgrad_reduce", C.byref(desc), ops.p(keys_s), ops.p(vals_s), ops.p(seg), n, ops.p(grad_rows), plan.max_dim, st)
-        self.sparse = (uniq, n_uniq, grad_rows, cap)
+        L.call("dmt_embgrad_reduce", C.byref(desc), ops.p(prep["keys_s"]), ops.p(prep["vals_s"]), ops.p(prep["seg"]), n,
+               ops.p(grad_rows), plan.max_dim, ops.stream_ptr())
+        self.sparse = (prep["uniq"], prep["n_uniq"], grad_rows, prep["cap"])
 
     def sort_segments(self, keys, vals, keys_s, vals_s, n):
         """Stable sort of (row, entry) pairs + segment ids of equal rows."""

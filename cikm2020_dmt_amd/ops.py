@@ -16,6 +16,28 @@ from . import _lib as L
 
 F32, BF16 = torch.float32, torch.bfloat16
 
+# Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
+#   PROFILE = {"gemm": [], "gather": []}  ->  entries (start_event, end_event, algorithmic_work)
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, key, work):
+        self.key, self.work = key, work
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1, self.work))
+        return False
+
 
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -67,7 +89,8 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
     d.c_last = c_last.data_ptr() if c_last is not None else None
     d.split_k, d.batch = split_k, batch
     d.a_bs, d.b_bs, d.c_bs, d.bias_bs, d.gate_bs, d.resid_bs, d.clast_bs = a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs
-    L.call("dmt_gemm", C.byref(d), stream_ptr())
+    with _Timed("gemm_%s" % ("bf16" if A.dtype == BF16 else "f32"), 2.0 * M * N * K * max(batch, 1)):
+        L.call("dmt_gemm", C.byref(d), stream_ptr())
 
 
 def _pick_split(tiles: int, red: int) -> int:

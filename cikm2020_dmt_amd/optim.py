@@ -77,6 +77,13 @@ class TFAdam:
         self.end()
         self.store.refresh_shadows()
 
+    def catch_up(self, uniq, n_uniq, cap):
+        """Rows about to be gathered: replay their pending zero-gradient steps (through the last completed step)."""
+        s = self.store
+        L.call("dmt_adam_catchup_rows", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps,
+               ops.stream_ptr())
+
     def flush_tables(self):
         """Replay pending zero-gradient updates on every table row (before checkpoint / full-table export)."""
         s = self.store

