@@ -2,7 +2,7 @@
 //   bf16 operands: v_mfma_f32_32x32x16_bf16      fp32 operands: v_mfma_f32_32x32x2_f32 (exact fma chain)
 // Workgroup = 4 wavefronts (2x2), tile 128x128, each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 fp32 acc VGPRs).
 // Operands are staged global -> registers -> LDS as [row][k] (k contiguous, row stride BK + one 16-byte pad
-// so ds_read_b128 fragment reads are bank-conflict free); the next K tile's global loads are in flight
+// so ds_read_b128 fragment reads are bank-conflict free; bf16: BK = 64 = one full 128-byte line per row); the next K tile's global loads are in flight
 // while the current one is multiplied.  Either operand may be k-contiguous (vector LDS writes) or
 // row-contiguous (transposed on the LDS write, lanes along k => conflict-free 2-byte writes), so the same
 // kernel serves Y = X W^T-shadow, dX = dY W and dW = X^T dY (reduction over the strided dim of both).
@@ -16,8 +16,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr int BM = 128, BN = 128, NT = 256;
 
 template <typename T> struct Cfg;
-template <> struct Cfg<bf16_t> { static constexpr int EPV = 8, BK = 32, LDK = 40; };
-template <> struct Cfg<float>  { static constexpr int EPV = 4, BK = 16, LDK = 20; };
+template <> struct Cfg<bf16_t> { static constexpr int EPV = 8, BK = 64, LDK = 72, NV = 4; };   // 128 x 64 x 2 B / 16 B / 256 thr
+template <> struct Cfg<float>  { static constexpr int EPV = 4, BK = 16, LDK = 20, NV = 2; };
 
 struct GemmArgs {
   int M, N, K;
@@ -35,6 +35,7 @@ struct GemmArgs {
   int a_mode, b_mode;   // 0: k-contiguous vectors, 1: row-contiguous vectors, 2: scalar
   int k_per_split;
   int out_f32;
+  int vec_epi;
 };
 
 union Vec16 {
@@ -56,16 +57,37 @@ template <> __device__ __forceinline__ bf16_t vget<bf16_t>(const Vec16& v, int i
 
 // Load this thread's two 16-byte pieces of a [128 rows] x [BK] operand tile.
 //   elem(r, k) = P[r*rs + k*cs];  rows >= R_real read as 0 (or 1 for the ones row), k >= k_end read as 0.
-template <typename T>
-__device__ __forceinline__ void load_tile(Vec16 (&reg)[2], const T* __restrict__ P, long long rs, long long cs, int mode,
+// MODE 0: k contiguous (cs == 1), 16-byte vectors along k;  MODE 1: rows contiguous (rs == 1), vectors along rows,
+// lanes along k;  MODE 2: arbitrary strides, scalar loads.  All register indexing is compile-time (no scratch).
+template <typename T, int MODE, bool GUARD>
+__device__ __forceinline__ void load_tile(Vec16 (&reg)[Cfg<T>::NV], const T* __restrict__ P, long long rs, long long cs,
                                           int row0, int k0, int R_real, int k_end, int ones_row, int tid) {
   constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK;
+  if constexpr (!GUARD) {
+    // interior tile, full k-step: no predicates at all in the hot loop
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < Cfg<T>::NV; ++p) {
+      const int v = tid + p * NT;
+      if constexpr (MODE == 0) {
+        reg[p].u = *reinterpret_cast<const uint4*>(P + (long long)(row0 + v / (BK / EPV)) * rs + (k0 + (v % (BK / EPV)) * EPV));
+      } else if constexpr (MODE == 1) {
+        reg[p].u = *reinterpret_cast<const uint4*>(P + (long long)(k0 + (v % BK)) * cs + (row0 + (v / BK) * EPV));
+      } else {
+        const T* src = P + (long long)(row0 + v / (BK / EPV)) * rs + (long long)(k0 + (v % (BK / EPV)) * EPV) * cs;
+        Vec16 x;
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) vset<T>(x, i, src[(long long)i * cs]);
+        reg[p] = x;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < Cfg<T>::NV; ++p) {
     const int v = tid + p * NT;
     Vec16 x;
     x.u = make_uint4(0u, 0u, 0u, 0u);
-    if (mode == 0) {
+    if constexpr (MODE == 0) {
       const int r = row0 + v / (BK / EPV);
       const int k = k0 + (v % (BK / EPV)) * EPV;
       if (r < R_real) {
@@ -82,7 +104,7 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[2], const T* __restrict__
         for (int i = 0; i < EPV; ++i)
           if (k + i < k_end) vset<T>(x, i, one_val<T>());
       }
-    } else if (mode == 1) {
+    } else if constexpr (MODE == 1) {
       const int k = k0 + (v % BK);
       const int r = row0 + (v / BK) * EPV;
       if (k < k_end) {
@@ -94,7 +116,9 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[2], const T* __restrict__
           for (int i = 0; i < EPV; ++i)
             if (r + i < R_real) vset<T>(x, i, src[i]);
         }
-        if (ones_row >= r && ones_row < r + EPV) vset<T>(x, ones_row - r, one_val<T>());
+#pragma unroll
+        for (int i = 0; i < EPV; ++i)
+          if (r + i == ones_row) vset<T>(x, i, one_val<T>());
       }
     } else {
       const int r = row0 + v / (BK / EPV);
@@ -111,13 +135,13 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[2], const T* __restrict__
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)[2], int mode, int tid) {
+template <typename T, int MODE>
+__device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)[Cfg<T>::NV], int tid) {
   constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < Cfg<T>::NV; ++p) {
     const int v = tid + p * NT;
-    if (mode == 1) {
+    if constexpr (MODE == 1) {
       const int k = v % BK;
       const int r = (v / BK) * EPV;
 #pragma unroll
@@ -130,11 +154,18 @@ __device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)
   }
 }
 
-template <typename T>
+constexpr int EPI_LD = 68;                       // fp32 words per staged epilogue row (64 + 4 pad)
+constexpr int EPI_WAVE_WORDS = 32 * EPI_LD;      // one wave stages 32 rows x 64 cols at a time
+constexpr int SMEM_BYTES_OPER = 2 * BM * 72 * 2; // As + Bs (bf16: 128*72*2 B each; fp32: 128*20*4 B each)
+constexpr int SMEM_BYTES_EPI = 4 * EPI_WAVE_WORDS * 4;
+constexpr int SMEM_BYTES = SMEM_BYTES_OPER > SMEM_BYTES_EPI ? SMEM_BYTES_OPER : SMEM_BYTES_EPI;
+
+template <typename T, int AMODE, int BMODE>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   constexpr int BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
-  __shared__ __attribute__((aligned(16))) T As[BM * LDK];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  T* As = reinterpret_cast<T*>(smem);
+  T* Bs = As + BM * LDK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -146,6 +177,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int k_begin = ks * g.k_per_split;
   const int k_end = (k_begin + g.k_per_split < g.K) ? (k_begin + g.k_per_split) : g.K;
+  if (k_begin >= k_end && g.split_k > 1) return;
 
   const T* A = reinterpret_cast<const T*>(g.A) + (long long)bt * g.a_bs;
   const T* Bp = reinterpret_cast<const T*>(g.B) + (long long)bt * g.b_bs;
@@ -160,20 +192,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Vec16 ra[2], rb[2];
-  if (k_begin < k_end) {
-    load_tile<T>(ra, A, g.a_rs, g.a_cs, g.a_mode, m0, k_begin, M_real, k_end, ones_row, tid);
-    // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
-    load_tile<T>(rb, Bp, g.b_cs, g.b_rs, g.b_mode, n0, k_begin, g.N, k_end, -1, tid);
-  }
+  Vec16 ra[Cfg<T>::NV], rb[Cfg<T>::NV];
+  const bool a_full = (m0 + BM <= M_real), b_full = (n0 + BN <= g.N);   // block-uniform
+  // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
+  auto load_both = [&](int kq) {
+    const bool kfull = (kq + BK <= k_end);
+    if (a_full && kfull) load_tile<T, AMODE, false>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
+    else load_tile<T, AMODE, true>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
+    if (b_full && kfull) load_tile<T, BMODE, false>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
+    else load_tile<T, BMODE, true>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
+  };
+  load_both(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    store_tile<T>(As, ra, g.a_mode, tid);
-    store_tile<T>(Bs, rb, g.b_mode, tid);
+    store_tile<T, AMODE>(As, ra, tid);
+    store_tile<T, BMODE>(Bs, rb, tid);
     __syncthreads();
-    if (k0 + BK < k_end) {
-      load_tile<T>(ra, A, g.a_rs, g.a_cs, g.a_mode, m0, k0 + BK, M_real, k_end, ones_row, tid);
-      load_tile<T>(rb, Bp, g.b_cs, g.b_rs, g.b_mode, n0, k0 + BK, g.N, k_end, -1, tid);
-    }
+    if (k0 + BK < k_end) load_both(k0 + BK);
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
@@ -207,12 +241,81 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
     }
     __syncthreads();
   }
-  if (k_begin >= k_end && g.split_k > 1) return;
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const float* bias = g.bias ? g.bias + (long long)bt * g.bias_bs : nullptr;
   const T* gate = g.gate ? reinterpret_cast<const T*>(g.gate) + (long long)bt * g.gate_bs : nullptr;
   const bool add_bias = (bias != nullptr) && (ks == 0);
+
+  if constexpr (sizeof(T) == 2) {
+    if (g.vec_epi) {
+      // bf16 output, 16-byte aligned rows: stage 32 x 64 fp32 per wave in LDS (the operand tiles are dead), then
+      // every lane finishes 8 consecutive columns: vector gate / residual loads and ONE 16-byte store per row piece.
+      float* Cw = reinterpret_cast<float*>(smem) + wave * EPI_WAVE_WORDS;
+      const bf16_t* resid = g.resid ? reinterpret_cast<const bf16_t*>(g.resid) + (long long)bt * g.resid_bs : nullptr;
+      bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs;
+      const int cbase = n0 + wn * 64;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cl = j * 32 + (lane & 31);
+          const int col = cbase + cl;
+          const float bv = (add_bias && col < g.N) ? bias[col] : 0.f;
+          const bool relu = col < g.act_ncols;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = acc[i][j][r] + bv;
+            if (relu) x = fmaxf(x, 0.f);
+            Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + cl] = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int rbase = m0 + wm * 64 + i * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = it * 8 + (lane >> 3);
+          const int cl = (lane & 7) * 8;
+          const int row = rbase + rl, col = cbase + cl;
+          if (row < g.M && col < g.N) {
+            float x[8];
+            const float4 lo = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl]);
+            const float4 hi = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl + 4]);
+            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+            if (col + 8 <= g.N) {
+              if (gate) {
+                Vec16 gv; gv.u = *reinterpret_cast<const uint4*>(gate + (long long)row * g.ldg + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (!(bf2f(gv.h[e]) > 0.f)) x[e] = 0.f;
+              }
+              if (resid) {
+                Vec16 rv; rv.u = *reinterpret_cast<const uint4*>(resid + (long long)row * g.ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += bf2f(rv.h[e]);
+              }
+              Vec16 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o.h[e] = f2bf(x[e]);
+              *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o.u;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (col + e < g.N) {
+                  float y = x[e];
+                  if (gate && !(bf2f(gate[(long long)row * g.ldg + col + e]) > 0.f)) y = 0.f;
+                  if (resid) y += bf2f(resid[(long long)row * g.ldr + col + e]);
+                  Cg[(long long)row * g.ldc + col + e] = f2bf(y);
+                }
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
+
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -248,6 +351,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
       }
     }
   }
+}
+
+template <typename T>
+void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
+#define DMT_GEMM_CASE(AM, BMo) \
+  if (g.a_mode == AM && g.b_mode == BMo) { hipLaunchKernelGGL((gemm_kernel<T, AM, BMo>), grid, dim3(NT), 0, st, g); return; }
+  DMT_GEMM_CASE(0, 0) DMT_GEMM_CASE(0, 1) DMT_GEMM_CASE(0, 2)
+  DMT_GEMM_CASE(1, 0) DMT_GEMM_CASE(1, 1) DMT_GEMM_CASE(1, 2)
+  DMT_GEMM_CASE(2, 0) DMT_GEMM_CASE(2, 1) DMT_GEMM_CASE(2, 2)
+#undef DMT_GEMM_CASE
 }
 
 int pick_mode(const void* P, long long rs, long long cs, int esz, int epv) {
@@ -287,7 +400,7 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   g.out_f32 = (d->out_dtype == DMT_F32);
   const int esz = d->in_dtype == DMT_F32 ? 4 : 2;
   const int epv = 16 / esz;
-  const int bk = d->in_dtype == DMT_F32 ? 16 : 32;
+  const int bk = d->in_dtype == DMT_F32 ? 16 : 64;
   g.a_mode = pick_mode(d->A, d->a_rs, d->a_cs, esz, epv);
   if (g.a_mode != 2 && batch > 1 && (d->a_bs % epv != 0)) g.a_mode = 2;
   // B rows in LDS are n: row stride b_cs, k stride b_rs
@@ -299,10 +412,11 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   dim3 grid((unsigned)((d->N + BN - 1) / BN), (unsigned)((d->M + BM - 1) / BM), (unsigned)(batch * split));
   DMT_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "dmt_gemm: grid too large (M=%d batch*split=%d)", d->M, batch * split);
   hipStream_t st = (hipStream_t)stream;
-  if (d->in_dtype == DMT_F32)
-    hipLaunchKernelGGL((gemm_kernel<float>), grid, dim3(NT), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_kernel<bf16_t>), grid, dim3(NT), 0, st, g);
+  // vectorised epilogue: bf16 in/out, no split / ones row, every row of C / gate / resid 16-byte aligned
+  auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };
+  g.vec_epi = (d->in_dtype == DMT_BF16 && d->out_dtype == DMT_BF16 && split == 1 && !d->a_ones_row && al16(d->C, d->ldc, d->c_bs) &&
+               al16(d->gate, d->ldg, d->gate_bs) && al16(d->resid, d->ldr, d->resid_bs)) ? 1 : 0;
+  if (d->in_dtype == DMT_F32) launch_gemm<float>(g, grid, st); else launch_gemm<bf16_t>(g, grid, st);
   DMT_CHECK_LAUNCH("dmt_gemm");
   return DMT_OK;
 }
