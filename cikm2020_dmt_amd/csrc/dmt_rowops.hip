@@ -104,13 +104,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(long long rows, int d, cons
   }
 }
 
+// One wavefront per column: lanes stride over the per-block partials, then a shuffle reduction (deterministic order).
 __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(int nblk, int d, const float* __restrict__ partials,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= 2 * d) return;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partials[(long long)b * 2 * d + c];
-  if (c < d) dgamma[c] += s; else dbeta[c - d] += s;
+  for (int b = lane; b < nblk; b += 64) s += partials[(long long)b * 2 * d + c];
+  s = wave_sum(s);
+  if (lane == 0) { if (c < d) dgamma[c] += s; else dbeta[c - d] += s; }
 }
 
 // ------------------------------------------------------------------------------------------ MMoE mix
@@ -401,7 +404,7 @@ extern "C" int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x,
                          (long long)ldx, gamma, stats, (const bf16_t*)dy, (long long)lddy, (bf16_t*)dx, (long long)lddx, partials);
       return 0; });
   if (rc != 0) { dmt_set_error("dmt_ln_bwd: d=%d > 1024 unsupported", d); return DMT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 3) / 4), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
   DMT_CHECK_LAUNCH("dmt_ln_bwd");
   return DMT_OK;
 }

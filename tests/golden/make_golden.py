@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures under tests/golden/ IN THIS CONTAINER (needs /root/reference, read-only).
+
+What comes from the reference itself:
+  * conf_golden.json   -- the reference's own parsing helpers (conf/recsys_conf.py: Conf.get_emb,
+                          get_attention_embed_v2, get_attention_embed_ts; util/util.py: parse_weight, csv_to_*)
+                          applied to its conf/settings/dmt.conf (the helpers are called unbound; Conf() itself is not
+                          instantiated because it creates directories under ~).
+  * demo474.npz        -- the 474 examples of jd_recsys_demo/*/test_ord/*/data/part-r-0000{0,1} at the
+                          post-vocabulary-lookup boundary: vocabularies from the reference's conf/idtables/*.py
+                          (Sku.py is missing upstream -> every SKU is an OOV hash bucket), feature names
+                          ord_seq_*_12m_10.
+  * lookup_golden.json -- raw id strings of a few features with the indices the lookup assigned.
+What comes from the oracle (the reference has NO golden outputs, SURVEY.md F14 -> parity unpinned):
+  * expected64.npz     -- logits / loss / gradient digests of oracle/dmt_oracle.py on the first 64 examples with
+                          seeded weights, and a 100-step B=256 training run of oracle/dmt_oracle_torch.py (float64)
+                          over the 474 examples (BASELINE.json configs[0]): loss curve, final AUCs.
+Large vocabularies are COMPACTED for the expected values: per vocabulary, the sorted set S = {idx} U {idx-1} U {0}
+of rows the data touches is renumbered 0..|S|-1 (adjacent rows stay adjacent, so the zero-pad offset idx-1 of the
+Transformer path is preserved); tests apply the same renumbering (tests/golden_util.py).
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from cikm2020_dmt_amd.conf.recsys_conf import Conf  # noqa: E402
+from cikm2020_dmt_amd.data_feed import tfrecord  # noqa: E402
+from cikm2020_dmt_amd.data_feed.index_tables import LookupTables  # noqa: E402
+from cikm2020_dmt_amd.sparse import SparseTensorValue  # noqa: E402
+from tests.golden_util import compact_inputs, load_demo, build_inputs, batch_slice, train_schedule  # noqa: E402
+
+
+def conf_golden():
+    import configparser
+    sys.path.insert(0, REF + "/DMT_code/util")
+    sys.path.insert(0, REF + "/DMT_code/conf")
+    import recsys_conf as ref_conf   # the reference module (imports only configparser + util)
+    import util as ref_util
+    cp = configparser.ConfigParser()
+    cp.read(REF + "/DMT_code/conf/settings/dmt.conf")
+    C = ref_conf.Conf
+    emb = cp.get("embedding", "emb")
+    g = dict(
+        embedding_list=C.get_emb(None, emb),
+        embedding_list_bias=C.get_emb(None, cp.get("embedding", "emb_bias")),
+        attention_embed_pairs=C.get_attention_embed_v2(None, cp.get("embedding", "attention_embed")),
+        attention_embed_seq_ts=C.get_attention_embed_ts(None, cp.get("embedding", "attention_embed_seq_ts")),
+        weight_ctr=ref_util.parse_weight(cp.get("class_weight", "weight_ctr")),
+        weight_ecvr=ref_util.parse_weight(cp.get("class_weight", "weight_ecvr")),
+        hidden_units_bottom=ref_util.csv_to_int_list(cp.get("model", "hidden_units_bottom")),
+        hidden_units_task=ref_util.csv_to_int_list(cp.get("model", "hidden_units_task")),
+        hidden_units_bias=ref_util.csv_to_int_list(cp.get("model", "hidden_units_bias")),
+        loss_weight=ref_util.csv_to_float_list(cp.get("parameter", "loss_weight")),
+        model=dict((k, cp.get("model", k)) for k in ("model_type", "feature_dimension", "num_experts", "transformer_d_model",
+                                                     "transformer_d_ff", "transformer_num_heads", "transformer_maxlen_k",
+                                                     "transformer_position_encoding_method", "zero_pad", "learning_rate",
+                                                     "step_boundary", "loss_unbias_method", "loss_ctr_rel_method")),
+    )
+    json.dump(g, open(os.path.join(OUT, "conf_golden.json"), "w"), indent=1, sort_keys=True)
+    return g
+
+
+def demo_fixture():
+    conf = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt_demo.conf")
+    tables = LookupTables(conf, idtables_dir=REF + "/DMT_code/conf/idtables")
+    files = sorted(glob.glob(REF + "/jd_recsys_demo/*/test_ord/*/data/part-r-*"))
+    feats = conf.get_idschema() + [f for f in conf.get_idschema_bias() if f not in conf.get_idschema()]
+    cols = {f: [] for f in feats}
+    wcols = {f: [] for f in feats}
+    dense, mask, label = [], [], []
+    raw_keep = {f: [] for f in ("item_brand", "item_shop", "item_fea_sku", "clk_seq_c3_7d_50", "cart_seq_ts_12m_10")}
+    for fn in files:
+        for rec in tfrecord.read_records(fn, verify_crc=True):
+            ex = tfrecord.decode_example(rec)
+            dense.append(ex["features"])
+            mask.append(ex["mask"])
+            label.append(ex["label"][0])
+            for f in feats:
+                cols[f].append(ex[f])
+                wcols[f].append(np.asarray(ex[f + "Wts"], np.float32))
+            for f in raw_keep:
+                if len(raw_keep[f]) < 40:
+                    raw_keep[f].append([b.decode() for b in ex[f]])
+    n = len(dense)
+    out = dict(features=np.stack(dense).astype(np.float32), mask=np.stack(mask).astype(np.float32), label=np.array(label, np.float32))
+    lookup_golden = {}
+    for f in feats:
+        raw = SparseTensorValue.from_rows(cols[f], object)
+        d = {f: raw}
+        tables.transform_id2index(d)
+        out["v_" + f] = d[f].values.astype(np.int32)
+        out["l_" + f] = d[f].lengths().astype(np.int16)
+        w = np.concatenate(wcols[f])
+        assert len(w) == len(d[f].values)
+        if not np.all(w == 1.0):
+            out["w_" + f] = w
+        if f in raw_keep:
+            rows = d[f].rows()
+            lookup_golden[f] = dict(raw=raw_keep[f], idx=[[int(x) for x in r] for r in rows[:len(raw_keep[f])]])
+    np.savez_compressed(os.path.join(OUT, "demo474.npz"), **out)
+    json.dump(lookup_golden, open(os.path.join(OUT, "lookup_golden.json"), "w"))
+    print("demo fixture:", n, "examples", os.path.getsize(os.path.join(OUT, "demo474.npz")), "bytes")
+
+
+def expected():
+    from oracle import dmt_oracle as O
+    from oracle import dmt_oracle_torch as OT
+    import torch
+    demo = load_demo()
+    spec_full = O.default_spec("12m_10")
+    inputs_all, comp = compact_inputs(build_inputs(demo, spec_full), spec_full)
+    so = O.scaled_spec(spec_full, comp["rows"])
+    P = O.init_params(so, seed=2020)
+    out = {}
+    # ---- (1) forward / loss / gradient digests on the first 64 examples
+    inp64, m64 = batch_slice(inputs_all, demo["mask"], np.arange(64), so)
+    (c, o), yb = O.inference(inp64, P, so)
+    out["click_logit"], out["order_logit"], out["y_bias"] = c, o, yb
+    out["loss"] = np.array(O.loss_multi_task_unbias(((c, o), yb), m64, so))
+    loss_t, _lg, G = OT.loss_and_grads(P, inp64, m64, so)
+    assert abs(loss_t - float(out["loss"])) < 1e-12
+    names = sorted(G)
+    out["grad_names"] = np.array(names)
+    out["grad_l2"] = np.array([np.linalg.norm(G[k]) for k in names])
+    out["grad_sum"] = np.array([G[k].sum() for k in names])
+    # ---- (2) BASELINE.json configs[0]: 100 train steps, batch 256, over the 474 demo examples (float64, dropout off)
+    tr = OT.TorchTrainer(P, so, lr=1e-3, dtype=torch.float64)
+    losses = []
+    for ids in train_schedule(len(demo["label"]), 256, 100):
+        inp, m = batch_slice(inputs_all, demo["mask"], ids, so)
+        l, _ = tr.step(inp, m)
+        losses.append(l)
+        if len(losses) % 20 == 0:
+            print("step", len(losses), "loss", l)
+    out["train_loss_curve"] = np.array(losses)
+    with torch.no_grad():
+        inp, m = batch_slice(inputs_all, demo["mask"], np.arange(len(demo["label"])), so)
+        (c2, o2), yb2 = OT.forward(tr.P, inp, so)
+    p_ctr = torch.sigmoid(c2 + yb2).numpy().reshape(-1)
+    p_cvr = torch.sigmoid(o2 + yb2).numpy().reshape(-1)
+    y_clk = demo["mask"][:, 1:5].sum(-1)
+    y_ord = demo["mask"][:, 3] + demo["mask"][:, 4]
+    out["final_p_ctr"], out["final_p_cvr"] = p_ctr, p_cvr
+    out["final_auc"] = np.array([O.exact_auc(y_clk, p_ctr), O.exact_auc(y_ord, p_cvr), O.tf_metrics_auc(y_clk, p_ctr), O.tf_metrics_auc(y_ord, p_cvr)])
+    print("final AUC (exact ctr, exact cvr, tf ctr, tf cvr):", out["final_auc"])
+    np.savez_compressed(os.path.join(OUT, "expected64.npz"), **out)
+
+
+if __name__ == "__main__":
+    conf_golden()
+    demo_fixture()
+    expected()

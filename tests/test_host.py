@@ -1,0 +1,142 @@
+"""Host-side logic: TFRecord codec, vocabulary lookup + FarmHash, Conf parser against the reference's own parse
+(golden), spec equality with the oracle, batches, variable inventory."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cikm2020_dmt_amd import spec as S
+from cikm2020_dmt_amd.conf.recsys_conf import Conf
+from cikm2020_dmt_amd.data_feed import tfrecord
+from cikm2020_dmt_amd.data_feed.farmhash import fingerprint64, to_hash_bucket_fast
+from cikm2020_dmt_amd.data_feed.index_tables import LookupTables
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from cikm2020_dmt_amd.engine import DeviceBatch, _GatherPlan
+from cikm2020_dmt_amd.sparse import SparseTensorValue
+from cikm2020_dmt_amd.variables import VariableStore
+from oracle import dmt_oracle as O
+from tests import golden_util as GU
+from tests.util import small_specs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tfrecord_roundtrip_and_crc(tmp_path):
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283          # CRC-32C check value
+    ex = {"label": np.array([1.0], np.float32), "mask": np.arange(5, dtype=np.float32), "header": [b"a\tb"],
+          "clk_seq_sku_7d_50": [b"123", b"unknow"], "clk_seq_sku_7d_50Wts": np.array([1.0, 2.0], np.float32),
+          "cnt": np.array([3, -1, 1 << 40], np.int64), "empty": []}
+    p = str(tmp_path / "x.tfrecord")
+    assert tfrecord.write_records(p, [tfrecord.encode_example(ex)] * 3) == 3
+    recs = list(tfrecord.read_records(p, verify_crc=True))
+    assert len(recs) == 3
+    back = tfrecord.decode_example(recs[1])
+    assert back["header"] == [b"a\tb"] and back["clk_seq_sku_7d_50"] == [b"123", b"unknow"]
+    assert np.array_equal(back["mask"], ex["mask"]) and np.array_equal(back["cnt"], ex["cnt"])
+    raw = bytearray(open(p, "rb").read()); raw[20] ^= 0xFF
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        list(tfrecord.read_records(p, verify_crc=True))
+
+
+def test_farmhash_known_answers():
+    # tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]   (TensorFlow API docs)
+    assert [to_hash_bucket_fast(s, 3) for s in (b"Hello", b"TensorFlow", b"2.x")] == [0, 2, 2]
+    assert fingerprint64(b"") == 0x9AE16A3B2F90404F           # HashLen0to16 of the empty string is k2
+    for n in (1, 3, 4, 7, 8, 16, 17, 32, 33, 64, 65, 200):    # every length class runs and stays within 64 bits
+        assert 0 <= fingerprint64(b"x" * n) < (1 << 64)
+
+
+def test_lookup_tables_against_golden_and_semantics():
+    g = json.load(open(os.path.join(GU.GOLDEN, "lookup_golden.json")))
+    conf = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt_demo.conf")
+    # Sku has no vocabulary upstream: every id hashes into [1, 5e6)
+    t = LookupTables(conf, id_tables={})
+    for raw, idx in zip(g["item_fea_sku"]["raw"], g["item_fea_sku"]["idx"]):
+        assert list(t.inf_transform("item_fea_sku", raw)) == idx
+        assert all(1 <= i < 5000000 for i in idx)
+    # Time tables have 23 == id_size entries -> no OOV buckets -> default 0
+    tt = LookupTables(conf, id_tables={"TimeCart": ["unknow"] + [str(i) for i in range(22)]})
+    assert list(tt.inf_transform("cart_seq_ts_12m_10", ["unknow", "3", "6648465"])) == [0, 4, 0]
+    # in-vocabulary ids map to their position
+    tb = LookupTables(conf, id_tables={"Brand": ["unknow", "184144", "7"]})
+    out = tb.inf_transform("item_brand", ["7", "unknow", "184144", "999"])
+    assert list(out[:3]) == [2, 0, 1] and 3 <= out[3] < 190000
+
+
+def test_conf_parser_matches_the_reference_parse():
+    g = json.load(open(os.path.join(GU.GOLDEN, "conf_golden.json")))
+    conf = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
+    assert [list(e) for e in conf.embedding_list] == g["embedding_list"]
+    assert [list(e) for e in conf.embedding_list_bias] == g["embedding_list_bias"]
+    assert [[list(p) for p in grp] for grp in conf.attention_embed_pairs] == g["attention_embed_pairs"]
+    assert conf.attention_embed_seq_ts == g["attention_embed_seq_ts"]
+    assert conf.weight_ctr == g["weight_ctr"] and conf.weight_ecvr == g["weight_ecvr"]
+    sp = conf.to_spec()
+    assert sp["hidden_units_bottom"] == g["hidden_units_bottom"] and sp["hidden_units_task"] == g["hidden_units_task"]
+    assert sp["d_model"] == int(g["model"]["transformer_d_model"]) and sp["d_ff"] == int(g["model"]["transformer_d_ff"])
+    assert conf.zero_pad == g["model"]["zero_pad"] == "true"
+
+
+def test_product_spec_equals_oracle_spec():
+    for suffix in ("12m_50", "12m_10"):
+        so, sp = O.default_spec(suffix), S.default_spec(suffix)
+        for k in so:
+            a, b = so[k], sp[k]
+            if k in ("embedding_list", "embedding_list_bias"):
+                a, b = [tuple(x) for x in a], [tuple(x) for x in b]
+            if k == "attention_embed_pairs":
+                a, b = [[tuple(p) for p in g] for g in a], [[tuple(p) for p in g] for g in b]
+            assert a == b, k
+    e = S.e64_spec()
+    assert e["d_model"] == 320 and e["d_ff"] == 1280 and S.mmoe_input_width(e) == 615 + 5 * 64 + 3 * 6 * 64 + 3 * 320
+
+
+def test_variable_inventory_matches_appendix_b():
+    so, sp = small_specs()
+    st = VariableStore(sp, "cpu", torch.float32, seed=0)
+    sd = st.state_dict()
+    shp = O.param_shapes(so)
+    assert set(sd) == set(shp)
+    for k, v in shp.items():
+        assert tuple(sd[k].shape) == tuple(v), k
+    assert st.P >= 3418515 - 166883052 * 0        # dense parameter count of SURVEY.md Appendix B fits the arena
+    P = O.init_params(so, seed=3)
+    st.load_state(P)
+    back = st.state_dict()
+    assert max(np.abs(back[k] - P[k].astype(np.float32)).max() for k in P) == 0.0
+    # packed leaves really are contiguous views
+    w = st.leaf["mmoe_layers/l0_cat_weights"]
+    assert w.shape == (1199, 4 * 512 + 8) and w.is_contiguous()
+    plan = _GatherPlan(sp, st)
+    assert (plan.K, plan.interest_off, plan.bias_off, plan.ldz) == (1199, 959, 1200, 1224)
+
+
+def test_sparse_and_device_batch_layout():
+    sp_ = SparseTensorValue.from_rows([[5, 6, 7], [], [9]], np.int64)
+    assert sp_.dense_shape == (3, 3) and list(sp_.lengths()) == [3, 0, 1]
+    dense, lens = sp_.to_padded(4)
+    assert dense.tolist() == [[5, 6, 7, 0], [0, 0, 0, 0], [9, 0, 0, 0]]
+    _so, sp = small_specs()
+    inputs, mask, label = make_batch(sp, 9, seed=1, lengths="ragged", weights="random")
+    b = DeviceBatch.from_inputs(inputs, sp, "cpu", mask, label)
+    col = b.feats["clk_seq_sku_7d_50"]
+    assert col.idx.dtype == torch.int32 and col.idx.shape == (9, col.T) and col.wts is not None
+    ref_lens = inputs["clk_seq_sku_7d_50"].lengths()
+    assert col.lens.tolist() == ref_lens.tolist()
+    for r in range(9):                                   # left aligned, zero padded
+        assert (col.idx[r, ref_lens[r]:] == 0).all()
+    inputs2, _, _ = make_batch(sp, 4, seed=1, lengths="full", weights="ones")
+    b2 = DeviceBatch.from_inputs(inputs2, sp, "cpu")
+    assert b2.feats["ord_seq_sku_12m_50"].wts is None and b2.feats["ord_seq_sku_12m_50"].T == 50
+
+
+def test_demo_fixture_shape_facts():
+    demo = GU.load_demo()
+    assert demo["features"].shape == (474, 615) and demo["mask"].shape == (474, 5)
+    cls = demo["mask"].argmax(1)
+    assert np.bincount(cls, minlength=5).tolist() == [434, 1, 21, 4, 14]       # SURVEY.md §8c label distribution
+    assert demo["l_clk_seq_sku_7d_50"].max() == 50 and demo["l_ord_seq_sku_12m_10"].max() == 10
+    assert demo["l_clk_seq_sku_7d_50"].min() >= 1

@@ -1,0 +1,111 @@
+"""CPU tests of the oracle itself: the two independent restatements agree, gradients match finite differences,
+the committed expected values are reproduced, and the TF-metric restatements behave."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmt_oracle as O
+from oracle import dmt_oracle_torch as OT
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from tests.util import small_specs
+from tests import golden_util as GU
+
+
+def test_numpy_and_torch_restatements_agree():
+    so, sp = small_specs()
+    P = O.init_params(so, seed=1)
+    rng = np.random.default_rng(0)
+    for k in P:
+        if k.endswith("/gamma") or k.endswith("/beta") or k.endswith("/bias"):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+    inputs, mask, _ = make_batch(sp, 6, seed=3, lengths="ragged", weights="random")
+    (c, o), yb = O.inference(inputs, P, so)
+    out = OT.forward(OT.to_torch(P), inputs, so)
+    assert np.abs(c - out[0][0].detach().numpy()).max() < 1e-12
+    assert np.abs(o - out[0][1].detach().numpy()).max() < 1e-12
+    assert np.abs(yb - out[1].detach().numpy()).max() < 1e-12
+    l_np = O.loss_multi_task_unbias(((c, o), yb), mask, so)
+    l_t = float(OT.loss_unbias(out, mask, so).detach())
+    assert abs(l_np - l_t) < 1e-12
+    for method in ("two_head_add", "two_head_multiply"):
+        for rel in ("ctr", "ctr_rel"):
+            a = O.loss_multi_task_unbias(((c, o), yb), mask, so, method, rel)
+            b = float(OT.loss_unbias(out, mask, so, method, rel).detach())
+            assert abs(a - b) < 1e-12
+
+
+def test_autograd_gradients_match_finite_differences():
+    so, sp = small_specs()
+    P = O.init_params(so, seed=4)
+    inputs, mask, _ = make_batch(sp, 3, seed=5, lengths="ragged", weights="random")
+    _loss, _lg, G = OT.loss_and_grads(P, inputs, mask, so)
+
+    def f(Pq):
+        return O.loss_multi_task_unbias(O.inference(inputs, Pq, so), mask, so)
+
+    rng = np.random.default_rng(1)
+    names = [n for n in sorted(P) if np.abs(G[n]).max() > 0]
+    picks = [names[i] for i in rng.choice(len(names), size=14, replace=False)]
+    for name in picks:
+        g = G[name]
+        idx = np.unravel_index(np.argmax(np.abs(g)), g.shape)      # an entry that matters
+        eps = 1e-6
+        Pp = dict(P); Pm = dict(P)
+        Pp[name] = P[name].copy(); Pp[name][idx] += eps
+        Pm[name] = P[name].copy(); Pm[name][idx] -= eps
+        fd = (f(Pp) - f(Pm)) / (2 * eps)
+        assert abs(fd - g[idx]) < 1e-6 * max(1.0, abs(g[idx])) + 2e-8, (name, fd, g[idx])
+
+
+def test_reference_masking_semantics():
+    """Padded keys get exactly zero attention; padded QUERY rows are overwritten with -2**32+1 after the softmax."""
+    B, T, d = 2, 4, 8
+    rng = np.random.default_rng(0)
+    Q = rng.standard_normal((B, T, d)); K = rng.standard_normal((B, T, d)); V = rng.standard_normal((B, T, d))
+    m = O.sequence_mask([2, 4], T)
+    out = O.scaled_dot_product_attention(Q, K, V, m, m)
+    # row 0, query 0 attends only keys 0,1
+    s = Q[0, 0] @ K[0, :2].T / np.sqrt(d)
+    p = np.exp(s - s.max()); p /= p.sum()
+    assert np.allclose(out[0, 0], p @ V[0, :2])
+    assert np.allclose(out[0, 3], O.PADDING_NUM * V[0].sum(0))
+    # mask_old docstring known-answer of the reference (TransformerModel_util.py:117-131): additive -2**32+1
+    assert O.PADDING_NUM == -4294967295.0
+
+
+def test_expected_fixture_is_reproduced_by_the_oracle():
+    demo = GU.load_demo()
+    spec_full = O.default_spec("12m_10")
+    inputs_all, comp = GU.compact_inputs(GU.build_inputs(demo, spec_full), spec_full)
+    so = O.scaled_spec(spec_full, comp["rows"])
+    P = O.init_params(so, seed=2020)
+    inp, m = GU.batch_slice(inputs_all, demo["mask"], np.arange(64), so)
+    (c, o), yb = O.inference(inp, P, so)
+    exp = np.load(os.path.join(GU.GOLDEN, "expected64.npz"))
+    assert np.abs(c - exp["click_logit"]).max() < 1e-10
+    assert np.abs(o - exp["order_logit"]).max() < 1e-10
+    assert np.abs(yb - exp["y_bias"]).max() < 1e-10
+    assert abs(O.loss_multi_task_unbias(((c, o), yb), m, so) - float(exp["loss"])) < 1e-10
+
+
+def test_tf_metrics_auc_restatement():
+    rng = np.random.default_rng(0)
+    y = (rng.random(4000) < 0.3).astype(np.float32)
+    p = np.clip(0.3 * y + 0.7 * rng.random(4000), 0, 1).astype(np.float32)
+    a_tf, a_ex = O.tf_metrics_auc(y, p), O.exact_auc(y, p)
+    assert abs(a_tf - a_ex) < 2e-3          # 200-bin trapezoid vs exact rank statistic
+    assert abs(O.exact_auc(y, y) - 1.0) < 1e-12
+    assert abs(O.exact_auc(np.array([0, 1, 0, 1.0]), np.array([0.5, 0.5, 0.5, 0.5])) - 0.5) < 1e-12
+
+
+def test_tf_adam_restatement_first_steps():
+    P = {"w": np.array([1.0, -2.0])}
+    adam = O.TFAdam(lr=1e-3)
+    g = {"w": np.array([0.5, -0.25])}
+    adam.apply(P, g)
+    # step 1: m = 0.1 g, v = 0.001 g^2, lr_t = lr*sqrt(0.001)/0.1 -> update = lr * g/|g| (up to eps)
+    assert np.allclose(P["w"], [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-9)
+    adam.apply(P, {"w": np.zeros(2)})      # zero gradient: parameters keep moving along the decaying first moment
+    assert P["w"][0] < 1.0 - 1e-3 and P["w"][1] > -2.0 + 1e-3
