@@ -80,6 +80,7 @@ _SIGS = {
     "dmt_ln_bwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "dmt_mmoe_mix_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
     "dmt_mmoe_mix_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp],
+    "dmt_scale_add_pos": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp],
     "dmt_relu_bwd": [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_loss_unbias": [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
                         c_vp, c_vp, c_vp, c_vp],

@@ -225,6 +225,18 @@ __global__ __launch_bounds__(1024) void loss_unbias_kernel(int B, const float* _
     const int y_ord = (int)(mk[3] + mk[4]);
     float p_ctr, p_cvr, dpc_dc, dpc_db, dpv_do, dpv_db;
     const float sc = sigmoidf_(c), so = sigmoidf_(o);
+    if (method == 2) {
+      // logit_loss: tf.nn.sigmoid_cross_entropy_with_logits = max(x,0) - x*z + log(1 + exp(-|x|)), no bias tower
+      const float xc = fmaxf(c, 0.f) - c * (float)y_clk + log1pf(expf(-fabsf(c)));
+      const float xo = fmaxf(o, 0.f) - o * (float)y_ord + log1pf(expf(-fabsf(o)));
+      lsum += lw_clk * wc * xc + lw_ord * wo * xo;
+      if (p_ctr_o) p_ctr_o[b] = sc;
+      if (p_cvr_o) p_cvr_o[b] = so;
+      if (d_click) d_click[b] = gscale * invB * lw_clk * wc * (sc - (float)y_clk);
+      if (d_order) d_order[b] = gscale * invB * lw_ord * wo * (so - (float)y_ord);
+      if (d_bias) d_bias[b] = 0.f;
+      continue;
+    }
     if (method == 1) {
       const float sb = sigmoidf_(yb);
       p_ctr = sc * sb; p_cvr = so * sb;
@@ -267,6 +279,17 @@ __global__ __launch_bounds__(1024) void loss_unbias_kernel(int B, const float* _
 }
 
 // ------------------------------------------------------------------------------------------ misc
+// y[b,t,:] = scale * x[b,t,:] + pos[t,:]   (TransformerModel.encode: enc *= d_model**0.5; enc += P[0:T])
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_pos_kernel(long long n, int Tlen, int d, const T* __restrict__ x, float scale,
+                                                            const float* __restrict__ pos, T* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % d);
+  const int t = (int)((i / d) % Tlen);
+  stf<T>(y + i, scale * ldf<T>(x + i) + (pos ? pos[(long long)t * d + c] : 0.f));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(long long rows, long long cols, const T* __restrict__ dy, long long lddy,
                                                        const T* __restrict__ y, long long ldy, T* __restrict__ dz, long long lddz) {
@@ -448,6 +471,19 @@ extern "C" int dmt_loss_unbias(int32_t B, const float* click, const float* order
   hipLaunchKernelGGL(loss_unbias_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, click, order, ybias, mask5, w_ctr, w_ecvr,
                      lw_clk, lw_ord, method, ctr_rel, grad_scale, loss, p_ctr, p_cvr, d_click, d_order, d_bias);
   DMT_CHECK_LAUNCH("dmt_loss_unbias");
+  return DMT_OK;
+}
+
+extern "C" int dmt_scale_add_pos(int32_t dtype, int64_t B, int32_t T, int32_t d, const void* x, float scale, const float* pos,
+                                 void* y, void* stream) {
+  DMT_CHECK_ARG(B > 0 && T > 0 && d > 0 && x && y, "dmt_scale_add_pos: bad argument");
+  const long long n = (long long)B * T * d;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((scale_add_pos_kernel<float>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, n, T, d, (const float*)x, scale, pos, (float*)y);
+  else
+    hipLaunchKernelGGL((scale_add_pos_kernel<bf16_t>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, n, T, d, (const bf16_t*)x, scale, pos, (bf16_t*)y);
+  DMT_CHECK_LAUNCH("dmt_scale_add_pos");
   return DMT_OK;
 }
 

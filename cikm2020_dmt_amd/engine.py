@@ -248,6 +248,35 @@ class DMTEngine:
         n = len(pos)
         return list(outs[:n]), outs[n], outs[n + 1]
 
+    def gather_raw(self, batch: DeviceBatch):
+        """generate_data's outputs: unscaled seq_emb / tar_emb ([0;E] lookups, no positions); no gradient path to the
+        tables (API-parity helper; the training path uses gather())."""
+        spec, plan, store = self.spec, self.plan, self.store
+        dev, cdt = store.device, store.compute_dtype
+        B, d = batch.B, spec["d_model"]
+        n_seq = len(spec["attention_embed_pairs"])
+        seq_T = [max(batch.feats[uf].T for (uf, _i) in pairs) for pairs in spec["attention_embed_pairs"]]
+        X = [torch.empty((B, seq_T[s], d), dtype=cdt, device=dev) for s in range(n_seq)]
+        tar = torch.empty((B, d), dtype=cdt, device=dev)
+        desc = L.GatherDesc()
+        items = [it for it in plan.items if it["seq_id"] >= 0]
+        desc.B, desc.n_features = B, len(items)
+        for i, it in enumerate(items):
+            col = batch.feats[it["feature"]]
+            f = desc.feat[i]
+            f.table = store.table[it["table"]].data_ptr()
+            f.rows, f.dim = it["rows"], it["dim"]
+            f.idx, f.wts, f.lens, f.T = col.idx.data_ptr(), None, col.lens.data_ptr(), col.T
+            f.pooled_off, f.seq_id, f.seq_off, f.group, f.inv_wsum = -1, it["seq_id"], it["seq_off"], it["group"], None
+        desc.n_seq = n_seq
+        for s in range(n_seq):
+            desc.seq_out[s], desc.seq_T[s], desc.pos[s] = X[s].data_ptr(), seq_T[s], None
+        desc.tar_out, desc.d_model, desc.seq_scale = tar.data_ptr(), d, 1.0
+        desc.pooled, desc.ld_pooled, desc.dense, desc.n_dense = None, 0, None, 0
+        desc.out_dtype = ops.dt_code(cdt)
+        L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
+        return X, tar
+
     def mha_self(self, x, lens, blk):
         """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
         d, H = self.spec["d_model"], self.spec["num_heads"]

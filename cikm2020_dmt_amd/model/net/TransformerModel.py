@@ -1,0 +1,65 @@
+"""TransformerModel with the reference's interface (/root/reference/DMT_code/model/net/TransformerModel.py:29-171):
+encoder = self-attention over the behaviour sequence, decoder = the target item as the single query."""
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from .. import runtime as R
+from .TransformerModel_util import ff, multihead_attention, _leaf
+
+
+class TransformerModel():
+    def __init__(self, hp):
+        self.hp = hp
+
+    def _d_model(self):
+        return self.hp.d_model if hasattr(self.hp, "d_model") else self.hp["d_model"]
+
+    def _get(self, key, default=None):
+        return getattr(self.hp, key) if hasattr(self.hp, key) else (self.hp.get(key, default) if isinstance(self.hp, dict) else default)
+
+    def encode_decode(self, input, name="encode_decode", training=True):
+        with R.variable_scope(name):
+            (seq_q, seq_q_lens, seq_k, seq_k_lens, seq_k_ts) = input
+            state_encode, _ = self.encode((seq_k, seq_k_lens, seq_k_ts), name, training=training)
+            state_decode = self.decode((seq_q, seq_q_lens, state_encode, seq_k_lens), name, training=training)
+            return state_decode.squeeze(1)
+
+    def position_encode(self, seq_k, seq_k_ts, seq_max_len, scale):
+        method = self._get("position_encoding_method", "position_learn")
+        if method != "position_learn":
+            raise NotImplementedError("position_encoding_method=%s (dmt.conf uses position_learn)" % method)
+        with R.variable_scope("positional_encoding_k_position_learn"):
+            pos, _ = _leaf("embedding_position_learn")
+        return ops.ScaleAddPosFn.apply(seq_k, pos, scale)
+
+    def encode(self, xs, name="encoder", training=True):
+        if training and self._get("dropout_rate", 0.0):
+            raise NotImplementedError("Transformer dropout is not implemented in the HIP path (use training=False)")
+        with R.variable_scope(name):
+            seq_emb, seqlens, seq_k_ts = xs
+            enc = self.position_encode(seq_emb, seq_k_ts, self._get("maxlen_k"), float(self._d_model()) ** 0.5)
+            for i in range(self._get("num_blocks_encode", 1)):
+                with R.variable_scope("num_blocks_{}".format(i)):
+                    enc = multihead_attention(queries=enc, keys=enc, values=enc, queries_length=seqlens, keys_length=seqlens,
+                                              num_heads=self._get("num_heads"), dropout_rate=0, training=False, causality=False,
+                                              scope="self-attention")
+                    enc = ff(enc, num_units=[self._get("d_ff"), self._d_model()])
+        return enc, seqlens
+
+    def decode(self, ys, name="decoder", training=True):
+        if self._get("is_decoder_add_pos_emb", False):
+            raise NotImplementedError("is_decoder_add_pos_emb=true")
+        with R.variable_scope(name):
+            query_emb, query_length, key_emb, key_length = ys
+            dec = ops.ScaleAddPosFn.apply(query_emb, None, float(self._d_model()) ** 0.5)
+            for i in range(self._get("num_blocks_decode", 1)):
+                with R.variable_scope("num_blocks_{}".format(i)):
+                    dec = multihead_attention(queries=dec, keys=key_emb, values=key_emb, queries_length=query_length,
+                                              keys_length=key_length, num_heads=self._get("num_heads"), dropout_rate=0,
+                                              training=False, causality=False, scope="vanilla_attention")
+                    tied = R.get_default().spec.get("tie_ffn", True)
+                    dec = ff(dec, num_units=[self._get("d_ff"), self._d_model()],
+                             scope="positionwise_feedforward" if tied else "positionwise_feedforward_dec")
+        return dec

@@ -1,0 +1,129 @@
+"""Functional Transformer ops with the reference's signatures (/root/reference/DMT_code/model/net/TransformerModel_util.py).
+
+    scaled_dot_product_attention :11-56     ln :58-78     mask :80-108     multihead_attention :160-209
+    ff :212-235     positional_encoding_learn :281-316
+Variables are looked up by scoped name in the active Runtime's store (the reference creates them under the same
+names with tf.get_variable / tf.layers.dense); dropout is not implemented (parity runs have it off).
+Tensors are device tensors; every op is a libdmt_hip.so kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from .. import runtime as R
+
+PADDING_NUM = float(-2 ** 32 + 1)
+
+
+def _store():
+    return R.get_default().store
+
+
+def _leaf(name):
+    st = _store()
+    full = R.current_scope() + name
+    if full not in st.leaf:
+        raise KeyError("variable '%s' is not part of the DMT variable inventory (SURVEY.md Appendix B)" % full)
+    return st.leaf[full], st.weight.get(full)
+
+
+def _check_dropout(rate, training):
+    if training and rate:
+        raise NotImplementedError("dropout is not implemented in the HIP path; call with training=False or dropout_rate=0")
+
+
+def ln(inputs, epsilon=1e-8, scope="ln"):
+    with R.variable_scope(scope):
+        gamma, _ = _leaf("gamma")
+        beta, _ = _leaf("beta")
+    return ops.layer_norm(inputs, gamma, beta, epsilon)
+
+
+def mask(inputs, query_masks=None, key_masks=None, type=None):
+    """Stand-alone masking of a score tensor is fused into the attention kernel; this helper exists for API parity
+    and applies the same rule with torch indexing on the host-visible tensor (not on the hot path)."""
+    if type in ("k", "key", "keys"):
+        h = inputs.shape[0] // key_masks.shape[0]
+        km = key_masks.bool().repeat(h, 1)[:, None, :].expand_as(inputs)
+        return torch.where(km, inputs, torch.full_like(inputs, PADDING_NUM))
+    if type in ("q", "query", "queries"):
+        h = inputs.shape[0] // query_masks.shape[0]
+        qm = query_masks.bool().repeat(h, 1)[:, :, None].expand_as(inputs)
+        return torch.where(qm, inputs, torch.full_like(inputs, PADDING_NUM))
+    raise NotImplementedError("mask type %r (causality is never used by DMT)" % (type,))
+
+
+def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, causality=False, dropout_rate=0., training=True,
+                                 scope="scaled_dot_product_attention"):
+    """Q,K,V: [h*N, T, d_k] head-major packing of the reference; masks [N, T] bool / 0-1.  Returns [h*N, T_q, d_k]."""
+    if causality:
+        raise NotImplementedError("causality=True is never used by DMT")
+    _check_dropout(dropout_rate, training)
+    N = key_masks.shape[0]
+    h = Q.shape[0] // N
+    dk = Q.shape[-1]
+
+    def unpack(x):  # [h*N, T, dk] -> [N, T, h*dk]
+        return torch.cat(torch.split(x, N, dim=0), dim=2).contiguous()
+
+    q, k, v = unpack(Q), unpack(K), unpack(V)
+    q_lens = query_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
+    k_lens = key_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
+    kv = torch.cat([k, v], dim=-1)
+    out = ops.AttnFn.apply(q, kv, None, q_lens, k_lens, h, h * dk, False)
+    return torch.cat(torch.split(out, dk, dim=2), dim=0)
+
+
+def multihead_attention(queries, keys, values, queries_length, keys_length, num_heads=8, dropout_rate=0, training=True,
+                        causality=False, scope="multihead_attention"):
+    if causality:
+        raise NotImplementedError("causality=True is never used by DMT")
+    _check_dropout(dropout_rate, training)
+    if values is not keys:
+        raise NotImplementedError("DMT always attends with values = keys")
+    d = queries.shape[-1]
+    with R.variable_scope(scope):
+        wl, w = _leaf("qkv_kernel")
+        bl, _ = _leaf("qkv_bias")
+        gamma, _ = _leaf("ln/gamma")
+        beta, _ = _leaf("ln/beta")
+    eng = R.get_default().engine
+    ql = queries_length.to(torch.int32).contiguous() if queries_length is not None else None
+    kl = keys_length.to(torch.int32).contiguous()
+    if queries is keys:
+        qkv = ops.linear(queries, wl, bl, w)
+        s = ops.AttnFn.apply(qkv, None, queries, ql, kl, num_heads, d, True)
+    else:
+        q = ops.linear(queries, wl[:, :d], bl[:d], eng._wslice(w, 0, d))
+        kv = ops.linear(keys, wl[:, d:], bl[d:], eng._wslice(w, d, 3 * d))
+        s = ops.AttnFn.apply(q, kv, queries, ql, kl, num_heads, d, False)
+    return ops.layer_norm(s, gamma, beta, 1e-8)
+
+
+def ff(inputs, num_units, scope="positionwise_feedforward"):
+    with R.variable_scope(scope):
+        w1l, w1 = _leaf("dense/kernel")
+        b1l, _ = _leaf("dense/bias")
+        w2l, w2 = _leaf("dense_1/kernel")
+        b2l, _ = _leaf("dense_1/bias")
+        gamma, _ = _leaf("ln/gamma")
+        beta, _ = _leaf("ln/beta")
+    if list(num_units) != [w1.f32.shape[1], w2.f32.shape[1]]:
+        raise ValueError("num_units %s does not match the stored FFN %s" % (list(num_units), [w1.f32.shape[1], w2.f32.shape[1]]))
+    s = ops.FFNFn.apply(inputs, w1l, b1l, w2l, b2l, w1, w2)
+    return ops.layer_norm(s, gamma, beta, 1e-8)
+
+
+def positional_encoding_learn(inputs, maxlen, masking=False, scope="positional_encoding_learn"):
+    """Returns P[0:T] broadcast to inputs' shape (lookup by range(T))."""
+    if masking:
+        raise NotImplementedError("masking=True is never used by DMT")
+    with R.variable_scope(scope):
+        pos, _ = _leaf("embedding_position_learn")
+    zeros = torch.zeros_like(inputs)
+    return ops.ScaleAddPosFn.apply(zeros, pos, 0.0)
+
+
+def positional_encoding(inputs, maxlen, masking=False, scope="positional_encoding"):
+    raise NotImplementedError("sinusoidal positions: dmt.conf uses transformer_position_encoding_method=position_learn")

@@ -390,6 +390,32 @@ class LossUnbiasFn(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+class ScaleAddPosFn(torch.autograd.Function):
+    """y = scale * x + pos[:T]  (TransformerModel.py:96-100)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, scale):
+        x = x.contiguous()
+        Bn, T, d = x.shape
+        y = torch.empty_like(x)
+        L.call("dmt_scale_add_pos", dt_code(x.dtype), Bn, T, d, p(x), float(scale), p(pos), p(y), stream_ptr())
+        ctx.scale, ctx.shape = scale, (Bn, T, d)
+        ctx.pos_shape = tuple(pos.shape) if pos is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        Bn, T, d = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("dmt_scale_add_pos", dt_code(dy.dtype), Bn, T, d, p(dy), float(ctx.scale), None, p(dx), stream_ptr())
+        dpos = None
+        if ctx.pos_shape is not None:
+            dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dy.device)
+            colsum(dy.view(Bn, T * d), 1.0, out=dpos.view(-1)[: T * d])
+        return dx, dpos, None
+
+
 # ------------------------------------------------------------------------------------------------ misc
 def cast_shadow(src_f32_2d, dst_plain, dst_t):
     rows, cols = src_f32_2d.shape

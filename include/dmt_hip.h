@@ -229,13 +229,19 @@ int dmt_mmoe_mix_bwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_t
                      void* dglogit, int64_t ld_dglogit, int32_t relu_mask /* 1: expert is a relu output, return the
                      gradient wrt its pre-activation */, void* stream);
 
+/* y[b,t,:] = scale * x[b,t,:] + pos[t,:]: the input prep of TransformerModel.encode / decode
+ * (model/net/TransformerModel.py:96-100,146-147) when the sequence embedding was gathered unscaled. pos may be NULL. */
+int dmt_scale_add_pos(int32_t dtype, int64_t B, int32_t T, int32_t d, const void* x, float scale, const float* pos, void* y,
+                      void* stream);
+
 /* Gradient of relu given its OUTPUT y: dz = dy * (y > 0)  (tf.nn.relu at base.py:64, TransformerModel_util.py:224). */
 int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const void* dy, int64_t lddy, const void* y, int64_t ldy,
                  void* dz, int64_t lddz, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Loss of the unbias model (model/inference_mlp.py:162-223) and its gradient in one pass.
- *   method: 0 two_head_add, 1 two_head_multiply;  ctr_rel: 1 adds the relevance-only cross entropies.
+ *   method: 0 two_head_add, 1 two_head_multiply, 2 plain logit_loss (sigmoid_cross_entropy_with_logits on the two
+ *   logits, model/inference_mlp.py:228-258; ybias ignored);  ctr_rel: 1 adds the relevance-only cross entropies.
  *   loss[0] = scalar loss (batch mean, class weights w_ctr/w_ecvr[5], loss weights lw[2]);
  *   p_ctr, p_cvr [B] as run_dnn.py:90-101; d_click/d_order/d_bias [B] = dloss/dlogit * grad_scale.
  *   logits are fp32 [B] (the towers' final 1-wide layer is produced in fp32).

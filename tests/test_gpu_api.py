@@ -1,0 +1,113 @@
+"""The reference-shaped facade (DMT_code/model operator signatures) on the HIP path vs the oracle's functions of the
+same names: Inference, mmoe_transformer_unbias.{generate_data, trans_core, embedding_trans, expert_gate, build_tower,
+embedding_mlp_bias}, base.embedding_combiner, TransformerModel.encode_decode, multihead_attention / ff / ln."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmt_oracle as O
+from cikm2020_dmt_amd import spec as S
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from cikm2020_dmt_amd.model import runtime as R
+from cikm2020_dmt_amd.model.inference_mlp import Inference
+from cikm2020_dmt_amd.model.net import TransformerModel_util as TU
+from tests.util import small_specs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Conf(dict):
+    pass
+
+
+def _make(cuda, model_type="mmoe_transformer_unbias"):
+    so, sp = small_specs()
+    conf = _Conf(model={"model_type": model_type})
+    inf = Inference(conf, device=cuda, compute_dtype=torch.float32, spec=sp)
+    P = O.init_params(so, seed=21)
+    rng = np.random.default_rng(1)
+    for k in P:
+        if k.endswith("/gamma") or k.endswith("/beta") or k.endswith("/bias"):
+            P[k] = P[k] + 0.1 * rng.standard_normal(P[k].shape)
+    inf.rt.store.load_state(P)
+    inputs, mask, label = make_batch(sp, 10, seed=8, lengths="ragged", weights="random")
+    return so, sp, P, inf, inputs, mask
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def test_inference_and_losses(cuda):
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    ((c, o), yb) = inf.inference(inputs, is_train=False)
+    (c_ref, o_ref), yb_ref = O.inference(inputs, P, so)
+    assert np.abs(_np(c) - c_ref).max() < 2e-4 and np.abs(_np(o) - o_ref).max() < 2e-4 and np.abs(_np(yb) - yb_ref).max() < 2e-4
+    for method in ("two_head_add", "two_head_multiply"):
+        for rel in ("ctr", "ctr_rel"):
+            got = float(inf.loss_multi_task_unbias(((c, o), yb), None, mask, True, method, rel).detach())
+            ref = O.loss_multi_task_unbias(((c_ref, o_ref), yb_ref), mask, so, method, rel)
+            assert abs(got - ref) / abs(ref) < 2e-5
+    got = float(inf.loss_multi_task((c, o), None, mask).detach())
+    ref = O.loss_multi_task((c_ref, o_ref), mask, so)
+    assert abs(got - ref) / abs(ref) < 2e-5
+    rel_logits = inf.inference(inputs, is_train=False, is_predict=True)
+    assert len(rel_logits) == 2 and np.abs(_np(rel_logits[0]) - c_ref).max() < 2e-4
+    with pytest.raises(SystemExit):
+        inf.get_optimizer("sgd", 0.1)
+    assert inf.get_optimizer("adam", 0.001) is not None
+
+
+def test_model_stage_methods(cuda):
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    m = inf.model
+    seq = m.generate_data(inputs)
+    ref = O.generate_data(inputs, P, so)
+    for (mk, ln_, se, ta, ts), (mk_r, ln_r, se_r, ta_r, _ts_r) in zip(seq, ref):
+        assert np.array_equal(_np(mk), mk_r) and np.array_equal(ln_.cpu().numpy(), ln_r)
+        assert np.abs(_np(se) - se_r).max() < 1e-6 and np.abs(_np(ta) - ta_r).max() < 1e-6 and ts is None
+    interest = m.trans_core(seq, is_train=False)
+    assert np.abs(_np(interest) - O.trans_core(ref, P, so)).max() < 2e-4
+    z = m.embedding_trans(inputs, is_train=False)
+    z_ref = O.embedding_trans(inputs, P, so)
+    assert z.shape == z_ref.shape and np.abs(_np(z) - z_ref).max() < 2e-4
+    comb = m.embedding_combiner(inputs)
+    assert np.abs(_np(comb) - O.embedding_combiner(inputs, P, so)).max() < 1e-5
+    tasks = m.expert_gate(z, sp["hidden_units_bottom"], [1, 1, 1], num_experts=4, num_tasks=2, is_train=False)
+    tasks_ref, gates_ref = O.expert_gate(z_ref, P, so)
+    for a, b in zip(tasks, tasks_ref):
+        assert np.abs(_np(a) - b).max() < 2e-4
+    assert np.abs(_np(inf.rt.engine.intermediates["gates"]) - np.stack(gates_ref)).max() < 1e-5   # gate softmax (run_dnn.py:721-725)
+    click = m.build_tower(tasks[0], sp["hidden_units_task"], [1], "click", is_train=False)
+    assert np.abs(_np(click) - O.build_tower(tasks_ref[0], P, so, "click")).max() < 2e-4
+    yb = m.embedding_mlp_bias(inputs, is_train=False)
+    assert np.abs(_np(yb) - O.embedding_mlp_bias(inputs, P, so)).max() < 1e-5
+
+
+def test_transformer_util_functions_under_scopes(cuda):
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    rng = np.random.default_rng(3)
+    B, T, d = 6, 9, sp["d_model"]
+    x = rng.standard_normal((B, T, d)); y = rng.standard_normal((B, 1, d))
+    lens = rng.integers(1, T + 1, size=B)
+    pre = S.trans_prefix(1)
+    xd = torch.tensor(x, dtype=torch.float32, device=cuda); yd = torch.tensor(y, dtype=torch.float32, device=cuda)
+    ld = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    one = torch.ones(B, dtype=torch.int32, device=cuda)
+    with R.variable_scope(pre.rstrip("/")):
+        with R.variable_scope("num_blocks_0"):
+            a = TU.multihead_attention(xd, xd, xd, ld, ld, num_heads=4, dropout_rate=0, training=False, scope="self-attention")
+            c = TU.multihead_attention(yd, xd, xd, one, ld, num_heads=4, dropout_rate=0, training=False, scope="vanilla_attention")
+            f = TU.ff(xd, [sp["d_ff"], d])
+            with R.variable_scope("self-attention"):
+                n = TU.ln(xd)
+    blk = pre + "num_blocks_0/"
+    a_ref = O.multihead_attention(x, x, x, lens, lens, 4, P, blk + "self-attention/")
+    c_ref = O.multihead_attention(y, x, x, np.ones(B, int), lens, 4, P, blk + "vanilla_attention/")
+    valid = O.sequence_mask(lens, T)[:, :, None]
+    assert (np.abs(_np(a) - a_ref) / (np.abs(a_ref) + 1.0)).max() < 5e-5           # includes the padded-query rows (F13)
+    assert np.abs(_np(c) - c_ref).max() < 5e-5
+    assert np.abs(_np(f) - O.ff(x, P, blk + "positionwise_feedforward/")).max() < 5e-5
+    assert np.abs(_np(n) - O.ln(x, P[blk + "self-attention/ln/gamma"], P[blk + "self-attention/ln/beta"])).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        TU.multihead_attention(xd, xd, xd, ld, ld, num_heads=4, dropout_rate=0.1, training=True, scope="self-attention")
