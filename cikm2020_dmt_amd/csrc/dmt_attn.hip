@@ -175,6 +175,418 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 MFMA forward.  One wavefront per (example, head), Tq, Tk <= 64.
+//   S^T[key, q] = K Q^T      v_mfma_f32_32x32x16_bf16, A = K rows, B = Q rows, both read k-contiguous from global
+//                            (swapped operands: each lane owns ONE query column, its 32+32 keys sit in the lane
+//                            pair (l, l^32) -> softmax max / sum = in-register reductions + one cross-half exchange)
+//   O^T[j, q]   = V^T P^T    B = P^T straight from the softmax registers (k-slot <-> key mapping below), A = V^T built
+//                            from the LDS-staged V tile with 2-byte reads (lanes along j: conflict free)
+// k-slot mapping of one k16 step u (keys 16u .. 16u+15): slot i of lane-half h  <->  key 16u + (i&3) + 8(i>>2) + 4h,
+// which is exactly where the 32x32 accumulator layout leaves the scores, so P never moves between lanes.
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, int j0, bool row_ok, int dh) {
+  union { bf16x8_t v; uint2 h[2]; } u;
+  u.h[0] = make_uint2(0u, 0u);
+  u.h[1] = make_uint2(0u, 0u);
+  if (row_ok) {
+    if (j0 + 4 <= dh) u.h[0] = *reinterpret_cast<const uint2*>(rowp + j0);
+    if (j0 + 8 <= dh) u.h[1] = *reinterpret_cast<const uint2*>(rowp + j0 + 4);
+  }
+  return u.v;
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+// A fragment of a TRANSPOSED [64][DHS] bf16 LDS tile: element i = tile[16u + (i&3) + 8(i>>2) + 4*half][j]
+template <int DHS>
+__device__ __forceinline__ bf16x8_t lds_frag_keyslots(const bf16_t* __restrict__ tile, int u, int half, int j) {
+  union { bf16x8_t v; bf16_t e[8]; } f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.e[i] = tile[(16 * u + (i & 3) + 8 * (i >> 2) + 4 * half) * DHS + j];
+  return f.v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
+  constexpr int NK = (DH + 15) / 16;
+  constexpr int NDT = (DH + 31) / 32;
+  constexpr int DHS = DH + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const long long wid = (long long)blockIdx.x * nw + wave;
+  if (wid >= (long long)a.B * a.H) return;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int half = lane >> 5, l31 = lane & 31;
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + (long long)wave * 64 * DHS;
+
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
+
+  // ---- stage V (rows >= Tk zero filled: 0 * garbage must not make NaN)
+  for (int c = lane; c < 64 * (DH / 4); c += 64) {
+    const int row = c / (DH / 4), j = (c - row * (DH / 4)) * 4;
+    uint2 v = make_uint2(0u, 0u);
+    if (row < Tk) v = *reinterpret_cast<const uint2*>(Vg + (long long)row * a.v_rs + j);
+    *reinterpret_cast<uint2*>(Vs + row * DHS + j) = v;
+  }
+
+  // ---- S^T = K Q^T
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  {
+    bf16x8_t aK[2][NK], bQ[2][NK];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t * 32 + l31;
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) {
+        const int j0 = s2 * 16 + 8 * half;
+        aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
+        bQ[t][s2] = load_frag8(Qg + (long long)row * a.q_rs, j0, row < Tq, DH);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ[qt][s2], acc[kt][qt], 0, 0, 0);
+  }
+
+  // ---- masked softmax over keys, per query column
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : Tq;
+  const float sc = sqrtf((float)DH);
+  bf16x8_t pB[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + l31;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float x = acc[kt][qt][r] / sc;
+        if (key >= klen) x = PADDING_NUM;
+        if (key >= Tk) x = -3.0e38f;
+        acc[kt][qt][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float e = (key < Tk) ? expf(acc[kt][qt][r] - m) : 0.f;
+        acc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const bool qpad = (q >= qlen);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      union { bf16x8_t v; unsigned w[4]; } f;
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const int r0 = 8 * (u & 1) + i;
+        float p0 = acc[u >> 1][qt][r0] / sum, p1 = acc[u >> 1][qt][r0 + 1] / sum;
+        if (qpad) {      // query mask applied AFTER the softmax (reference behaviour)
+          const int k0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+          p0 = (k0 < Tk) ? PADDING_NUM : 0.f;
+          p1 = (k0 + 1 < Tk) ? PADDING_NUM : 0.f;
+        }
+        f.w[i >> 1] = pack_bf16(p0, p1);
+      }
+      pB[qt][u] = f.v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- O^T = V^T P^T, residual, store
+  const bf16_t* Rg = a.resid ? reinterpret_cast<const bf16_t*>(a.resid) + (long long)b * a.r_bs + h * DH : nullptr;
+  bf16_t* Og = reinterpret_cast<bf16_t*>(a.out) + (long long)b * a.o_bs + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t av = lds_frag_keyslots<DHS>(Vs, u, half, jj);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[0][u], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[1][u], o[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qt * 32 + l31;
+      if (q >= Tq) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = dt * 32 + 8 * g + 4 * half;
+        if (j + 4 > DH) continue;
+        float x0 = o[qt][4 * g + 0], x1 = o[qt][4 * g + 1], x2 = o[qt][4 * g + 2], x3 = o[qt][4 * g + 3];
+        if (Rg) {
+          union { uint2 v; bf16_t e[4]; } rv;
+          rv.v = *reinterpret_cast<const uint2*>(Rg + (long long)q * a.r_rs + j);
+          x0 += bf2f(rv.e[0]); x1 += bf2f(rv.e[1]); x2 += bf2f(rv.e[2]); x3 += bf2f(rv.e[3]);
+        }
+        uint2 ov;
+        ov.x = pack_bf16(x0, x1);
+        ov.y = pack_bf16(x2, x3);
+        *reinterpret_cast<uint2*>(Og + (long long)q * a.o_rs + j) = ov;
+      }
+    }
+  }
+}
+
+// A fragment with NATURAL k slots from a [64][DHS] tile: element i = tile[16u + 8*half + i][j]
+template <int DHS>
+__device__ __forceinline__ bf16x8_t lds_frag_rows(const bf16_t* __restrict__ tile, int u, int half, int j) {
+  union { bf16x8_t v; bf16_t e[8]; } f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.e[i] = tile[(16 * u + 8 * half + i) * DHS + j];
+  return f.v;
+}
+
+// Store an O^T-style accumulator pair (rows = head-dim in registers, column = lane's row of the output matrix).
+template <int DH>
+__device__ __forceinline__ void store_rows_T(const f32x16_t (&o)[2], bf16_t* __restrict__ base, long long rs, int dt, int l31,
+                                             int half, int n_rows) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = t * 32 + l31;
+    if (row >= n_rows) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = dt * 32 + 8 * g + 4 * half;
+      if (j + 4 > DH) continue;
+      uint2 ov;
+      ov.x = pack_bf16(o[t][4 * g + 0], o[t][4 * g + 1]);
+      ov.y = pack_bf16(o[t][4 * g + 2], o[t][4 * g + 3]);
+      *reinterpret_cast<uint2*>(base + (long long)row * rs + j) = ov;
+    }
+  }
+}
+
+// bf16 MFMA backward (flash style: P recomputed).  Same wave-per-(example, head) decomposition as the forward.
+//   S^T = K Q^T, dP^T = V dO^T                (operands k-contiguous from global)
+//   dS  = P * (dP - rowsum(P*dP)) / sqrt(dh)  in the accumulator layout (lane = query column)
+//   dQ^T = K^T dS^T                           (B = dS from registers, A = K^T from the LDS tile)
+//   dV^T = dO^T P,  dK^T = Q^T dS             (P, dS transposed through LDS as [key][q]; A = dO^T / Q^T from LDS tiles)
+template <int DH>
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
+  constexpr int NK = (DH + 15) / 16;
+  constexpr int NDT = (DH + 31) / 32;
+  constexpr int DHS = DH + 4;
+  constexpr int PLD = 72;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const long long wid = blockIdx.x;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int half = lane >> 5, l31 = lane & 31;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Qs = Ks + 64 * DHS;
+  bf16_t* dOs = Qs + 64 * DHS;
+  bf16_t* PL = dOs + 64 * DHS;
+  bf16_t* DL = PL + 64 * PLD;
+
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
+  const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
+
+  for (int c = lane; c < 64 * (DH / 4); c += 64) {
+    const int row = c / (DH / 4), j = (c - row * (DH / 4)) * 4;
+    uint2 kv = make_uint2(0u, 0u), qv = make_uint2(0u, 0u), dv = make_uint2(0u, 0u);
+    if (row < Tk) kv = *reinterpret_cast<const uint2*>(Kg + (long long)row * a.k_rs + j);
+    if (row < Tq) {
+      qv = *reinterpret_cast<const uint2*>(Qg + (long long)row * a.q_rs + j);
+      dv = *reinterpret_cast<const uint2*>(dOg + (long long)row * a.do_rs + j);
+    }
+    *reinterpret_cast<uint2*>(Ks + row * DHS + j) = kv;
+    *reinterpret_cast<uint2*>(Qs + row * DHS + j) = qv;
+    *reinterpret_cast<uint2*>(dOs + row * DHS + j) = dv;
+  }
+
+  f32x16_t acc[2][2], dp[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; dp[i][j][r] = 0.f; }
+  {
+    bf16x8_t aK[2][NK], bQ[2][NK];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t * 32 + l31;
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) {
+        const int j0 = s2 * 16 + 8 * half;
+        aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
+        bQ[t][s2] = load_frag8(Qg + (long long)row * a.q_rs, j0, row < Tq, DH);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ[qt][s2], acc[kt][qt], 0, 0, 0);
+  }
+  {
+    bf16x8_t aV[2][NK], bD[2][NK];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t * 32 + l31;
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) {
+        const int j0 = s2 * 16 + 8 * half;
+        aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
+        bD[t][s2] = load_frag8(dOg + (long long)row * a.do_rs, j0, row < Tq, DH);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          dp[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD[qt][s2], dp[kt][qt], 0, 0, 0);
+  }
+
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : Tq;
+  const float sc = sqrtf((float)DH);
+  bf16x8_t dsB[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + l31;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float x = acc[kt][qt][r] / sc;
+        if (key >= klen) x = PADDING_NUM;
+        if (key >= Tk) x = -3.0e38f;
+        acc[kt][qt][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float e = (key < Tk) ? expf(acc[kt][qt][r] - m) : 0.f;
+        acc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = acc[kt][qt][r] / sum;
+        acc[kt][qt][r] = pv;
+        dot += pv * dp[kt][qt][r];
+      }
+    dot += __shfl_xor(dot, 32, 64);
+    const bool qpad = (q >= qlen);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float pv = acc[kt][qt][r];
+        float ds = (key < klen) ? pv * (dp[kt][qt][r] - dot) / sc : 0.f;   // no gradient into masked keys
+        if (qpad) { ds = 0.f; pv = (key < Tk) ? PADDING_NUM : 0.f; }       // constant rows: gradient reaches V only
+        dp[kt][qt][r] = ds;
+        PL[key * PLD + q] = f2bf(pv);
+        DL[key * PLD + q] = f2bf(ds);
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      union { bf16x8_t v; unsigned w[4]; } f;
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const int r0 = 8 * (u & 1) + i;
+        f.w[i >> 1] = pack_bf16(dp[u >> 1][qt][r0], dp[u >> 1][qt][r0 + 1]);
+      }
+      dsB[qt][u] = f.v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- dQ^T = K^T dS^T
+  bf16_t* dQg = reinterpret_cast<bf16_t*>(a.dQ) + (long long)b * a.dq_bs + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t av = lds_frag_keyslots<DHS>(Ks, u, half, jj);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[0][u], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[1][u], o[1], 0, 0, 0);
+    }
+    store_rows_T<DH>(o, dQg, a.dq_rs, dt, l31, half, Tq);
+  }
+
+  // ---- dV^T = dO^T P  and  dK^T = Q^T dS   (reduction over queries, natural k slots)
+  bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
+  bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t ov[2], ok[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ov[0][r] = 0.f; ov[1][r] = 0.f; ok[0][r] = 0.f; ok[1][r] = 0.f; }
+    const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t ad = lds_frag_rows<DHS>(dOs, u, half, jj);
+      const bf16x8_t aq = lds_frag_rows<DHS>(Qs, u, half, jj);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key = kt * 32 + l31;
+        const bf16x8_t bp = *reinterpret_cast<const bf16x8_t*>(PL + key * PLD + 16 * u + 8 * half);
+        const bf16x8_t bd = *reinterpret_cast<const bf16x8_t*>(DL + key * PLD + 16 * u + 8 * half);
+        ov[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bp, ov[kt], 0, 0, 0);
+        ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
+      }
+    }
+    store_rows_T<DH>(ov, dVg, a.dv_rs, dt, l31, half, Tk);
+    store_rows_T<DH>(ok, dKg, a.dk_rs, dt, l31, half, Tk);
+  }
+}
+
 int fill_args(AttnArgs& a, const dmt_attn_desc* d) {
   a.B = d->B; a.H = d->H; a.dh = d->dh; a.Tq = d->Tq; a.Tk = d->Tk;
   a.Q = d->Q; a.q_bs = d->q_bs; a.q_rs = d->q_rs;
@@ -237,6 +649,25 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   const size_t lds = (size_t)nw * a.lds_per_wave * 4;
   DMT_CHECK_ARG(lds <= 160 * 1024, "dmt_attn_fwd: Tk*dh too large for LDS");
   hipStream_t st = (hipStream_t)stream;
+  // bf16 MFMA path: 8-byte aligned rows (all strides multiples of 4 elements) and an instantiated head dim
+  auto al8 = [](const void* q, long long s0, long long s1) { return q == nullptr || (((uintptr_t)q) % 8 == 0 && s0 % 4 == 0 && s1 % 4 == 0); };
+  const bool mfma_ok = d->dtype == DMT_BF16 && (d->dh == 20 || d->dh == 80 || d->dh == 16 || d->dh == 32 || d->dh == 64) &&
+                       al8(d->Q, d->q_bs, d->q_rs) && al8(d->K, d->k_bs, d->k_rs) && al8(d->V, d->v_bs, d->v_rs) &&
+                       al8(d->resid, d->r_bs, d->r_rs) && al8(d->out, d->o_bs, d->o_rs);
+  if (mfma_ok) {
+    const int nwm = 4;
+    const size_t ldsm = (size_t)nwm * 64 * (d->dh + 4) * 2;
+    const unsigned nb = (unsigned)cdiv64((long long)d->B * d->H, nwm);
+    switch (d->dh) {
+      case 16: hipLaunchKernelGGL((attn_fwd_mfma_kernel<16>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
+      case 20: hipLaunchKernelGGL((attn_fwd_mfma_kernel<20>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
+      case 32: hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
+      case 64: hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
+      default: hipLaunchKernelGGL((attn_fwd_mfma_kernel<80>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
+    }
+    DMT_CHECK_LAUNCH("dmt_attn_fwd(mfma)");
+    return DMT_OK;
+  }
   if (d->dtype == DMT_F32) launch_fwd<float>(a, nw, lds, st); else launch_fwd<bf16_t>(a, nw, lds, st);
   DMT_CHECK_LAUNCH("dmt_attn_fwd");
   return DMT_OK;
@@ -260,6 +691,27 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
   const size_t lds = (size_t)nw * a.lds_per_wave * 4;
   DMT_CHECK_ARG(lds <= 160 * 1024, "dmt_attn_bwd: Tk*dh too large for LDS");
   hipStream_t st = (hipStream_t)stream;
+  {
+    auto al8 = [](const void* q, long long s0, long long s1) { return q == nullptr || (((uintptr_t)q) % 8 == 0 && s0 % 4 == 0 && s1 % 4 == 0); };
+    const dmt_attn_desc& f = d->f;
+    const bool mfma_ok = f.dtype == DMT_BF16 && (f.dh == 20 || f.dh == 80 || f.dh == 16 || f.dh == 32 || f.dh == 64) &&
+                         al8(f.Q, f.q_bs, f.q_rs) && al8(f.K, f.k_bs, f.k_rs) && al8(f.V, f.v_bs, f.v_rs) &&
+                         al8(d->dout, d->do_bs, d->do_rs) && al8(d->dQ, d->dq_bs, d->dq_rs) && al8(d->dK, d->dk_bs, d->dk_rs) &&
+                         al8(d->dV, d->dv_bs, d->dv_rs);
+    if (mfma_ok) {
+      const size_t ldsm = ((size_t)3 * 64 * (f.dh + 4) + (size_t)2 * 64 * 72) * 2;
+      const unsigned nbm = (unsigned)((long long)f.B * f.H);
+      switch (f.dh) {
+        case 16: hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), dim3(nbm), dim3(64), ldsm, st, a); break;
+        case 20: hipLaunchKernelGGL((attn_bwd_mfma_kernel<20>), dim3(nbm), dim3(64), ldsm, st, a); break;
+        case 32: hipLaunchKernelGGL((attn_bwd_mfma_kernel<32>), dim3(nbm), dim3(64), ldsm, st, a); break;
+        case 64: hipLaunchKernelGGL((attn_bwd_mfma_kernel<64>), dim3(nbm), dim3(64), ldsm, st, a); break;
+        default: hipLaunchKernelGGL((attn_bwd_mfma_kernel<80>), dim3(nbm), dim3(64), ldsm, st, a); break;
+      }
+      DMT_CHECK_LAUNCH("dmt_attn_bwd(mfma)");
+      return DMT_OK;
+    }
+  }
   int r = (d->f.dtype == DMT_F32) ? launch_bwd<float>(a, nw, lds, st) : launch_bwd<bf16_t>(a, nw, lds, st);
   if (r != 0) { dmt_set_error("dmt_attn_bwd: head dim %d not instantiated (4,8,16,20,32,64,80)", d->f.dh); return DMT_ERR_UNSUPPORTED; }
   DMT_CHECK_LAUNCH("dmt_attn_bwd");

@@ -1,7 +1,7 @@
 """End-to-end parity of the HIP path with the CPU oracle: forward logits, loss, every gradient, train steps.
 
 Tolerances (stated): fp32 path -- logits |d| <= 2e-4 absolute (values are O(1)), loss rel 1e-5,
-gradients: L2 error <= 2e-3 of the tensor's L2 norm;  bf16 path -- logits 6e-2, loss rel 3e-2, gradient L2 error <= 0.15
+gradients: L2 error <= 2e-3 of the tensor's L2 norm;  bf16 path -- logits 6e-2, loss rel 3e-2, gradient L2 error <= 0.2
 (bf16 activations flip borderline relu units in a 24-example batch; tensors whose true gradient is ~0 are measured
 against the global gradient scale).
 """
@@ -17,7 +17,7 @@ from tests.util import small_specs, sparse_to_dense_tables, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: dict(logit=2e-4, loss=1e-5, grad=2e-3, floor=1e-6), torch.bfloat16: dict(logit=6e-2, loss=3e-2, grad=0.15, floor=3e-3)}
+TOL = {torch.float32: dict(logit=2e-4, loss=1e-5, grad=2e-3, floor=1e-6), torch.bfloat16: dict(logit=6e-2, loss=3e-2, grad=0.2, floor=3e-3)}
 
 
 def _setup(cuda, dtype, B=24, seed=5, lengths="ragged", weights="random", seq_lens=None):
