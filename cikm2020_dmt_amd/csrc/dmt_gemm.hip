@@ -36,6 +36,7 @@ struct GemmArgs {
   int k_per_split;
   int out_f32;
   int vec_epi;
+  int fast_ok;   // operand extents fit the 32-bit buffer offsets
 };
 
 union Vec16 {
@@ -59,29 +60,10 @@ template <> __device__ __forceinline__ bf16_t vget<bf16_t>(const Vec16& v, int i
 //   elem(r, k) = P[r*rs + k*cs];  rows >= R_real read as 0 (or 1 for the ones row), k >= k_end read as 0.
 // MODE 0: k contiguous (cs == 1), 16-byte vectors along k;  MODE 1: rows contiguous (rs == 1), vectors along rows,
 // lanes along k;  MODE 2: arbitrary strides, scalar loads.  All register indexing is compile-time (no scratch).
-template <typename T, int MODE, bool GUARD>
+template <typename T, int MODE>
 __device__ __forceinline__ void load_tile(Vec16 (&reg)[Cfg<T>::NV], const T* __restrict__ P, long long rs, long long cs,
                                           int row0, int k0, int R_real, int k_end, int ones_row, int tid) {
   constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK;
-  if constexpr (!GUARD) {
-    // interior tile, full k-step: no predicates at all in the hot loop
-#pragma unroll
-    for (int p = 0; p < Cfg<T>::NV; ++p) {
-      const int v = tid + p * NT;
-      if constexpr (MODE == 0) {
-        reg[p].u = *reinterpret_cast<const uint4*>(P + (long long)(row0 + v / (BK / EPV)) * rs + (k0 + (v % (BK / EPV)) * EPV));
-      } else if constexpr (MODE == 1) {
-        reg[p].u = *reinterpret_cast<const uint4*>(P + (long long)(k0 + (v % BK)) * cs + (row0 + (v / BK) * EPV));
-      } else {
-        const T* src = P + (long long)(row0 + v / (BK / EPV)) * rs + (long long)(k0 + (v % (BK / EPV)) * EPV) * cs;
-        Vec16 x;
-#pragma unroll
-        for (int i = 0; i < EPV; ++i) vset<T>(x, i, src[(long long)i * cs]);
-        reg[p] = x;
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int p = 0; p < Cfg<T>::NV; ++p) {
     const int v = tid + p * NT;
@@ -154,6 +136,60 @@ __device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)
   }
 }
 
+// ---- hot-loop loads: one buffer descriptor per operand and block (base = the block's first row, so per-thread byte
+// offsets stay small), per-thread voffsets computed ONCE, the k position travels in a scalar register.  Rows past the end
+// of a k-contiguous operand fall outside the descriptor's range and read as 0 (hardware bounds check), so M / N tails
+// need no predicate.  Zero VALU address math per load.
+template <typename T, int MODE>
+struct FastLoad {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[Cfg<T>::NV];
+  long long kstride_bytes;   // bytes per unit of k
+
+  __device__ __forceinline__ void init(const T* P, long long rs, long long cs, int row0, int R_real, int K, int tid) {
+    constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK;
+    long long valid_elems;
+    const T* base;
+    if constexpr (MODE == 0) {
+      base = P + (long long)row0 * rs;
+      valid_elems = (R_real > row0) ? ((long long)(R_real - row0 - 1) * rs + K) : 0;
+      kstride_bytes = (long long)sizeof(T);
+#pragma unroll
+      for (int p = 0; p < Cfg<T>::NV; ++p) {
+        const int v = tid + p * NT;
+        voff[p] = (int)(((long long)(v / (BK / EPV)) * rs + (v % (BK / EPV)) * EPV) * (long long)sizeof(T));
+      }
+    } else {
+      base = P + row0;
+      valid_elems = (long long)(K - 1) * cs + (R_real - row0);
+      kstride_bytes = cs * (long long)sizeof(T);
+#pragma unroll
+      for (int p = 0; p < Cfg<T>::NV; ++p) {
+        const int v = tid + p * NT;
+        voff[p] = (int)(((long long)(v % BK) * cs + (v / BK) * EPV) * (long long)sizeof(T));
+      }
+    }
+    long long bytes = valid_elems * (long long)sizeof(T);
+    bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+  }
+
+  __device__ __forceinline__ void load(Vec16 (&reg)[Cfg<T>::NV], int k0) const {
+    const int soff = (int)((long long)k0 * kstride_bytes);
+#pragma unroll
+    for (int p = 0; p < Cfg<T>::NV; ++p) {
+      auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[p], soff, 0);
+      reg[p].u = make_uint4((unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]);
+    }
+  }
+};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 constexpr int EPI_LD = 68;                       // fp32 words per staged epilogue row (64 + 4 pad)
 constexpr int EPI_WAVE_WORDS = 32 * EPI_LD;      // one wave stages 32 rows x 64 cols at a time
 constexpr int SMEM_BYTES_OPER = 2 * BM * 72 * 2; // As + Bs (bf16: 128*72*2 B each; fp32: 128*20*4 B each)
@@ -195,12 +231,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   Vec16 ra[Cfg<T>::NV], rb[Cfg<T>::NV];
   const bool a_full = (m0 + BM <= M_real), b_full = (n0 + BN <= g.N);   // block-uniform
   // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
+  // fast path per operand: full k-step and (k-contiguous: no ones row in this tile; row-contiguous: full tile)
+  const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
+  const bool a_fast = g.fast_ok && (AMODE == 0 ? !ones_here : (AMODE == 1 ? a_full : false));
+  const bool b_fast = g.fast_ok && (BMODE == 0 ? true : (BMODE == 1 ? b_full : false));
+  FastLoad<T, (AMODE == 1 ? 1 : 0)> fa;
+  FastLoad<T, (BMODE == 1 ? 1 : 0)> fb;
+  fa.init(A, g.a_rs, g.a_cs, m0, M_real, g.K, tid);
+  fb.init(Bp, g.b_cs, g.b_rs, n0, g.N, g.K, tid);
   auto load_both = [&](int kq) {
     const bool kfull = (kq + BK <= k_end);
-    if (a_full && kfull) load_tile<T, AMODE, false>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
-    else load_tile<T, AMODE, true>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
-    if (b_full && kfull) load_tile<T, BMODE, false>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
-    else load_tile<T, BMODE, true>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
+    if (a_fast && kfull) fa.load(ra, kq);
+    else load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
+    if (b_fast && kfull) fb.load(rb, kq);
+    else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
   };
   load_both(k_begin);
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
@@ -293,10 +337,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] += bf2f(rv.h[e]);
               }
-              Vec16 o;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o.h[e] = f2bf(x[e]);
-              *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o.u;
+              uint4 o;
+              o.x = cvt_pk_bf16(x[0], x[1]); o.y = cvt_pk_bf16(x[2], x[3]);
+              o.z = cvt_pk_bf16(x[4], x[5]); o.w = cvt_pk_bf16(x[6], x[7]);
+              *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o;
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
@@ -416,6 +460,13 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };
   g.vec_epi = (d->in_dtype == DMT_BF16 && d->out_dtype == DMT_BF16 && split == 1 && !d->a_ones_row && al16(d->C, d->ldc, d->c_bs) &&
                al16(d->gate, d->ldg, d->gate_bs) && al16(d->resid, d->ldr, d->resid_bs)) ? 1 : 0;
+  {
+    // 32-bit buffer offsets: per-thread voffset spans <= 128 rows (mode 0) or BK k-rows (mode 1); the scalar k offset
+    // spans the whole reduction extent of one operand
+    const long long a_k_bytes = (long long)d->K * (g.a_mode == 1 ? d->a_cs : 1) * esz, b_k_bytes = (long long)d->K * (g.b_mode == 1 ? d->b_rs : 1) * esz;
+    const long long a_v_bytes = (g.a_mode == 1 ? 64ll * d->a_cs : 128ll * d->a_rs) * esz, b_v_bytes = (g.b_mode == 1 ? 64ll * d->b_rs : 128ll * d->b_cs) * esz;
+    g.fast_ok = (a_k_bytes + a_v_bytes < 0x7FFFFFFFll && b_k_bytes + b_v_bytes < 0x7FFFFFFFll) ? 1 : 0;
+  }
   if (d->in_dtype == DMT_F32) launch_gemm<float>(g, grid, st); else launch_gemm<bf16_t>(g, grid, st);
   DMT_CHECK_LAUNCH("dmt_gemm");
   return DMT_OK;

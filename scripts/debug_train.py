@@ -1,5 +1,5 @@
 import numpy as np, torch, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import dmt_oracle as O, dmt_oracle_torch as OT
 from cikm2020_dmt_amd.data_feed.synthetic import make_batch
 from cikm2020_dmt_amd.train import Trainer

@@ -1,6 +1,6 @@
 """Per-launch timing of the GEMM calls of one train step (HIP events), grouped by shape/layout."""
 import sys, os, collections
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cikm2020_dmt_amd import ops, spec as S
 from cikm2020_dmt_amd.data_feed.synthetic import make_batch
