@@ -37,6 +37,7 @@ struct GemmArgs {
   int out_f32;
   int vec_epi;
   int fast_ok;   // operand extents fit the 32-bit buffer offsets
+  int gx, gy, gz, inner, panels;   // XCD-aware block remap (see gemm_kernel)
 };
 
 union Vec16 {
@@ -87,8 +88,9 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[Cfg<T>::NV], const T* __r
           if (k + i < k_end) vset<T>(x, i, one_val<T>());
       }
     } else if constexpr (MODE == 1) {
-      const int k = k0 + (v % BK);
-      const int r = row0 + (v / BK) * EPV;
+      // bf16: thread owns a 4(k) x 8(rows) block (vector p = k offset p) so the LDS store can transpose it in registers
+      const int k = k0 + (sizeof(T) == 2 ? (tid % 16) * 4 + p : (v % BK));
+      const int r = row0 + (sizeof(T) == 2 ? (tid / 16) * EPV : (v / BK) * EPV);
       if (k < k_end) {
         const T* src = P + (long long)k * cs + r;
         if (r + EPV <= R_real) {
@@ -120,6 +122,25 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[Cfg<T>::NV], const T* __r
 template <typename T, int MODE>
 __device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)[Cfg<T>::NV], int tid) {
   constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
+  if constexpr (MODE == 1 && sizeof(T) == 2) {
+    // reg[p].h[i] = elem(row r0+i, k q0+p): transpose the 4 x 8 block -> 8 rows x (4 consecutive k) = 8-byte LDS stores
+    const int q0 = (tid % 16) * 4, r0 = (tid / 16) * EPV;
+    const unsigned a0[4] = {reg[0].u.x, reg[0].u.y, reg[0].u.z, reg[0].u.w};
+    const unsigned a1[4] = {reg[1].u.x, reg[1].u.y, reg[1].u.z, reg[1].u.w};
+    const unsigned a2[4] = {reg[2].u.x, reg[2].u.y, reg[2].u.z, reg[2].u.w};
+    const unsigned a3[4] = {reg[3].u.x, reg[3].u.y, reg[3].u.z, reg[3].u.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      uint2 lo, hi;   // rows r0+2w (low halves) and r0+2w+1 (high halves)
+      lo.x = (a0[w] & 0xFFFFu) | (a1[w] << 16);
+      lo.y = (a2[w] & 0xFFFFu) | (a3[w] << 16);
+      hi.x = (a0[w] >> 16) | (a1[w] & 0xFFFF0000u);
+      hi.y = (a2[w] >> 16) | (a3[w] & 0xFFFF0000u);
+      *reinterpret_cast<uint2*>(S + (r0 + 2 * w) * LDK + q0) = lo;
+      *reinterpret_cast<uint2*>(S + (r0 + 2 * w + 1) * LDK + q0) = hi;
+    }
+    return;
+  }
 #pragma unroll
   for (int p = 0; p < Cfg<T>::NV; ++p) {
     const int v = tid + p * NT;
@@ -166,7 +187,10 @@ struct FastLoad {
 #pragma unroll
       for (int p = 0; p < Cfg<T>::NV; ++p) {
         const int v = tid + p * NT;
-        voff[p] = (int)(((long long)(v % BK) * cs + (v / BK) * EPV) * (long long)sizeof(T));
+        if constexpr (sizeof(T) == 2)
+          voff[p] = (int)(((long long)((tid % 16) * 4 + p) * cs + (tid / 16) * EPV) * (long long)sizeof(T));
+        else
+          voff[p] = (int)(((long long)(v % BK) * cs + (v / BK) * EPV) * (long long)sizeof(T));
       }
     }
     long long bytes = valid_elems * (long long)sizeof(T);
@@ -207,10 +231,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bz = blockIdx.z;
+  // XCD-aware remap of the 1-D grid.  The dispatcher places workgroup L on XCD (L % 8); each XCD has a private L2.
+  // All tiles that share an operand panel are given ids with the same (L % 8) and consecutive (L / 8), so they run
+  // concurrently on ONE XCD and the panel is fetched into that L2 once:
+  //   no split-K : panel = (M tile, batch), swept over its N tiles          (A panel shared)
+  //   split-K    : panel = K chunk, swept over its (N tile, M tile) pairs   (both operand chunks shared)
+  // A wrong placement guess costs speed only, never correctness.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, jq = L >> 3;
+  const int pi = jq / g.inner, in = jq - pi * g.inner;
+  const int P = pi * 8 + xcd;
+  if (P >= g.panels) return;
+  int bx, by, bz;
+  if (g.split_k > 1) { bz = P; bx = in % g.gx; by = in / g.gx; }
+  else { by = P % g.gy; bz = P / g.gy; bx = in; }
   const int bt = bz / g.split_k;
   const int ks = bz - bt * g.split_k;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int k_begin = ks * g.k_per_split;
   const int k_end = (k_begin + g.k_per_split < g.K) ? (k_begin + g.k_per_split) : g.K;
   if (k_begin >= k_end && g.split_k > 1) return;
@@ -453,8 +490,11 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   long long kps = (d->K + split - 1) / split;
   kps = ((kps + bk - 1) / bk) * bk;
   g.k_per_split = (int)kps;
-  dim3 grid((unsigned)((d->N + BN - 1) / BN), (unsigned)((d->M + BM - 1) / BM), (unsigned)(batch * split));
-  DMT_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "dmt_gemm: grid too large (M=%d batch*split=%d)", d->M, batch * split);
+  g.gx = (d->N + BN - 1) / BN; g.gy = (d->M + BM - 1) / BM; g.gz = batch * split;
+  if (split > 1) { g.inner = g.gx * g.gy; g.panels = g.gz; } else { g.inner = g.gx; g.panels = g.gy * g.gz; }
+  const long long nblk = 8ll * g.inner * ((g.panels + 7) / 8);
+  DMT_CHECK_ARG(nblk < 0x7FFFFFFFll, "dmt_gemm: grid too large");
+  dim3 grid((unsigned)nblk);
   hipStream_t st = (hipStream_t)stream;
   // vectorised epilogue: bf16 in/out, no split / ones row, every row of C / gate / resid 16-byte aligned
   auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };
