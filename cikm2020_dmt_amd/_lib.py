@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("in_dtype", c_i32), ("out_dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
                 ("A", c_vp), ("a_rs", c_i64), ("a_cs", c_i64), ("B", c_vp), ("b_rs", c_i64), ("b_cs", c_i64),
                 ("C", c_vp), ("ldc", c_i64), ("bias", c_vp), ("act_ncols", c_i32), ("gate", c_vp), ("ldg", c_i64),
-                ("resid", c_vp), ("ldr", c_i64), ("a_ones_row", c_i32), ("c_last", c_vp), ("split_k", c_i32),
+                ("resid", c_vp), ("ldr", c_i64), ("a_ones_row", c_i32), ("c_last", c_vp), ("split_k", c_i32), ("accumulate", c_i32),
                 ("batch", c_i32), ("a_bs", c_i64), ("b_bs", c_i64), ("c_bs", c_i64), ("bias_bs", c_i64),
                 ("gate_bs", c_i64), ("resid_bs", c_i64), ("clast_bs", c_i64)]
 

@@ -200,7 +200,48 @@ __device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, 
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
-// A fragment of a TRANSPOSED [64][DHS] bf16 LDS tile: element i = tile[16u + (i&3) + 8(i>>2) + 4*half][j]
+constexpr int TLD = 72;   // row stride (elements) of a transposed [dh][64 rows] bf16 LDS tile: 144 B = 9 x 16 B (odd)
+
+// Stage X[row][j] (global, `n_rows` valid rows, row stride rs) as the TRANSPOSED tile Xt[j][row] (row < 64, zero filled).
+// Each work item moves a 4(rows) x 4(dims) block: four 8-byte loads, a 4x4 bf16 transpose in registers, four 8-byte
+// LDS stores.  Lanes run along rows first, so the stores of 16 lanes cover 128 contiguous bytes of one LDS row.
+template <int DH>
+__device__ __forceinline__ void stage_transposed(bf16_t* __restrict__ Xt, const bf16_t* __restrict__ Xg, long long rs, int n_rows, int lane) {
+  constexpr int NJ = DH / 4;
+  for (int item = lane; item < 16 * NJ; item += 64) {
+    const int rg = item & 15, jg = item >> 4;
+    const int r0 = rg * 4, j0 = jg * 4;
+    uint2 a = make_uint2(0u, 0u), b = a, c = a, d = a;
+    if (r0 + 0 < n_rows) a = *reinterpret_cast<const uint2*>(Xg + (long long)(r0 + 0) * rs + j0);
+    if (r0 + 1 < n_rows) b = *reinterpret_cast<const uint2*>(Xg + (long long)(r0 + 1) * rs + j0);
+    if (r0 + 2 < n_rows) c = *reinterpret_cast<const uint2*>(Xg + (long long)(r0 + 2) * rs + j0);
+    if (r0 + 3 < n_rows) d = *reinterpret_cast<const uint2*>(Xg + (long long)(r0 + 3) * rs + j0);
+    uint2 o0, o1, o2, o3;
+    o0.x = (a.x & 0xFFFFu) | (b.x << 16);      o0.y = (c.x & 0xFFFFu) | (d.x << 16);
+    o1.x = (a.x >> 16) | (b.x & 0xFFFF0000u);  o1.y = (c.x >> 16) | (d.x & 0xFFFF0000u);
+    o2.x = (a.y & 0xFFFFu) | (b.y << 16);      o2.y = (c.y & 0xFFFFu) | (d.y << 16);
+    o3.x = (a.y >> 16) | (b.y & 0xFFFF0000u);  o3.y = (c.y >> 16) | (d.y & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(Xt + (j0 + 0) * TLD + r0) = o0;
+    *reinterpret_cast<uint2*>(Xt + (j0 + 1) * TLD + r0) = o1;
+    *reinterpret_cast<uint2*>(Xt + (j0 + 2) * TLD + r0) = o2;
+    *reinterpret_cast<uint2*>(Xt + (j0 + 3) * TLD + r0) = o3;
+  }
+}
+
+// A fragment (row j of X^T) in ACCUMULATOR slot order: element i <-> row 16u + (i&3) + 8(i>>2) + 4*half  (two 8-byte reads)
+__device__ __forceinline__ bf16x8_t frag_T_slots(const bf16_t* __restrict__ Xt, int u, int half, int j) {
+  union { bf16x8_t v; uint2 h[2]; } f;
+  f.h[0] = *reinterpret_cast<const uint2*>(Xt + j * TLD + 16 * u + 4 * half);
+  f.h[1] = *reinterpret_cast<const uint2*>(Xt + j * TLD + 16 * u + 8 + 4 * half);
+  return f.v;
+}
+
+// A fragment (row j of X^T) in NATURAL order: element i <-> row 16u + 8*half + i  (one 16-byte read)
+__device__ __forceinline__ bf16x8_t frag_T_rows(const bf16_t* __restrict__ Xt, int u, int half, int j) {
+  return *reinterpret_cast<const bf16x8_t*>(Xt + j * TLD + 16 * u + 8 * half);
+}
+
+// (legacy) A fragment from a NATURAL [64][DHS] tile, 2-byte reads: element i = tile[16u + (i&3) + 8(i>>2) + 4*half][j]
 template <int DHS>
 __device__ __forceinline__ bf16x8_t lds_frag_keyslots(const bf16_t* __restrict__ tile, int u, int half, int j) {
   union { bf16x8_t v; bf16_t e[8]; } f;
@@ -223,19 +264,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   const int b = (int)(wid / a.H), h = (int)(wid % a.H);
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
-  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem) + (long long)wave * 64 * DHS;
+  bf16_t* Vt = reinterpret_cast<bf16_t*>(smem) + (long long)wave * DH * TLD;
 
   const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
   const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
   const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
 
-  // ---- stage V (rows >= Tk zero filled: 0 * garbage must not make NaN)
-  for (int c = lane; c < 64 * (DH / 4); c += 64) {
-    const int row = c / (DH / 4), j = (c - row * (DH / 4)) * 4;
-    uint2 v = make_uint2(0u, 0u);
-    if (row < Tk) v = *reinterpret_cast<const uint2*>(Vg + (long long)row * a.v_rs + j);
-    *reinterpret_cast<uint2*>(Vs + row * DHS + j) = v;
-  }
+  // ---- stage V^T (keys >= Tk zero filled: 0 * garbage must not make NaN)
+  stage_transposed<DH>(Vt, Vg, a.v_rs, Tk, lane);
 
   // ---- S^T = K Q^T
   f32x16_t acc[2][2];
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bf16x8_t av = lds_frag_keyslots<DHS>(Vs, u, half, jj);
+      const bf16x8_t av = frag_T_slots(Vt, u, half, jj);
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[0][u], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[1][u], o[1], 0, 0, 0);
     }
@@ -403,29 +439,22 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
   const int b = (int)(wid / a.H), h = (int)(wid % a.H);
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Qs = Ks + 64 * DHS;
-  bf16_t* dOs = Qs + 64 * DHS;
-  bf16_t* PL = dOs + 64 * DHS;
-  bf16_t* DL = PL + 64 * PLD;
+  // three LDS regions; the [key][q] copies of P and dS reuse the K^T and dO^T regions once those are dead
+  constexpr int REG = (DH > 64 ? DH : 64) * TLD;
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* dOt = Kt + REG;
+  bf16_t* Qt = dOt + REG;
+  bf16_t* PL = Kt;
+  bf16_t* DL = dOt;
 
   const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
   const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
   const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
   const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
 
-  for (int c = lane; c < 64 * (DH / 4); c += 64) {
-    const int row = c / (DH / 4), j = (c - row * (DH / 4)) * 4;
-    uint2 kv = make_uint2(0u, 0u), qv = make_uint2(0u, 0u), dv = make_uint2(0u, 0u);
-    if (row < Tk) kv = *reinterpret_cast<const uint2*>(Kg + (long long)row * a.k_rs + j);
-    if (row < Tq) {
-      qv = *reinterpret_cast<const uint2*>(Qg + (long long)row * a.q_rs + j);
-      dv = *reinterpret_cast<const uint2*>(dOg + (long long)row * a.do_rs + j);
-    }
-    *reinterpret_cast<uint2*>(Ks + row * DHS + j) = kv;
-    *reinterpret_cast<uint2*>(Qs + row * DHS + j) = qv;
-    *reinterpret_cast<uint2*>(dOs + row * DHS + j) = dv;
-  }
+  stage_transposed<DH>(Kt, Kg, a.k_rs, Tk, lane);
+  stage_transposed<DH>(dOt, dOg, a.do_rs, Tq, lane);
+  stage_transposed<DH>(Qt, Qg, a.q_rs, Tq, lane);
 
   f32x16_t acc[2][2], dp[2][2];
 #pragma unroll
@@ -527,8 +556,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
         float ds = (key < klen) ? pv * (dp[kt][qt][r] - dot) / sc : 0.f;   // no gradient into masked keys
         if (qpad) { ds = 0.f; pv = (key < Tk) ? PADDING_NUM : 0.f; }       // constant rows: gradient reaches V only
         dp[kt][qt][r] = ds;
-        PL[key * PLD + q] = f2bf(pv);
-        DL[key * PLD + q] = f2bf(ds);
+        acc[kt][qt][r] = pv;
       }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -553,36 +581,67 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bf16x8_t av = lds_frag_keyslots<DHS>(Ks, u, half, jj);
+      const bf16x8_t av = frag_T_slots(Kt, u, half, jj);
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[0][u], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[1][u], o[1], 0, 0, 0);
     }
     store_rows_T<DH>(o, dQg, a.dq_rs, dt, l31, half, Tq);
   }
 
-  // ---- dV^T = dO^T P  and  dK^T = Q^T dS   (reduction over queries, natural k slots)
+  // ---- dV^T = dO^T P   (reduction over queries, natural k slots).  P goes to LDS as [key][q] over the dead K^T tile.
   bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
   bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        PL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = f2bf(acc[kt][qt][r]);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
-    f32x16_t ov[2], ok[2];
+    f32x16_t ov[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ov[0][r] = 0.f; ov[1][r] = 0.f; ok[0][r] = 0.f; ok[1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { ov[0][r] = 0.f; ov[1][r] = 0.f; }
     const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bf16x8_t ad = lds_frag_rows<DHS>(dOs, u, half, jj);
-      const bf16x8_t aq = lds_frag_rows<DHS>(Qs, u, half, jj);
+      const bf16x8_t ad = frag_T_rows(dOt, u, half, jj);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const int key = kt * 32 + l31;
-        const bf16x8_t bp = *reinterpret_cast<const bf16x8_t*>(PL + key * PLD + 16 * u + 8 * half);
-        const bf16x8_t bd = *reinterpret_cast<const bf16x8_t*>(DL + key * PLD + 16 * u + 8 * half);
+        const bf16x8_t bp = *reinterpret_cast<const bf16x8_t*>(PL + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
         ov[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bp, ov[kt], 0, 0, 0);
-        ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
       }
     }
     store_rows_T<DH>(ov, dVg, a.dv_rs, dt, l31, half, Tk);
+  }
+  // ---- dK^T = Q^T dS.  dS goes to LDS as [key][q] over the dead dO^T tile.
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        DL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = f2bf(dp[kt][qt][r]);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t ok[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ok[0][r] = 0.f; ok[1][r] = 0.f; }
+    const int jj = (dt * 32 + l31 < DH) ? dt * 32 + l31 : DH - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t aq = frag_T_rows(Qt, u, half, jj);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8_t bd = *reinterpret_cast<const bf16x8_t*>(DL + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
+        ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
+      }
+    }
     store_rows_T<DH>(ok, dKg, a.dk_rs, dt, l31, half, Tk);
   }
 }
@@ -656,7 +715,7 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
                        al8(d->resid, d->r_bs, d->r_rs) && al8(d->out, d->o_bs, d->o_rs);
   if (mfma_ok) {
     const int nwm = 4;
-    const size_t ldsm = (size_t)nwm * 64 * (d->dh + 4) * 2;
+    const size_t ldsm = (size_t)nwm * d->dh * 72 * 2;
     const unsigned nb = (unsigned)cdiv64((long long)d->B * d->H, nwm);
     switch (d->dh) {
       case 16: hipLaunchKernelGGL((attn_fwd_mfma_kernel<16>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
@@ -699,7 +758,7 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
                          al8(d->dout, d->do_bs, d->do_rs) && al8(d->dQ, d->dq_bs, d->dq_rs) && al8(d->dK, d->dk_bs, d->dk_rs) &&
                          al8(d->dV, d->dv_bs, d->dv_rs);
     if (mfma_ok) {
-      const size_t ldsm = ((size_t)3 * 64 * (f.dh + 4) + (size_t)2 * 64 * 72) * 2;
+      const size_t ldsm = (size_t)3 * (f.dh > 64 ? f.dh : 64) * 72 * 2;
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
       switch (f.dh) {
         case 16: hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), dim3(nbm), dim3(64), ldsm, st, a); break;

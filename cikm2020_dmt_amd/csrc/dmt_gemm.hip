@@ -30,7 +30,7 @@ struct GemmArgs {
   const void* resid; long long ldr;
   int a_ones_row;
   float* c_last;
-  int split_k, batch;
+  int split_k, batch, accumulate;
   long long a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs;
   int a_mode, b_mode;   // 0: k-contiguous vectors, 1: row-contiguous vectors, 2: scalar
   int k_per_split;
@@ -415,14 +415,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
         }
         if (row == ones_row) {
           float* cl = g.c_last + (long long)bt * g.clast_bs;
-          if (g.split_k > 1) atomicAdd(cl + col, x); else cl[col] = x;
+          if (g.split_k > 1 || g.accumulate) atomicAdd(cl + col, x); else cl[col] = x;
           continue;
         }
         if (g.out_f32) {
           float* Cp = reinterpret_cast<float*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
           if (g.resid && ks == 0)
             x += reinterpret_cast<const float*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col];
-          if (g.split_k > 1) atomicAdd(Cp, x); else *Cp = x;
+          if (g.split_k > 1 || g.accumulate) atomicAdd(Cp, x); else *Cp = x;
         } else {
           bf16_t* Cp = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
           if (g.resid)
@@ -462,7 +462,7 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   DMT_CHECK_ARG(d->A && d->B && d->C, "dmt_gemm: null operand");
   const int split = d->split_k > 1 ? d->split_k : 1;
   const int batch = d->batch > 1 ? d->batch : 1;
-  DMT_CHECK_ARG(split == 1 || d->out_dtype == DMT_F32, "dmt_gemm: split_k needs an fp32 C");
+  DMT_CHECK_ARG((split == 1 && !d->accumulate) || d->out_dtype == DMT_F32, "dmt_gemm: split_k / accumulate need an fp32 C");
   DMT_CHECK_ARG(split == 1 || (d->act_ncols == 0 && d->gate == nullptr), "dmt_gemm: split_k cannot fuse relu / gate");
   DMT_CHECK_ARG(!d->a_ones_row || d->c_last != nullptr, "dmt_gemm: a_ones_row needs c_last");
   DMT_CHECK_ARG(!d->a_ones_row || d->M >= 2, "dmt_gemm: a_ones_row needs M >= 2");
@@ -475,7 +475,7 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   g.bias = d->bias; g.act_ncols = d->act_ncols;
   g.gate = d->gate; g.ldg = d->ldg; g.resid = d->resid; g.ldr = d->ldr;
   g.a_ones_row = d->a_ones_row ? 1 : 0; g.c_last = d->c_last;
-  g.split_k = split; g.batch = batch;
+  g.split_k = split; g.batch = batch; g.accumulate = d->accumulate ? 1 : 0;
   g.a_bs = d->a_bs; g.b_bs = d->b_bs; g.c_bs = d->c_bs; g.bias_bs = d->bias_bs; g.gate_bs = d->gate_bs;
   g.resid_bs = d->resid_bs; g.clast_bs = d->clast_bs;
   g.out_f32 = (d->out_dtype == DMT_F32);
@@ -498,7 +498,7 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // vectorised epilogue: bf16 in/out, no split / ones row, every row of C / gate / resid 16-byte aligned
   auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };
-  g.vec_epi = (d->in_dtype == DMT_BF16 && d->out_dtype == DMT_BF16 && split == 1 && !d->a_ones_row && al16(d->C, d->ldc, d->c_bs) &&
+  g.vec_epi = (d->in_dtype == DMT_BF16 && d->out_dtype == DMT_BF16 && split == 1 && !d->accumulate && !d->a_ones_row && al16(d->C, d->ldc, d->c_bs) &&
                al16(d->gate, d->ldg, d->gate_bs) && al16(d->resid, d->ldr, d->resid_bs)) ? 1 : 0;
   {
     // 32-bit buffer offsets: per-thread voffset spans <= 128 rows (mode 0) or BK k-rows (mode 1); the scalar k offset

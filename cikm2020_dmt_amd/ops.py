@@ -69,7 +69,7 @@ def require_cuda(*ts):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_ncols=0, gate=None, ldg=0, resid=None,
-         ldr=0, ones_row=False, c_last=None, split_k=1, batch=1, a_bs=0, b_bs=0, c_bs=0, bias_bs=0, gate_bs=0,
+         ldr=0, ones_row=False, c_last=None, split_k=1, accumulate=False, batch=1, a_bs=0, b_bs=0, c_bs=0, bias_bs=0, gate_bs=0,
          resid_bs=0, clast_bs=0):
     require_cuda(A, Bm, out)
     d = L.GemmDesc()
@@ -88,6 +88,7 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
     d.a_ones_row = 1 if ones_row else 0
     d.c_last = c_last.data_ptr() if c_last is not None else None
     d.split_k, d.batch = split_k, batch
+    d.accumulate = 1 if accumulate else 0
     d.a_bs, d.b_bs, d.c_bs, d.bias_bs, d.gate_bs, d.resid_bs, d.clast_bs = a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs
     with _Timed("gemm_%s" % ("bf16" if A.dtype == BF16 else "f32"), 2.0 * M * N * K * max(batch, 1)):
         L.call("dmt_gemm", C.byref(d), stream_ptr())
@@ -139,16 +140,42 @@ def linear_backward_input(dz, w: Weight, gate=None, resid=None, out=None):
     return out
 
 
-def linear_backward_weight(x, dz, want_bias=True):
-    """dW[K,N] = x^T dz, db[N] = colsum(dz) (ones row), fp32, split over the (long) row dimension."""
+def _grad_view(leaf):
+    """The fp32 gradient-arena view behind a parameter leaf (or a basic slice of one), if it can be accumulated into
+    in place: 2-D with unit inner stride, or 1-D contiguous."""
+    g = getattr(leaf, "grad", None)
+    if g is None:
+        base = getattr(leaf, "_base", None)
+        if base is None or base.grad is None or leaf.dim() != base.dim():
+            return None
+        # a basic slice `base[..., a:b]` / `base[a:b]`: same strides, offset inside the base storage
+        off = leaf.storage_offset() - base.storage_offset()
+        if off < 0 or leaf.stride() != base.stride():
+            return None
+        g = base.grad.as_strided(leaf.shape, base.grad.stride(), base.grad.storage_offset() + off)
+    if g.dtype != F32 or (g.dim() == 2 and g.shape[1] > 1 and g.stride(1) != 1) or (g.dim() == 1 and g.numel() > 1 and g.stride(0) != 1):
+        return None
+    return g
+
+
+def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
+    """dW[K,N] = x^T dz, db[N] = colsum(dz) (ones row), fp32, split over the (long) row dimension.
+    When the parameter leaves expose their gradient-arena views the result is ACCUMULATED there by the kernel
+    (fp32 atomics) and (None, None) is returned -- no temporary, no zero fill, no autograd add."""
     M, K = x.shape
     N = dz.shape[1]
     ldx, ldz = _row_major2d(x, "x"), _row_major2d(dz, "dz")
-    dW = torch.zeros((K, N), dtype=F32, device=x.device)
-    db = torch.zeros((N,), dtype=F32, device=x.device) if want_bias else None
+    gw = _grad_view(w_leaf) if w_leaf is not None else None
+    gb = _grad_view(b_leaf) if (b_leaf is not None and want_bias) else None
     rows = K + 1 if want_bias else K
     tiles = ((rows + 127) // 128) * ((N + 127) // 128)
     split = _pick_split(tiles, M)
+    if gw is not None and (gb is not None or not want_bias):
+        gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
+             split_k=split, accumulate=True)
+        return None, None
+    dW = torch.zeros((K, N), dtype=F32, device=x.device)
+    db = torch.zeros((N,), dtype=F32, device=x.device) if want_bias else None
     gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, dW, N, ones_row=want_bias, c_last=db, split_k=split)
     return dW, db
 
@@ -170,6 +197,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
         y = linear_forward(x2, w, b_leaf, act_ncols=act_ncols, out_dtype=out_dtype)
         ctx.w = w
+        ctx.leaves = (w_leaf, b_leaf)
         ctx.act_ncols = act_ncols
         ctx.xshape = x.shape
         ctx.has_bias = b_leaf is not None
@@ -188,7 +216,7 @@ class LinearFn(torch.autograd.Function):
         elif dz.stride(-1) != 1:
             dz = dz.contiguous()
         dx = linear_backward_input(dz, ctx.w) if ctx.needs_input_grad[0] else None
-        dW, db = linear_backward_weight(x2, dz, want_bias=ctx.has_bias)
+        dW, db = linear_backward_weight(x2, dz, want_bias=ctx.has_bias, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
         if dx is not None:
             dx = dx.reshape(ctx.xshape)
         return dx, dW, db, None, None, None
@@ -209,6 +237,7 @@ class FFNFn(torch.autograd.Function):
         h = linear_forward(x2, w1, b1_leaf, act_ncols=w1.f32.shape[1])
         s = linear_forward(h, w2, b2_leaf, resid=x2)
         ctx.w1, ctx.w2 = w1, w2
+        ctx.leaves = (w1_leaf, b1_leaf, w2_leaf, b2_leaf)
         ctx.save_for_backward(x2, h)
         ctx.xshape = x.shape
         return s.reshape(x.shape)
@@ -220,9 +249,9 @@ class FFNFn(torch.autograd.Function):
         if ds2.stride(-1) != 1:
             ds2 = ds2.contiguous()
         dh = linear_backward_input(ds2, ctx.w2, gate=h)          # (ds W2^T) * (h > 0)
-        dW2, db2 = linear_backward_weight(h, ds2)
+        dW2, db2 = linear_backward_weight(h, ds2, w_leaf=ctx.leaves[2], b_leaf=ctx.leaves[3])
         dx = linear_backward_input(dh, ctx.w1, resid=ds2)        # dh W1^T + ds (residual branch)
-        dW1, db1 = linear_backward_weight(x2, dh)
+        dW1, db1 = linear_backward_weight(x2, dh, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
         return dx.reshape(ctx.xshape), dW1, db1, dW2, db2, None, None
 
 

@@ -163,6 +163,7 @@ typedef struct {
   int32_t a_ones_row;          /* 1: logical row M-1 of A is all ones; its output row goes to c_last */
   float* c_last;               /* fp32 [N] (bias gradient) when a_ones_row                          */
   int32_t split_k;             /* >1: K split over workgroups, fp32 atomicAdd into C (C must be fp32, zeroed) */
+  int32_t accumulate;          /* 1: C (fp32) and c_last are accumulated into (atomicAdd) even without split_k  */
   int32_t batch;               /* >=1 */
   int64_t a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs;   /* per-batch element strides    */
 } dmt_gemm_desc;
