@@ -267,7 +267,12 @@ __global__ __launch_bounds__(256) void finish_heads_kernel(const uint32_t* __res
   if (e == n - 1) n_uniq[0] = (k[e] >= invalid) ? s : s + 1;
 }
 
-// One wavefront per chunk of 64 sorted entries; lane j owns element j of the (<= 64 wide) row.
+// One wavefront per chunk of 64 sorted entries.
+//   phase A (parallel): lane i decodes entry i -> source address, scale (w/sum w or sqrt(d)), row width, segment id;
+//   phase B: the entries are walked in order, lane j owning element j of the (<= 64 wide) gradient row; the loads of
+//            four consecutive entries are issued together before they are consumed (the chunk is otherwise a chain of
+//            dependent L2/HBM round trips).  Runs of equal rows are summed in registers and flushed with ONE fp32
+//            atomicAdd per element; only runs that cross a chunk boundary meet another wave's partial.
 template <typename GT_>
 __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_desc d, const uint32_t* __restrict__ skeys,
                                                              const uint32_t* __restrict__ svals, const int* __restrict__ seg,
@@ -280,50 +285,72 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   const long long e0 = wave * 64;
   if (e0 >= n) return;
   const long long e = e0 + lane;
-  uint32_t my_key = (e < n) ? skeys[e] : (uint32_t)d.total_rows;
-  uint32_t my_val = (e < n) ? svals[e] : 0u;
-  int my_seg = (e < n) ? seg[e] : -1;
-  const int cnt = (int)((n - e0) < 64 ? (n - e0) : 64);
-  float acc = 0.f;
-  int cur_seg = -1, cur_dim = 0;
-  for (int i = 0; i < cnt; ++i) {
-    const uint32_t key = __shfl(my_key, i, 64);
-    if (key >= (uint32_t)d.total_rows) break;      // invalid keys sort last
-    const uint32_t ev = __shfl(my_val, i, 64);
-    const int sg = __shfl(my_seg, i, 64);
-    int f = 0;
-    while (f + 1 < d.n_features && (long long)ev >= s_base[f + 1]) ++f;
-    const dmt_gather_feature& F = d.feat[f];
-    long long r = (long long)ev - s_base[f];
-    const long long per = (long long)d.B * F.T;
-    int kind = 0;
-    if (F.pooled_off >= 0) {
-      if (r >= per) { kind = 1; r -= per; }
-    } else {
-      kind = 1;
-    }
-    const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
-    if (sg != cur_seg) {
-      if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
-      acc = 0.f;
-      cur_seg = sg;
-      cur_dim = F.dim;
-    }
-    if (lane < F.dim) {
-      float gv, sc;
+  // ---- phase A
+  const GT_* my_src = nullptr;
+  float my_scale = 0.f;
+  int my_dim = 0, my_seg = -1;
+  if (e < n) {
+    const uint32_t key = skeys[e];
+    if (key < (uint32_t)d.total_rows) {
+      const uint32_t ev = svals[e];
+      my_seg = seg[e];
+      int f = 0;
+      while (f + 1 < d.n_features && (long long)ev >= s_base[f + 1]) ++f;
+      const dmt_gather_feature& F = d.feat[f];
+      long long r = (long long)ev - s_base[f];
+      const long long per = (long long)d.B * F.T;
+      int kind = 0;
+      if (F.pooled_off >= 0) {
+        if (r >= per) { kind = 1; r -= per; }
+      } else {
+        kind = 1;
+      }
+      const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
+      my_dim = F.dim;
       if (kind == 0) {
         const float w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
-        sc = w * F.inv_wsum[b];
-        gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dpooled) + (long long)b * d.ld_pooled + F.pooled_off + lane);
+        my_scale = w * F.inv_wsum[b];
+        my_src = reinterpret_cast<const GT_*>(d.dpooled) + (long long)b * d.ld_pooled + F.pooled_off;
       } else {
-        sc = d.seq_scale;
+        my_scale = d.seq_scale;
         if (F.seq_id == DMT_SEQ_TARGET)
-          gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + F.seq_off + lane);
+          my_src = reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + F.seq_off;
         else
-          gv = ldf<GT_>(reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) +
-                        ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off + lane);
+          my_src = reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) + ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off;
       }
-      acc += sc * gv;
+    }
+  }
+  const unsigned long long my_addr = (unsigned long long)my_src;
+  const unsigned my_lo = (unsigned)my_addr, my_hi = (unsigned)(my_addr >> 32);
+  // invalid keys sort last: the number of valid entries of this chunk
+  const unsigned long long vmask = __ballot(my_seg >= 0);
+  const int cnt = __popcll(vmask);
+  // ---- phase B
+  float acc = 0.f;
+  int cur_seg = -1, cur_dim = 0;
+  for (int i0 = 0; i0 < cnt; i0 += 4) {
+    float v[4], sc[4];
+    int sg[4], dm[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = (i0 + k < cnt) ? i0 + k : cnt - 1;
+      const unsigned lo = __shfl(my_lo, i, 64), hi = __shfl(my_hi, i, 64);
+      sc[k] = __shfl(my_scale, i, 64);
+      sg[k] = __shfl(my_seg, i, 64);
+      dm[k] = __shfl(my_dim, i, 64);
+      const GT_* src = reinterpret_cast<const GT_*>(((unsigned long long)hi << 32) | lo);
+      v[k] = (lane < dm[k]) ? ldf<GT_>(src + lane) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k >= cnt) break;
+      if (sg[k] != cur_seg) {
+        if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
+        acc = 0.f;
+        cur_seg = sg[k];
+        cur_dim = dm[k];
+      }
+      acc += sc[k] * v[k];
     }
   }
   if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
