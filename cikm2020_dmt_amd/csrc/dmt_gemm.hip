@@ -208,6 +208,23 @@ struct FastLoad {
   }
 };
 
+// Row-contiguous fast path: overwrite the elements of logical row `ones_row` (the all-ones row that yields the bias
+// gradient) in this thread's staged vectors.
+template <typename T>
+__device__ __forceinline__ void patch_ones_row(Vec16 (&reg)[Cfg<T>::NV], int row0, int ones_row, int tid) {
+  constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK;
+#pragma unroll
+  for (int p = 0; p < Cfg<T>::NV; ++p) {
+    const int v = tid + p * NT;
+    const int r = row0 + (sizeof(T) == 2 ? (tid / 16) * EPV : (v / BK) * EPV);
+    if (ones_row >= r && ones_row < r + EPV) {
+#pragma unroll
+      for (int i = 0; i < EPV; ++i)
+        if (r + i == ones_row) vset<T>(reg[p], i, one_val<T>());
+    }
+  }
+}
+
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   unsigned r;
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
@@ -269,16 +286,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   const bool a_full = (m0 + BM <= M_real), b_full = (n0 + BN <= g.N);   // block-uniform
   // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
   // fast path per operand: full k-step and (k-contiguous: no ones row in this tile; row-contiguous: full tile)
+  // Row tails never need a predicate on the fast path: k-contiguous operands read rows past the end as 0 (buffer bounds
+  // check); row-contiguous operands read whatever follows in memory (or 0 past the allocation), but those tile rows only
+  // feed output rows / columns >= M / N, which the epilogue never stores.  The ones row is patched in after the load.
   const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
-  const bool a_fast = g.fast_ok && (AMODE == 0 ? !ones_here : (AMODE == 1 ? a_full : false));
-  const bool b_fast = g.fast_ok && (BMODE == 0 ? true : (BMODE == 1 ? b_full : false));
+  const bool a_fast = g.fast_ok && (AMODE == 0 ? !ones_here : (AMODE == 1));
+  const bool b_fast = g.fast_ok && (BMODE == 0 || BMODE == 1);
+  (void)a_full; (void)b_full;
   FastLoad<T, (AMODE == 1 ? 1 : 0)> fa;
   FastLoad<T, (BMODE == 1 ? 1 : 0)> fb;
   fa.init(A, g.a_rs, g.a_cs, m0, M_real, g.K, tid);
   fb.init(Bp, g.b_cs, g.b_rs, n0, g.N, g.K, tid);
   auto load_both = [&](int kq) {
     const bool kfull = (kq + BK <= k_end);
-    if (a_fast && kfull) fa.load(ra, kq);
+    if (a_fast && kfull) {
+      fa.load(ra, kq);
+      if (AMODE == 1 && ones_here) patch_ones_row<T>(ra, m0, ones_row, tid);
+    }
     else load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
     if (b_fast && kfull) fb.load(rb, kq);
     else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
