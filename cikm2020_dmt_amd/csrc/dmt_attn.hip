@@ -646,6 +646,136 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Single-query attention (the decoder: the target item attends over the encoded sequence, Tq == 1).  Memory bound:
+// one wavefront per (example, head), lane k owns key k and streams its K / V rows straight from global in 4-element
+// chunks; q / dO are wave-uniform (broadcast) loads; P.V and dQ run with lanes along the head dim over coalesced rows.
+template <typename T> struct Chunk4;
+template <> struct Chunk4<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { const float4 x = *reinterpret_cast<const float4*>(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Chunk4<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[4]) {
+    const uint2 x = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xFFFF0000u); v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xFFFF0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[4]) {
+    uint2 o; o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+};
+
+template <typename T, int DH, bool BWD>
+__global__ __launch_bounds__(256) void attn_q1_kernel(const AttnArgs a) {
+  __shared__ float s_buf[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= (long long)a.B * a.H) return;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int Tk = a.Tk;
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : 1;
+  const float sc = sqrtf((float)DH);
+  const T* Qg = reinterpret_cast<const T*>(a.Q) + (long long)b * a.q_bs + h * DH;
+  const T* Kg = reinterpret_cast<const T*>(a.K) + (long long)b * a.k_bs + h * DH;
+  const T* Vg = reinterpret_cast<const T*>(a.V) + (long long)b * a.v_bs + h * DH;
+  const T* Kr = Kg + (long long)lane * a.k_rs;
+  const T* Vr = Vg + (long long)lane * a.v_rs;
+  const T* dOg = BWD ? reinterpret_cast<const T*>(a.dout) + (long long)b * a.do_bs + h * DH : nullptr;
+
+  float s = 0.f, dP = 0.f;
+  if (lane < Tk) {
+#pragma unroll 5
+    for (int c = 0; c < DH; c += 4) {
+      float kq[4], qq[4];
+      Chunk4<T>::ld(Kr + c, kq);
+      Chunk4<T>::ld(Qg + c, qq);
+      s = fmaf(qq[0], kq[0], s); s = fmaf(qq[1], kq[1], s); s = fmaf(qq[2], kq[2], s); s = fmaf(qq[3], kq[3], s);
+      if constexpr (BWD) {
+        float vv[4], dd[4];
+        Chunk4<T>::ld(Vr + c, vv);
+        Chunk4<T>::ld(dOg + c, dd);
+        dP = fmaf(dd[0], vv[0], dP); dP = fmaf(dd[1], vv[1], dP); dP = fmaf(dd[2], vv[2], dP); dP = fmaf(dd[3], vv[3], dP);
+      }
+    }
+    s = s / sc;
+    if (lane >= klen) s = PADDING_NUM;
+  }
+  const float m = wave_max(lane < Tk ? s : -3.0e38f);
+  const float e = (lane < Tk) ? expf(s - m) : 0.f;
+  const float sum = wave_sum(e);
+  float p = e / sum;
+  const bool qpad = (0 >= qlen);
+  if constexpr (!BWD) {
+    if (qpad) p = PADDING_NUM;
+    if (lane < Tk) s_buf[wave][lane] = p;
+    __builtin_amdgcn_wave_barrier();
+    const T* Rg = a.resid ? reinterpret_cast<const T*>(a.resid) + (long long)b * a.r_bs + h * DH : nullptr;
+    T* Og = reinterpret_cast<T*>(a.out) + (long long)b * a.o_bs + h * DH;
+    for (int j = lane; j < DH; j += 64) {
+      float o = 0.f;
+#pragma unroll 5
+      for (int k = 0; k < Tk; ++k) o = fmaf(s_buf[wave][k], ldf<T>(Vg + (long long)k * a.v_rs + j), o);
+      if (Rg) o += ldf<T>(Rg + j);
+      stf<T>(Og + j, o);
+    }
+  } else {
+    float ds = 0.f;
+    if (!qpad) {
+      const float dot = wave_sum(lane < Tk ? p * dP : 0.f);
+      ds = (lane < klen) ? p * (dP - dot) / sc : 0.f;
+    } else {
+      p = PADDING_NUM;
+    }
+    if (lane < Tk) {
+      s_buf[wave][lane] = ds;
+      T* dKr = reinterpret_cast<T*>(a.dK) + (long long)b * a.dk_bs + (long long)lane * a.dk_rs + h * DH;
+      T* dVr = reinterpret_cast<T*>(a.dV) + (long long)b * a.dv_bs + (long long)lane * a.dv_rs + h * DH;
+#pragma unroll 5
+      for (int c = 0; c < DH; c += 4) {
+        float qq[4], dd[4], ok[4], ov[4];
+        Chunk4<T>::ld(Qg + c, qq);
+        Chunk4<T>::ld(dOg + c, dd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ok[i] = ds * qq[i]; ov[i] = p * dd[i]; }
+        Chunk4<T>::st(dKr + c, ok);
+        Chunk4<T>::st(dVr + c, ov);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    T* dQg = reinterpret_cast<T*>(a.dQ) + (long long)b * a.dq_bs + h * DH;
+    for (int j = lane; j < DH; j += 64) {
+      float g = 0.f;
+#pragma unroll 5
+      for (int k = 0; k < Tk; ++k) g = fmaf(s_buf[wave][k], ldf<T>(Kg + (long long)k * a.k_rs + j), g);
+      stf<T>(dQg + j, g);
+    }
+  }
+}
+
+template <typename T, bool BWD>
+int launch_q1(const AttnArgs& a, hipStream_t st) {
+  const unsigned nb = (unsigned)cdiv64((long long)a.B * a.H, 4);
+  switch (a.dh) {
+    case 16: hipLaunchKernelGGL((attn_q1_kernel<T, 16, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((attn_q1_kernel<T, 20, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((attn_q1_kernel<T, 32, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((attn_q1_kernel<T, 64, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 80: hipLaunchKernelGGL((attn_q1_kernel<T, 80, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// 4-element chunks: 8-byte (bf16) / 16-byte (fp32) aligned rows
+static bool q1_aligned(int dtype, const void* q, long long s0, long long s1, int dh) {
+  const int esz = dtype == DMT_F32 ? 4 : 2;
+  return q == nullptr || (((uintptr_t)q) % (4 * esz) == 0 && s0 % 4 == 0 && s1 % 4 == 0 && dh % 4 == 0);
+}
+
 int fill_args(AttnArgs& a, const dmt_attn_desc* d) {
   a.B = d->B; a.H = d->H; a.dh = d->dh; a.Tq = d->Tq; a.Tk = d->Tk;
   a.Q = d->Q; a.q_bs = d->q_bs; a.q_rs = d->q_rs;
@@ -708,9 +838,14 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   const size_t lds = (size_t)nw * a.lds_per_wave * 4;
   DMT_CHECK_ARG(lds <= 160 * 1024, "dmt_attn_fwd: Tk*dh too large for LDS");
   hipStream_t st = (hipStream_t)stream;
+  if (d->Tq == 1 && q1_aligned(d->dtype, d->Q, d->q_bs, d->q_rs, d->dh) && q1_aligned(d->dtype, d->K, d->k_bs, d->k_rs, d->dh) &&
+      q1_aligned(d->dtype, d->V, d->v_bs, d->v_rs, d->dh)) {
+    const int r1 = (d->dtype == DMT_F32) ? launch_q1<float, false>(a, st) : launch_q1<bf16_t, false>(a, st);
+    if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_fwd(q1)"); return DMT_OK; }
+  }
   // bf16 MFMA path: 8-byte aligned rows (all strides multiples of 4 elements) and an instantiated head dim
   auto al8 = [](const void* q, long long s0, long long s1) { return q == nullptr || (((uintptr_t)q) % 8 == 0 && s0 % 4 == 0 && s1 % 4 == 0); };
-  const bool mfma_ok = d->dtype == DMT_BF16 && (d->dh == 20 || d->dh == 80 || d->dh == 16 || d->dh == 32 || d->dh == 64) &&
+  const bool mfma_ok = d->dtype == DMT_BF16 && d->Tq >= 8 && (d->dh == 20 || d->dh == 80 || d->dh == 16 || d->dh == 32 || d->dh == 64) &&
                        al8(d->Q, d->q_bs, d->q_rs) && al8(d->K, d->k_bs, d->k_rs) && al8(d->V, d->v_bs, d->v_rs) &&
                        al8(d->resid, d->r_bs, d->r_rs) && al8(d->out, d->o_bs, d->o_rs);
   if (mfma_ok) {
@@ -751,9 +886,18 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
   DMT_CHECK_ARG(lds <= 160 * 1024, "dmt_attn_bwd: Tk*dh too large for LDS");
   hipStream_t st = (hipStream_t)stream;
   {
+    const dmt_attn_desc& f1 = d->f;
+    if (f1.Tq == 1 && q1_aligned(f1.dtype, f1.Q, f1.q_bs, f1.q_rs, f1.dh) && q1_aligned(f1.dtype, f1.K, f1.k_bs, f1.k_rs, f1.dh) &&
+        q1_aligned(f1.dtype, f1.V, f1.v_bs, f1.v_rs, f1.dh) && q1_aligned(f1.dtype, d->dout, d->do_bs, d->do_rs, f1.dh) &&
+        q1_aligned(f1.dtype, d->dK, d->dk_bs, d->dk_rs, f1.dh) && q1_aligned(f1.dtype, d->dV, d->dv_bs, d->dv_rs, f1.dh)) {
+      const int r1 = (f1.dtype == DMT_F32) ? launch_q1<float, true>(a, st) : launch_q1<bf16_t, true>(a, st);
+      if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_bwd(q1)"); return DMT_OK; }
+    }
+  }
+  {
     auto al8 = [](const void* q, long long s0, long long s1) { return q == nullptr || (((uintptr_t)q) % 8 == 0 && s0 % 4 == 0 && s1 % 4 == 0); };
     const dmt_attn_desc& f = d->f;
-    const bool mfma_ok = f.dtype == DMT_BF16 && (f.dh == 20 || f.dh == 80 || f.dh == 16 || f.dh == 32 || f.dh == 64) &&
+    const bool mfma_ok = f.dtype == DMT_BF16 && f.Tq >= 8 && (f.dh == 20 || f.dh == 80 || f.dh == 16 || f.dh == 32 || f.dh == 64) &&
                          al8(f.Q, f.q_bs, f.q_rs) && al8(f.K, f.k_bs, f.k_rs) && al8(f.V, f.v_bs, f.v_rs) &&
                          al8(d->dout, d->do_bs, d->do_rs) && al8(d->dQ, d->dq_bs, d->dq_rs) && al8(d->dK, d->dk_bs, d->dk_rs) &&
                          al8(d->dV, d->dv_bs, d->dv_rs);

@@ -190,7 +190,9 @@ class VariableStore:
             self.leaf[name] = t
             if len(info.shape) == 2:
                 lp = self.lp[info.offset: info.offset + info.numel].view(info.shape) if bf else None
-                lp_t = torch.zeros((info.shape[1], info.shape[0]), dtype=torch.bfloat16, device=dev) if bf else None
+                # transposed shadow [N, K] with the row stride padded to 8 elements (16-byte rows for vector loads, e.g. K = 3047)
+                kpad = (info.shape[0] + 7) // 8 * 8
+                lp_t = torch.zeros((info.shape[1], kpad), dtype=torch.bfloat16, device=dev)[:, : info.shape[0]] if bf else None
                 self.weight[name] = Weight(t.detach(), lp, lp_t)
                 self._w2d.append(name)
         self.table: Dict[str, torch.Tensor] = {}
