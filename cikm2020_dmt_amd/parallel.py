@@ -32,8 +32,8 @@ def allreduce_dense_(flat_grads: torch.Tensor, async_op: bool = False):
 
 
 def _all_gather_cat(dst: torch.Tensor, loc: torch.Tensor, W: int, cap: int):
-    if loc.device.type != "cpu" and hasattr(dist, "all_gather_into_tensor"):
-        dist.all_gather_into_tensor(dst, loc)
+    if dist.get_backend() == "nccl" and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(dst, loc)      # one RCCL all-gather straight into the rank-major buffer
         return
     parts = [torch.empty_like(loc) for _ in range(W)]
     dist.all_gather(parts, loc)

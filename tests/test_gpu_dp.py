@@ -1,0 +1,78 @@
+"""Data-parallel train step with TWO ranks (both on the one visible GPU, gloo transport over device tensors): the
+exchange + merge + optimizer path of Trainer.train_step against the oracle's mean-of-tower gradients + TF-Adam.
+(RCCL itself needs >= 2 GPUs; the rank logic, sparse merge kernels and optimizer are identical.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import dmt_oracle as O
+from oracle import dmt_oracle_torch as OT
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from tests.util import small_specs
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q, steps):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    so, sp = small_specs()
+    P = O.init_params(so, seed=5)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False)
+    tr.store.load_state(P)
+    losses = []
+    for s in range(steps):
+        inputs, mask, _ = make_batch(sp, 6, seed=700 + 10 * s + rank, lengths="ragged", weights="random")
+        losses.append(float(tr.train_step(tr.make_batch(inputs, mask))))
+    tr.opt.flush_tables()
+    torch.cuda.synchronize()
+    q.put((rank, losses, tr.store.state_dict()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_steps_match_oracle(cuda):
+    world, steps = 2, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    # every rank holds the identical replica
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+    # oracle: gradient = mean over towers of the per-tower gradients (run_dnn.py:45-80), one Adam step per global step
+    so, sp = small_specs()
+    P = {k: v.copy() for k, v in O.init_params(so, seed=5).items()}
+    adam = O.TFAdam(lr=1e-3)
+    ref_losses = []
+    for s in range(steps):
+        Gs, Ls = [], []
+        for r in range(world):
+            inputs, mask, _ = make_batch(sp, 6, seed=700 + 10 * s + r, lengths="ragged", weights="random")
+            l, _lg, G = OT.loss_and_grads(P, inputs, mask, so)
+            Gs.append(G); Ls.append(l)
+        adam.apply(P, {k: (Gs[0][k] + Gs[1][k]) / world for k in Gs[0]})
+        ref_losses.append(np.mean(Ls))
+    assert np.abs(np.array(res[0][1]) - np.array(ref_losses)).max() < 1e-4
+    got = res[0][2]
+    total = sum(P[k].size for k in P)
+    n_off = sum(int((np.abs(got[k] - P[k]) > 2e-5).sum()) for k in P)
+    worst = max(float(np.abs(got[k] - P[k]).max()) for k in P)
+    assert n_off <= 1e-4 * total and worst < 5e-4, (n_off, total, worst)
