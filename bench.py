@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--law", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -63,7 +64,7 @@ def main():
 
     sp = S.e64_spec() if args.dims == "e64" else S.default_spec()
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234)
+    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout)
     nb = 4
     batches = []
     for i in range(nb):
@@ -123,8 +124,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=50/50/10 full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows)"
-                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, args.law),
+                               "per-GPU batch %d, L=50/50/10 full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, args.law, "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "roofline": roofline, "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }

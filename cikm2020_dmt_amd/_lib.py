@@ -52,7 +52,8 @@ class AttnDesc(C.Structure):
     _fields_ = [("dtype", c_i32), ("B", c_i32), ("H", c_i32), ("dh", c_i32), ("Tq", c_i32), ("Tk", c_i32),
                 ("Q", c_vp), ("q_bs", c_i64), ("q_rs", c_i64), ("K", c_vp), ("k_bs", c_i64), ("k_rs", c_i64),
                 ("V", c_vp), ("v_bs", c_i64), ("v_rs", c_i64), ("q_lens", c_vp), ("k_lens", c_vp),
-                ("resid", c_vp), ("r_bs", c_i64), ("r_rs", c_i64), ("out", c_vp), ("o_bs", c_i64), ("o_rs", c_i64)]
+                ("resid", c_vp), ("r_bs", c_i64), ("r_rs", c_i64), ("out", c_vp), ("o_bs", c_i64), ("o_rs", c_i64),
+                ("drop_seed", C.c_uint32), ("drop_keep", c_f32)]
 
 
 class AttnBwdDesc(C.Structure):
@@ -81,6 +82,7 @@ _SIGS = {
     "dmt_mmoe_mix_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
     "dmt_mmoe_mix_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp],
     "dmt_scale_add_pos": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp],
+    "dmt_dropout": [c_i32, c_i64, c_vp, c_vp, C.c_uint32, c_f32, c_vp],
     "dmt_relu_bwd": [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_loss_unbias": [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp,
                         c_vp, c_vp, c_vp, c_vp],

@@ -24,7 +24,17 @@ struct AttnArgs {
   void* dK; long long dk_bs, dk_rs;
   void* dV; long long dv_bs, dv_rs;
   int lds_per_wave;    // floats
+  // dropout on the attention weights (after the query mask): D = keep(idx) / keep_prob, idx = ((b*H+h)*Tq+q)*Tk+k
+  unsigned drop_seed, drop_thr;
+  float drop_inv;
+  int drop_on;
 };
+
+__device__ __forceinline__ float drop_factor(const AttnArgs& a, int b, int h, int q, int key) {
+  if (!a.drop_on) return 1.f;
+  const unsigned idx = (unsigned)((((long long)b * a.H + h) * a.Tq + q) * a.Tk + key);
+  return dmt_drop_keep(a.drop_seed, idx, a.drop_thr) ? a.drop_inv : 0.f;
+}
 
 template <typename T, int DHT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
@@ -74,6 +84,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     const float sum = wave_sum(e);
     float p = e / sum;
     if (q >= qlen) p = PADDING_NUM;            // query mask applied AFTER the softmax (reference behaviour, F13)
+    p *= drop_factor(a, b, h, q, lane);
     if (lane < Tk) pbuf[lane] = p;
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < dh; j += 64) {
@@ -144,12 +155,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
     const float sum = wave_sum(e);
     float p = e / sum;
     float ds = 0.f;
+    const float Dk = drop_factor(a, b, h, q, lane);
+    dP *= Dk;                                            // gradient w.r.t. the pre-dropout weights
     if (q < qlen) {
       const float dot = wave_sum(lane < Tk ? p * dP : 0.f);
       ds = (lane < klen) ? p * (dP - dot) / sc : 0.f;   // tf.where(key_mask, x, pad): no gradient into masked keys
     } else {
       p = PADDING_NUM;                                   // constant rows: gradient reaches V only
     }
+    p *= Dk;                                             // dropped weights feed dV
     if (lane < Tk) {
 #pragma unroll
       for (int j = 0; j < DH; ++j) {
@@ -343,11 +357,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
       for (int i = 0; i < 8; i += 2) {
         const int r0 = 8 * (u & 1) + i;
         float p0 = acc[u >> 1][qt][r0] / sum, p1 = acc[u >> 1][qt][r0 + 1] / sum;
+        const int k0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
         if (qpad) {      // query mask applied AFTER the softmax (reference behaviour)
-          const int k0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
           p0 = (k0 < Tk) ? PADDING_NUM : 0.f;
           p1 = (k0 + 1 < Tk) ? PADDING_NUM : 0.f;
         }
+        if (a.drop_on) { p0 *= drop_factor(a, b, h, q, k0); p1 *= drop_factor(a, b, h, q, k0 + 1); }
         f.w[i >> 1] = pack_bf16(p0, p1);
       }
       pB[qt][u] = f.v;
@@ -543,6 +558,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) {
         const float pv = acc[kt][qt][r] / sum;
         acc[kt][qt][r] = pv;
+        if (a.drop_on) dp[kt][qt][r] *= drop_factor(a, b, h, q, kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
         dot += pv * dp[kt][qt][r];
       }
     dot += __shfl_xor(dot, 32, 64);
@@ -555,6 +571,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
         float pv = acc[kt][qt][r];
         float ds = (key < klen) ? pv * (dp[kt][qt][r] - dot) / sc : 0.f;   // no gradient into masked keys
         if (qpad) { ds = 0.f; pv = (key < Tk) ? PADDING_NUM : 0.f; }       // constant rows: gradient reaches V only
+        if (a.drop_on) pv *= drop_factor(a, b, h, q, key);                 // dropped weights feed dV
         dp[kt][qt][r] = ds;
         acc[kt][qt][r] = pv;
       }
@@ -709,8 +726,10 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(const AttnArgs a) {
   const float sum = wave_sum(e);
   float p = e / sum;
   const bool qpad = (0 >= qlen);
+  const float Dk = drop_factor(a, b, h, 0, lane);
   if constexpr (!BWD) {
     if (qpad) p = PADDING_NUM;
+    p *= Dk;
     if (lane < Tk) s_buf[wave][lane] = p;
     __builtin_amdgcn_wave_barrier();
     const T* Rg = a.resid ? reinterpret_cast<const T*>(a.resid) + (long long)b * a.r_bs + h * DH : nullptr;
@@ -724,12 +743,14 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(const AttnArgs a) {
     }
   } else {
     float ds = 0.f;
+    dP *= Dk;
     if (!qpad) {
       const float dot = wave_sum(lane < Tk ? p * dP : 0.f);
       ds = (lane < klen) ? p * (dP - dot) / sc : 0.f;
     } else {
       p = PADDING_NUM;
     }
+    p *= Dk;
     if (lane < Tk) {
       s_buf[wave][lane] = ds;
       T* dKr = reinterpret_cast<T*>(a.dK) + (long long)b * a.dk_bs + (long long)lane * a.dk_rs + h * DH;
@@ -784,6 +805,10 @@ int fill_args(AttnArgs& a, const dmt_attn_desc* d) {
   a.q_lens = d->q_lens; a.k_lens = d->k_lens;
   a.resid = d->resid; a.r_bs = d->r_bs; a.r_rs = d->r_rs;
   a.out = d->out; a.o_bs = d->o_bs; a.o_rs = d->o_rs;
+  a.drop_on = (d->drop_keep > 0.f && d->drop_keep < 1.f) ? 1 : 0;
+  a.drop_seed = d->drop_seed;
+  a.drop_thr = a.drop_on ? (unsigned)(d->drop_keep * 16777216.0f) : 0u;
+  a.drop_inv = a.drop_on ? 1.f / d->drop_keep : 1.f;
   a.dout = nullptr; a.dQ = a.dK = a.dV = nullptr;
   a.do_bs = a.do_rs = a.dq_bs = a.dq_rs = a.dk_bs = a.dk_rs = a.dv_bs = a.dv_rs = 0;
   return 0;

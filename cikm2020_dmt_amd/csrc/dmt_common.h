@@ -54,4 +54,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// counter-based dropout mask shared by every kernel (and restated in oracle/dmt_oracle.py:dropout_mask)
+__device__ __forceinline__ uint32_t dmt_mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool dmt_drop_keep(uint32_t seed, uint32_t idx, uint32_t thr24) { return (dmt_mix32(idx ^ seed) >> 8) < thr24; }
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -291,6 +291,14 @@ __global__ __launch_bounds__(256) void scale_add_pos_kernel(long long n, int Tle
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(long long n, const T* __restrict__ x, T* __restrict__ y, uint32_t seed, uint32_t thr24,
+                                                      float inv_keep) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  stf<T>(y + i, dmt_drop_keep(seed, (uint32_t)i, thr24) ? ldf<T>(x + i) * inv_keep : 0.f);
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(long long rows, long long cols, const T* __restrict__ dy, long long lddy,
                                                        const T* __restrict__ y, long long ldy, T* __restrict__ dz, long long lddz) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -484,6 +492,19 @@ extern "C" int dmt_scale_add_pos(int32_t dtype, int64_t B, int32_t T, int32_t d,
   else
     hipLaunchKernelGGL((scale_add_pos_kernel<bf16_t>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, n, T, d, (const bf16_t*)x, scale, pos, (bf16_t*)y);
   DMT_CHECK_LAUNCH("dmt_scale_add_pos");
+  return DMT_OK;
+}
+
+extern "C" int dmt_dropout(int32_t dtype, int64_t n, const void* x, void* y, uint32_t seed, float keep_prob, void* stream) {
+  DMT_CHECK_ARG(n > 0 && n < 0xFFFFFFFFll && x && y, "dmt_dropout: bad argument (n must fit 32 bits)");
+  DMT_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "dmt_dropout: keep_prob must be in (0, 1]");
+  const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((dropout_kernel<float>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (long long)n, (const float*)x, (float*)y, seed, thr, 1.f / keep_prob);
+  else
+    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (long long)n, (const bf16_t*)x, (bf16_t*)y, seed, thr, 1.f / keep_prob);
+  DMT_CHECK_LAUNCH("dmt_dropout");
   return DMT_OK;
 }
 

@@ -210,6 +210,7 @@ class DMTEngine:
         self.w_ctr = torch.tensor(spec["weight_ctr"], dtype=F32, device=dev)
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
+        self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
 
     def gather_bytes(self, batch, seq_T) -> float:
         """Algorithmic HBM bytes of one gather launch: int32 indices read once, fp32 table rows for
@@ -277,22 +278,28 @@ class DMTEngine:
         L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
         return X, tar
 
-    def mha_self(self, x, lens, blk):
+    def _attn_drop(self, stream):
+        rate = self.spec.get("dropout_rate", 0.0)
+        if self.dropout_step_seed is None or not rate:
+            return 0, 1.0
+        return ops.site_seed(self.dropout_step_seed, stream), 1.0 - rate
+
+    def mha_self(self, x, lens, blk, stream=2):
         """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "self-attention/"
         qkv = ops.linear(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"))
-        s1 = ops.AttnFn.apply(qkv, None, x, lens, lens, H, d, True)
+        s1 = ops.AttnFn.apply(qkv, None, x, lens, lens, H, d, True, *self._attn_drop(stream))
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
-    def mha_cross(self, q_in, mem, q_lens, k_lens, blk):
+    def mha_cross(self, q_in, mem, q_lens, k_lens, blk, stream=3):
         """multihead_attention(q, mem, mem, q_lens, k_lens) with scope 'vanilla_attention'."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "vanilla_attention/"
         wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
         q = ops.linear(q_in, wl[:, :d], bl[:d], self._wslice(w, 0, d))
         kv = ops.linear(mem, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d))
-        s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False)
+        s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False, *self._attn_drop(stream))
         return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
     def ff(self, x, ffs):
@@ -304,13 +311,15 @@ class DMTEngine:
     def encode_prepared(self, x, lens, i):
         """TransformerModel.encode after the input prep (x = sqrt(d)*seq_emb + P, fused into the gather)."""
         blk = trans_prefix(i) + "num_blocks_0/"
-        x = self.mha_self(x, lens, blk)
+        x = ops.dropout(x, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 0)     # TransformerModel.py:101
+        x = self.mha_self(x, lens, blk, 10 * i + 2)
         return self.ff(x, blk + "positionwise_feedforward/")
 
     def decode_prepared(self, y, mem, lens, i):
         """TransformerModel.decode after the input prep (y = sqrt(d)*tar[:,None,:])."""
         blk = trans_prefix(i) + "num_blocks_0/"
-        y = self.mha_cross(y, mem, None, lens, blk)
+        y = ops.dropout(y, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 1)     # TransformerModel.py:151
+        y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3)
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(y, blk + ffs)
 
@@ -362,6 +371,7 @@ class DMTEngine:
         for li in range(n):
             nm = "layer_bias%d/" % li
             h = ops.linear(h, self._lf(nm + "kernel"), self._lf(nm + "bias"), self._w(nm + "kernel"), relu=True)
+            h = ops.dropout(h, sp.get("dropout_rate_bias", [0.0] * n)[li], self.dropout_step_seed, 100 + li)   # :274-278
         nm = "layer_bias%d/" % n
         return ops.linear(h, self._lf(nm + "kernel"), self._lf(nm + "bias"), self._w(nm + "kernel"), out_dtype=F32)
 

@@ -276,12 +276,49 @@ def _chk3(t, name):
         raise ValueError("%s must be [B,T,*] with unit inner stride" % name)
 
 
+def mix32(h: int) -> int:
+    h &= 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def site_seed(step_seed: int, stream: int) -> int:
+    """Seed of one dropout site at one step (streams: 10*i+0 encoder input, +1 decoder input, +2 self-attention weights,
+    +3 cross-attention weights of sequence i; 100+l bias-tower layer l)."""
+    return mix32((step_seed * 0x9E3779B1 + stream * 0x85EBCA6B + 1) & 0xFFFFFFFF)
+
+
+class DropoutFn(torch.autograd.Function):
+    """tf.layers.dropout: y = x * keep(i) / keep_prob with libdmt_hip's counter-based mask; its own gradient."""
+
+    @staticmethod
+    def forward(ctx, x, seed32, keep_prob):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.call("dmt_dropout", dt_code(x.dtype), x.numel(), p(x), p(y), int(seed32), float(keep_prob), stream_ptr())
+        ctx.args = (int(seed32), float(keep_prob))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("dmt_dropout", dt_code(dy.dtype), dy.numel(), p(dy), p(dx), ctx.args[0], ctx.args[1], stream_ptr())
+        return dx, None, None
+
+
+def dropout(x, rate, step_seed, stream):
+    if step_seed is None or not rate:
+        return x
+    return DropoutFn.apply(x, site_seed(step_seed, stream), 1.0 - rate)
+
+
 class AttnFn(torch.autograd.Function):
     """out = concat_h softmax(mask(QK^T/sqrt(dh))) V + resid.  q,k,v may be column slices of packed projections;
     their gradients are written straight into one packed buffer per distinct base tensor (`pack`)."""
 
     @staticmethod
-    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn):
+    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn, drop_seed=0, drop_keep=1.0):
         # self_attn: packed_q is [B,T,3d] = (Q|K|V), packed_kv is None.
         # cross:     packed_q is [B,Tq,d] = Q, packed_kv is [B,Tk,2d] = (K|V).
         if self_attn:
@@ -293,9 +330,11 @@ class AttnFn(torch.autograd.Function):
         B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
         out = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
         desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
+        desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
         L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
         ctx.save_for_backward(packed_q, packed_kv, q_lens, k_lens)
         ctx.H, ctx.d, ctx.self_attn = H, d, self_attn
+        ctx.drop = (int(drop_seed), float(drop_keep))
         ctx.has_resid = resid is not None
         return out
 
@@ -318,12 +357,13 @@ class AttnFn(torch.autograd.Function):
         B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
         bd = L.AttnBwdDesc()
         bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
+        bd.f.drop_seed, bd.f.drop_keep = ctx.drop
         bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
         bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
         bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
         bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
         L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
-        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None
+        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

@@ -21,13 +21,16 @@ from .variables import VariableStore
 
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
-                 step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20):
+                 step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = False, dropout_seed: int = 1):
         self.spec = spec
         self.device = torch.device(device)
         self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init)
         self.engine = DMTEngine(spec, self.store)
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
+        # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in
+        # train().  Off by default here because parity runs need it off; bench.py turns it on.
+        self.dropout, self.dropout_seed = dropout, dropout_seed
 
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
@@ -42,9 +45,12 @@ class Trainer:
     def forward_backward(self, batch: DeviceBatch):
         self.sync_rows(batch)
         self.store.zero_grad()
+        rank, _W = parallel.world()
+        self.engine.dropout_step_seed = (self.dropout_seed + self.opt.global_step + 7919 * rank) if self.dropout else None
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
         loss.backward()
+        self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
         return loss.detach()
 

@@ -188,6 +188,9 @@ typedef struct {
   const int32_t* k_lens;       /* [B] */
   const void* resid; int64_t r_bs, r_rs;   /* or NULL */
   void* out; int64_t o_bs, o_rs;
+  uint32_t drop_seed;          /* dropout on the attention weights (TransformerModel_util.py:51), applied after the query mask: */
+  float drop_keep;             /* keep probability; >= 1 (or 0) disables.  mask(i) = dmt_dropout_keep(drop_seed, i, keep),      */
+                               /* i = ((b*H + h)*Tq + q)*Tk + k                                                                  */
 } dmt_attn_desc;
 
 int dmt_attn_fwd(const dmt_attn_desc* d, void* stream);
@@ -234,6 +237,11 @@ int dmt_mmoe_mix_bwd(int32_t dtype, int32_t B, int32_t E, int32_t U, int32_t n_t
  * (model/net/TransformerModel.py:96-100,146-147) when the sequence embedding was gathered unscaled. pos may be NULL. */
 int dmt_scale_add_pos(int32_t dtype, int64_t B, int32_t T, int32_t d, const void* x, float scale, const float* pos, void* y,
                       void* stream);
+
+/* tf.layers.dropout (TransformerModel.py:101,151; mmoe_transformer_unbias.py:274-278): y[i] = x[i] * keep(i) / keep_prob with the
+ * counter-based mask  keep(i) = (mix32(i ^ seed) >> 8) < keep_prob * 2^24,  mix32 = murmur3 finaliser.  The same call is its own
+ * gradient (dx = dropout(dy)).  Deterministic in (seed, i): the oracle reproduces the mask (oracle/dmt_oracle.py:dropout_mask). */
+int dmt_dropout(int32_t dtype, int64_t n, const void* x, void* y, uint32_t seed, float keep_prob, void* stream);
 
 /* Gradient of relu given its OUTPUT y: dz = dy * (y > 0)  (tf.nn.relu at base.py:64, TransformerModel_util.py:224). */
 int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const void* dy, int64_t lddy, const void* y, int64_t ldy,

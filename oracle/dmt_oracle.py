@@ -205,6 +205,36 @@ def init_params(spec, seed=0, dtype=np.float64) -> Dict[str, np.ndarray]:
     return out
 
 
+# --------------------------------------------------------------------------------------------- dropout
+def _mix32(h):
+    h = np.asarray(h, dtype=np.uint64) & 0xFFFFFFFF
+    h ^= h >> 16; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13; h = (h * 0xC2B2AE35) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def site_seed(step_seed: int, stream: int) -> int:
+    """32-bit seed of one dropout site (stream) at one step; streams: 10*i+0 encoder input, 10*i+1 decoder input,
+    10*i+2 self-attention weights, 10*i+3 cross-attention weights of sequence i; 100+l bias-tower layer l."""
+    return int(_mix32((step_seed * 0x9E3779B1 + stream * 0x85EBCA6B + 1) & 0xFFFFFFFF))
+
+
+def dropout_mask(seed32: int, n: int, keep_prob: float) -> np.ndarray:
+    """keep(i) = (mix32(i ^ seed) >> 8) < keep_prob * 2**24 -- the counter-based mask of libdmt_hip (dmt_common.h).
+    The reference uses tf.layers.dropout's stateful RNG (TransformerModel.py:101,151; TransformerModel_util.py:51;
+    mmoe_transformer_unbias.py:274-278); only the DISTRIBUTION (Bernoulli(keep), scaled by 1/keep) is reference behaviour."""
+    idx = np.arange(n, dtype=np.uint64)
+    thr = np.uint64(int(np.float32(keep_prob) * np.float32(16777216.0)))
+    return (_mix32(idx ^ np.uint64(seed32)) >> 8) < thr
+
+
+def dropout(x, rate, step_seed, stream):
+    if step_seed is None or not rate:
+        return x
+    keep = 1.0 - rate
+    m = dropout_mask(site_seed(step_seed, stream), x.size, keep).reshape(x.shape)
+    return np.where(m, x / keep, 0.0)
+
+
 # --------------------------------------------------------------------------------------------- ops
 def ln(x, gamma, beta, epsilon=1e-8):
     """TransformerModel_util.py:58-78: biased variance over the last dim, eps INSIDE the sqrt."""
@@ -224,8 +254,8 @@ def sequence_mask(lengths, maxlen):
     return (np.arange(maxlen)[None, :] < np.asarray(lengths)[:, None])
 
 
-def scaled_dot_product_attention(Q, K, V, query_masks, key_masks):
-    """TransformerModel_util.py:11-56 with dropout off and causality False.
+def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, dropout_rate=0.0, step_seed=None, stream=0):
+    """TransformerModel_util.py:11-56 with causality False (dropout only when step_seed is given).
     Q [hN,Tq,dk]  K,V [hN,Tk,dk]  masks [N,T*] bool."""
     d_k = Q.shape[-1]
     outputs = np.matmul(Q, np.transpose(K, (0, 2, 1)))
@@ -236,10 +266,18 @@ def scaled_dot_product_attention(Q, K, V, query_masks, key_masks):
     outputs = softmax(outputs)
     qm = np.tile(query_masks, (h, 1))[:, :, None]                     # mask(type='query'), :91-97 (AFTER softmax)
     outputs = np.where(np.broadcast_to(qm, outputs.shape), outputs, PADDING_NUM)
+    if step_seed is not None and dropout_rate:
+        N = key_masks.shape[0]
+        Tq, Tk = outputs.shape[1], outputs.shape[2]
+        keep = 1.0 - dropout_rate
+        m = dropout_mask(site_seed(step_seed, stream), N * h * Tq * Tk, keep).reshape(N, h, Tq, Tk)   # idx = ((b*H+h)*Tq+q)*Tk+k
+        m = np.transpose(m, (1, 0, 2, 3)).reshape(h * N, Tq, Tk)                                      # head-major packing
+        outputs = np.where(m, outputs / keep, 0.0)
     return np.matmul(outputs, V)
 
 
-def multihead_attention(queries, keys, values, queries_length, keys_length, num_heads, P, scope):
+def multihead_attention(queries, keys, values, queries_length, keys_length, num_heads, P, scope, dropout_rate=0.0,
+                        step_seed=None, stream=0):
     """TransformerModel_util.py:160-209.  NOTE: no output projection."""
     query_masks = sequence_mask(queries_length, queries.shape[1])
     key_masks = sequence_mask(keys_length, keys.shape[1])
@@ -249,7 +287,7 @@ def multihead_attention(queries, keys, values, queries_length, keys_length, num_
     Q_ = np.concatenate(np.split(Q, num_heads, axis=2), axis=0)
     K_ = np.concatenate(np.split(K, num_heads, axis=2), axis=0)
     V_ = np.concatenate(np.split(V, num_heads, axis=2), axis=0)
-    out = scaled_dot_product_attention(Q_, K_, V_, query_masks, key_masks)
+    out = scaled_dot_product_attention(Q_, K_, V_, query_masks, key_masks, dropout_rate, step_seed, stream)
     out = np.concatenate(np.split(out, num_heads, axis=0), axis=2)
     out = out + queries
     return ln(out, P[scope + "ln/gamma"], P[scope + "ln/beta"])
@@ -263,26 +301,31 @@ def ff(inputs, P, scope):
     return ln(o, P[scope + "ln/gamma"], P[scope + "ln/beta"])
 
 
-def encode(seq_emb, seqlens, P, prefix, spec):
-    """TransformerModel.py:84-123 with position_learn (dmt.conf:50), dropout off."""
+def encode(seq_emb, seqlens, P, prefix, spec, step_seed=None, seq_index=0):
+    """TransformerModel.py:84-123 with position_learn (dmt.conf:50); dropout (rate spec['dropout_rate']) when step_seed given."""
     T = seq_emb.shape[1]
+    rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
     enc = seq_emb * (spec["d_model"] ** 0.5)
     pos = P[prefix + "positional_encoding_k_position_learn/embedding_position_learn"]
     enc = enc + pos[np.arange(T)][None, :, :]                          # positional_encoding_learn, util:281-316
+    enc = dropout(enc, rate, step_seed, 10 * seq_index + 0)            # TransformerModel.py:101
     for i in range(spec["num_blocks_encode"]):
         blk = prefix + "num_blocks_%d/" % i
-        enc = multihead_attention(enc, enc, enc, seqlens, seqlens, spec["num_heads"], P, blk + "self-attention/")
+        enc = multihead_attention(enc, enc, enc, seqlens, seqlens, spec["num_heads"], P, blk + "self-attention/", rate, step_seed,
+                                  10 * seq_index + 2)
         enc = ff(enc, P, blk + "positionwise_feedforward/")
     return enc
 
 
-def decode(query_emb, query_length, key_emb, key_length, P, prefix, spec):
+def decode(query_emb, query_length, key_emb, key_length, P, prefix, spec, step_seed=None, seq_index=0):
     """TransformerModel.py:125-171 (is_decoder_add_pos_emb=false)."""
+    rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
     dec = query_emb * (spec["d_model"] ** 0.5)
+    dec = dropout(dec, rate, step_seed, 10 * seq_index + 1)            # TransformerModel.py:151
     for i in range(spec["num_blocks_decode"]):
         blk = prefix + "num_blocks_%d/" % i
         dec = multihead_attention(dec, key_emb, key_emb, query_length, key_length, spec["num_heads"], P,
-                                  blk + "vanilla_attention/")
+                                  blk + "vanilla_attention/", rate, step_seed, 10 * seq_index + 3)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         dec = ff(dec, P, blk + ffs)                                    # same scope => tied weights (SURVEY F11)
     return dec
@@ -326,15 +369,15 @@ def generate_data(inputs, P, spec):
     return seq_data
 
 
-def trans_core(seq_data, P, spec):
+def trans_core(seq_data, P, spec, step_seed=None):
     """mmoe_transformer_unbias.py:189-223 (is_trans_out_concat_item=false)."""
     states = []
     for i, (mask, lens, seq_emb, tar, _ts) in enumerate(seq_data):
         prefix = trans_prefix(i)
         seq_q = tar[:, None, :]
         q_lens = np.ones(seq_q.shape[0], dtype=np.int64)
-        memory = encode(seq_emb, lens, P, prefix, spec)
-        dec = decode(seq_q, q_lens, memory, lens, P, prefix, spec)
+        memory = encode(seq_emb, lens, P, prefix, spec, step_seed, i)
+        dec = decode(seq_q, q_lens, memory, lens, P, prefix, spec, step_seed, i)
         states.append(dec[:, 0, :])
     return np.concatenate(states, -1)
 
@@ -366,10 +409,10 @@ def embedding_combiner(inputs, P, spec, emb_list=None, prefix="embedding_trans/"
     return np.concatenate([f.astype(dt) for f in feats], axis=1)
 
 
-def embedding_trans(inputs, P, spec):
+def embedding_trans(inputs, P, spec, step_seed=None):
     """mmoe_transformer_unbias.py:226-233."""
     seq_data = generate_data(inputs, P, spec)
-    interest = trans_core(seq_data, P, spec)
+    interest = trans_core(seq_data, P, spec, step_seed)
     features = embedding_combiner(inputs, P, spec)
     return np.concatenate([features, interest], -1)
 
@@ -412,23 +455,24 @@ def build_tower(x, P, spec, name):
     return dense_layer(y, P[s + "weights"], P[s + "biases"], "identity")
 
 
-def embedding_mlp_bias(inputs, P, spec):
-    """mmoe_transformer_unbias.py:259-289, dropout off."""
+def embedding_mlp_bias(inputs, P, spec, step_seed=None):
+    """mmoe_transformer_unbias.py:259-289 (dropout after each hidden layer when step_seed is given)."""
     y = embedding_combiner(inputs, P, spec, emb_list=spec["embedding_list_bias"], prefix="", with_dense=False)
     n = len(spec["hidden_units_bias"])
     for li in range(n):
         y = np.maximum(y @ P["layer_bias%d/kernel" % li] + P["layer_bias%d/bias" % li], 0.0)
+        y = dropout(y, spec.get("dropout_rate_bias", [0.0] * n)[li] if step_seed is not None else 0.0, step_seed, 100 + li)
     return y @ P["layer_bias%d/kernel" % n] + P["layer_bias%d/bias" % n]
 
 
-def inference(inputs, P, spec, is_predict=False):
-    """mmoe_transformer_unbias.py:293-316 -> ((click_logit, order_logit), y_bias)."""
-    features = embedding_trans(inputs, P, spec)
+def inference(inputs, P, spec, is_predict=False, step_seed=None):
+    """mmoe_transformer_unbias.py:293-316 -> ((click_logit, order_logit), y_bias).  step_seed != None == is_train with dropout."""
+    features = embedding_trans(inputs, P, spec, step_seed)
     mmoe_layers, _g = expert_gate(features, P, spec)
     logits = tuple(build_tower(m, P, spec, nm) for m, nm in zip(mmoe_layers, ("click", "order")))
     if is_predict:
         return logits
-    return logits, embedding_mlp_bias(inputs, P, spec)
+    return logits, embedding_mlp_bias(inputs, P, spec, step_seed)
 
 
 # --------------------------------------------------------------------------------------------- loss

@@ -31,6 +31,16 @@ def _padded(sp, dtype=torch.long):
     return dense, valid
 
 
+def _drop(x, rate, step_seed, stream, mask_shape=None, perm=None):
+    """x * mask / keep with the numpy oracle's counter-based mask (oracle/dmt_oracle.py:dropout_mask)."""
+    if step_seed is None or not rate:
+        return x
+    from oracle.dmt_oracle import dropout_mask, site_seed
+    keep = 1.0 - rate
+    m = dropout_mask(site_seed(step_seed, stream), x.numel(), keep).reshape(tuple(x.shape))
+    return torch.where(torch.as_tensor(m), x / keep, torch.zeros_like(x))
+
+
 def _trans_prefix(i):
     return "embedding_trans/trans_sequence_%d/encode_decode_sequence_%d/encode_decode_sequence_%d/" % (i, i, i)
 
@@ -41,8 +51,8 @@ def _ln(x, g, b, eps=1e-8):
     return g * (x - mu) * torch.rsqrt(var + eps) + b          # TransformerModel_util.py:72-76
 
 
-def _mha(q_in, kv_in, q_len, k_len, H, P, s):
-    """TransformerModel_util.py:160-209 / :11-56 (dropout off).  [B,Tq,d],[B,Tk,d] -> [B,Tq,d]."""
+def _mha(q_in, kv_in, q_len, k_len, H, P, s, rate=0.0, step_seed=None, stream=0):
+    """TransformerModel_util.py:160-209 / :11-56.  [B,Tq,d],[B,Tk,d] -> [B,Tq,d]."""
     B, Tq, d = q_in.shape
     Tk = kv_in.shape[1]
     dh = d // H
@@ -55,6 +65,7 @@ def _mha(q_in, kv_in, q_len, k_len, H, P, s):
     A = torch.softmax(S, dim=-1)
     qmask = (torch.arange(Tq)[None, :] < q_len[:, None])[:, None, :, None]
     A = torch.where(qmask, A, torch.full_like(A, PADDING_NUM))                     # post-softmax query mask (F13)
+    A = _drop(A, rate, step_seed, stream)                                          # [B,H,Tq,Tk] order == kernel index order
     O = (A @ V).transpose(1, 2).reshape(B, Tq, d)
     return _ln(O + q_in, P[s + "ln/gamma"], P[s + "ln/beta"])
 
@@ -76,7 +87,7 @@ def _pool_mean(E, idx, valid, w):
     return rows.sum(1) / torch.where(ws == 0, torch.ones_like(ws), ws)
 
 
-def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_intermediates=False):
+def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_intermediates=False, step_seed=None):
     """mmoe_transformer_unbias.py:293-316."""
     any_p = next(iter(P.values()))
     dt = any_p.dtype
@@ -101,12 +112,14 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         seq_emb = torch.cat(seq_parts, -1)
         tar = torch.cat(tar_parts, -1)
         T = seq_emb.shape[1]
+        rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
         x = seq_emb * (d ** 0.5) + P[pre + "positional_encoding_k_position_learn/embedding_position_learn"][:T][None]
+        x = _drop(x, rate, step_seed, 10 * i + 0)
         blk = pre + "num_blocks_0/"
-        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/")
+        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2)
         mem = _ff(x, P, blk + "positionwise_feedforward/")
-        y = (tar * (d ** 0.5))[:, None, :]
-        y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/")
+        y = _drop((tar * (d ** 0.5))[:, None, :], rate, step_seed, 10 * i + 1)
+        y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         y = _ff(y, P, blk + ffs)
         states.append(y[:, 0, :])
@@ -161,6 +174,7 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
     n = len(spec["hidden_units_bias"])
     for li in range(n):
         yb = torch.relu(yb @ P["layer_bias%d/kernel" % li] + P["layer_bias%d/bias" % li])
+        yb = _drop(yb, spec.get("dropout_rate_bias", [0.0] * n)[li] if step_seed is not None else 0.0, step_seed, 100 + li)
     yb = yb @ P["layer_bias%d/kernel" % n] + P["layer_bias%d/bias" % n]
     out = (logits, yb)
     return (out, inter) if return_intermediates else out
@@ -198,9 +212,9 @@ def to_torch(P_np: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=Tru
     return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in P_np.items()}
 
 
-def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64):
+def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64, step_seed=None):
     P = to_torch(P_np, dtype)
-    out = forward(P, inputs, spec)
+    out = forward(P, inputs, spec, step_seed=step_seed)
     loss = loss_unbias(out, mask, spec)
     loss.backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}

@@ -109,3 +109,18 @@ def test_tf_adam_restatement_first_steps():
     assert np.allclose(P["w"], [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-9)
     adam.apply(P, {"w": np.zeros(2)})      # zero gradient: parameters keep moving along the decaying first moment
     assert P["w"][0] < 1.0 - 1e-3 and P["w"][1] > -2.0 + 1e-3
+
+
+def test_dropout_restatement_agrees_and_is_unbiased():
+    so, sp = small_specs()
+    so = dict(so, dropout_rate=0.1, dropout_rate_bias=[0.5, 0.5])
+    P = O.init_params(so, seed=1)
+    inputs, mask, _ = make_batch(sp, 5, seed=3, lengths="ragged", weights="random")
+    (c, o), yb = O.inference(inputs, P, so, step_seed=77)
+    out = OT.forward(OT.to_torch(P), inputs, so, step_seed=77)
+    assert np.abs(c - out[0][0].detach().numpy()).max() < 1e-12 and np.abs(yb - out[1].detach().numpy()).max() < 1e-12
+    (c0, _), yb0 = O.inference(inputs, P, so)
+    assert np.abs(c - c0).max() > 1e-3 and np.abs(yb - yb0).max() > 1e-3
+    m = O.dropout_mask(O.site_seed(5, 2), 200000, 0.9)
+    assert abs(m.mean() - 0.9) < 3e-3
+    assert O.site_seed(5, 2) != O.site_seed(5, 3) != O.site_seed(6, 2)
