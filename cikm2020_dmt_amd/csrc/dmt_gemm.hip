@@ -1,19 +1,25 @@
 // MFMA GEMM with fused epilogue (bias / relu / relu-gradient gate / residual), batched, split-K.
 //   bf16 operands: v_mfma_f32_32x32x16_bf16      fp32 operands: v_mfma_f32_32x32x2_f32 (exact fma chain)
 // Workgroup = 4 wavefronts (2x2), tile 128x128, each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 fp32 acc VGPRs).
-// Operands are staged global -> registers -> LDS as [row][k] (k contiguous, row stride BK + one 16-byte pad
-// so ds_read_b128 fragment reads are bank-conflict free; bf16: BK = 64 = one full 128-byte line per row); the next K tile's global loads are in flight
-// while the current one is multiplied.  Either operand may be k-contiguous (vector LDS writes) or
-// row-contiguous (transposed on the LDS write, lanes along k => conflict-free 2-byte writes), so the same
-// kernel serves Y = X W^T-shadow, dX = dY W and dW = X^T dY (reduction over the strided dim of both).
+// Operands are staged global -> registers -> LDS; the next K tile's global loads are in flight while the current one
+// is multiplied.  Either operand may be
+//   k-contiguous   (mode 0): LDS image [row][k], row stride BK + one 16-byte pad, fragments by ds_read_b128;
+//   row-contiguous (mode 1): bf16: LDS image [k][row] copied as it lies in memory (coalesced 256-byte rows, 16-byte LDS
+//                  writes, row stride 320 B so four k rows fall in four different bank quarters) and transposed for free
+//                  by ds_read_b64_tr_b16 when the fragment is read; fp32: transposed on the LDS write;
+//   strided        (mode 2): scalar loads,
+// so the same kernel serves Y = X W^T-shadow, dX = dY W and dW = X^T dY (reduction over the strided dim of both).
 #include "dmt_common.h"
+#include <type_traits>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int LDT = 160;   // bf16 row-contiguous LDS image: [BK][LDT] (128 rows + 32 pad: 320 B = 256 + 64)
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> { static constexpr int EPV = 8, BK = 64, LDK = 72, NV = 4; };   // 128 x 64 x 2 B / 16 B / 256 thr
@@ -88,9 +94,9 @@ __device__ __forceinline__ void load_tile(Vec16 (&reg)[Cfg<T>::NV], const T* __r
           if (k + i < k_end) vset<T>(x, i, one_val<T>());
       }
     } else if constexpr (MODE == 1) {
-      // bf16: thread owns a 4(k) x 8(rows) block (vector p = k offset p) so the LDS store can transpose it in registers
-      const int k = k0 + (sizeof(T) == 2 ? (tid % 16) * 4 + p : (v % BK));
-      const int r = row0 + (sizeof(T) == 2 ? (tid / 16) * EPV : (v / BK) * EPV);
+      // bf16: 16 consecutive threads cover one k row of the tile (128 rows = 256 B)
+      const int k = k0 + (sizeof(T) == 2 ? (v / 16) : (v % BK));
+      const int r = row0 + (sizeof(T) == 2 ? (v % 16) * EPV : (v / BK) * EPV);
       if (k < k_end) {
         const T* src = P + (long long)k * cs + r;
         if (r + EPV <= R_real) {
@@ -123,21 +129,10 @@ template <typename T, int MODE>
 __device__ __forceinline__ void store_tile(T* __restrict__ S, const Vec16 (&reg)[Cfg<T>::NV], int tid) {
   constexpr int EPV = Cfg<T>::EPV, BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
   if constexpr (MODE == 1 && sizeof(T) == 2) {
-    // reg[p].h[i] = elem(row r0+i, k q0+p): transpose the 4 x 8 block -> 8 rows x (4 consecutive k) = 8-byte LDS stores
-    const int q0 = (tid % 16) * 4, r0 = (tid / 16) * EPV;
-    const unsigned a0[4] = {reg[0].u.x, reg[0].u.y, reg[0].u.z, reg[0].u.w};
-    const unsigned a1[4] = {reg[1].u.x, reg[1].u.y, reg[1].u.z, reg[1].u.w};
-    const unsigned a2[4] = {reg[2].u.x, reg[2].u.y, reg[2].u.z, reg[2].u.w};
-    const unsigned a3[4] = {reg[3].u.x, reg[3].u.y, reg[3].u.z, reg[3].u.w};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      uint2 lo, hi;   // rows r0+2w (low halves) and r0+2w+1 (high halves)
-      lo.x = (a0[w] & 0xFFFFu) | (a1[w] << 16);
-      lo.y = (a2[w] & 0xFFFFu) | (a3[w] << 16);
-      hi.x = (a0[w] >> 16) | (a1[w] & 0xFFFF0000u);
-      hi.y = (a2[w] >> 16) | (a3[w] & 0xFFFF0000u);
-      *reinterpret_cast<uint2*>(S + (r0 + 2 * w) * LDK + q0) = lo;
-      *reinterpret_cast<uint2*>(S + (r0 + 2 * w + 1) * LDK + q0) = hi;
+    for (int p = 0; p < Cfg<T>::NV; ++p) {
+      const int v = tid + p * NT;
+      *reinterpret_cast<uint4*>(S + (v / 16) * LDT + (v % 16) * EPV) = reg[p].u;   // plain copy: [k][row]
     }
     return;
   }
@@ -188,7 +183,7 @@ struct FastLoad {
       for (int p = 0; p < Cfg<T>::NV; ++p) {
         const int v = tid + p * NT;
         if constexpr (sizeof(T) == 2)
-          voff[p] = (int)(((long long)((tid % 16) * 4 + p) * cs + (tid / 16) * EPV) * (long long)sizeof(T));
+          voff[p] = (int)(((long long)(v / 16) * cs + (v % 16) * EPV) * (long long)sizeof(T));
         else
           voff[p] = (int)(((long long)(v % BK) * cs + (v / BK) * EPV) * (long long)sizeof(T));
       }
@@ -216,7 +211,7 @@ __device__ __forceinline__ void patch_ones_row(Vec16 (&reg)[Cfg<T>::NV], int row
 #pragma unroll
   for (int p = 0; p < Cfg<T>::NV; ++p) {
     const int v = tid + p * NT;
-    const int r = row0 + (sizeof(T) == 2 ? (tid / 16) * EPV : (v / BK) * EPV);
+    const int r = row0 + (sizeof(T) == 2 ? (v % 16) * EPV : (v / BK) * EPV);
     if (ones_row >= r && ones_row < r + EPV) {
 #pragma unroll
       for (int i = 0; i < EPV; ++i)
@@ -233,16 +228,18 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 
 constexpr int EPI_LD = 68;                       // fp32 words per staged epilogue row (64 + 4 pad)
 constexpr int EPI_WAVE_WORDS = 32 * EPI_LD;      // one wave stages 32 rows x 64 cols at a time
-constexpr int SMEM_BYTES_OPER = 2 * BM * 72 * 2; // As + Bs (bf16: 128*72*2 B each; fp32: 128*20*4 B each)
+constexpr int OPER_BYTES = 64 * LDT * 2;          // one operand tile: bf16 [64][160] (mode 1) >= [128][72] (mode 0) >= fp32 [128][20]
+constexpr int SMEM_BYTES_OPER = 2 * OPER_BYTES;
 constexpr int SMEM_BYTES_EPI = 4 * EPI_WAVE_WORDS * 4;
 constexpr int SMEM_BYTES = SMEM_BYTES_OPER > SMEM_BYTES_EPI ? SMEM_BYTES_OPER : SMEM_BYTES_EPI;
 
 template <typename T, int AMODE, int BMODE>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   constexpr int BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
+  // one buffer per operand; the epilogue staging reuses the same memory once the K loop is done
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-  T* As = reinterpret_cast<T*>(smem);
-  T* Bs = As + BM * LDK;
+  T* As0 = reinterpret_cast<T*>(smem);
+  T* Bs0 = reinterpret_cast<T*>(smem + OPER_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -297,32 +294,30 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   FastLoad<T, (BMODE == 1 ? 1 : 0)> fb;
   fa.init(A, g.a_rs, g.a_cs, m0, M_real, g.K, tid);
   fb.init(Bp, g.b_cs, g.b_rs, n0, g.N, g.K, tid);
-  auto load_both = [&](int kq) {
-    const bool kfull = (kq + BK <= k_end);
-    if (a_fast && kfull) {
-      fa.load(ra, kq);
-      if (AMODE == 1 && ones_here) patch_ones_row<T>(ra, m0, ones_row, tid);
+  // fragment of a 32-row sub-tile starting at row rb, k offset kk: lane l holds row rb + (l & 31), k = kk + 8*(l>>5) .. +8
+  auto frag = [&](const T* S, auto mode, int rb, int kk) -> bf16x8_t {
+    if constexpr (decltype(mode)::value == 1) {
+      // each 16-lane group reads a [4 k][16 rows] block; lane i points at k row (i >> 2), rows 4*(i & 3)..+4 and receives
+      // the block's column i, i.e. 4 consecutive k of row i
+      const int i16 = lane & 15, grp = lane >> 4;
+      const T* p = S + (kk + 8 * (grp >> 1) + (i16 >> 2)) * LDT + rb + 16 * (grp & 1) + 4 * (i16 & 3);
+      typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * LDT));
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      return *reinterpret_cast<const bf16x8_t*>(&S[(rb + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
     }
-    else load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, kq, M_real, k_end, ones_row, tid);
-    if (b_fast && kfull) fb.load(rb, kq);
-    else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, kq, g.N, k_end, -1, tid);
   };
-  load_both(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    store_tile<T, AMODE>(As, ra, tid);
-    store_tile<T, BMODE>(Bs, rb, tid);
-    __syncthreads();
-    if (k0 + BK < k_end) load_both(k0 + BK);
+  auto compute = [&](const T* As, const T* Bs) {
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 16) {
         bf16x8_t af[2], bfv[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
+        for (int i = 0; i < 2; ++i) af[i] = frag(As, std::integral_constant<int, AMODE>{}, wm * 64 + i * 32, kk);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bfv[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wn * 64 + j * 32 + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
+        for (int j = 0; j < 2; ++j) bfv[j] = frag(Bs, std::integral_constant<int, BMODE>{}, wn * 64 + j * 32, kk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -344,6 +339,54 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfv[j], acc[i][j], 0, 0, 0);
       }
     }
+  };
+
+  // Software pipeline: the loads of tile k+1 are issued before tile k is multiplied and are only waited for (and, for the
+  // ones row, patched) when they are stored to LDS after the barrier that ends the multiply.  The all-fast case has its
+  // own loop with its last tile peeled: any merge of the load destinations with another path (the guarded loader, a
+  // conditional load) makes the compiler copy them right after issue, which waits for the loads before the MFMA block.
+  int k_done = k_begin;
+  if (a_fast && b_fast) {
+    const int k_fast_end = k_begin + ((k_end - k_begin) / BK) * BK;
+    if (k_fast_end > k_begin) {
+      const bool patch = (AMODE == 1) && ones_here;
+      fa.load(ra, k_begin);
+      fb.load(rb, k_begin);
+      if (patch) patch_ones_row<T>(ra, m0, ones_row, tid);
+      store_tile<T, AMODE>(As0, ra, tid);
+      store_tile<T, BMODE>(Bs0, rb, tid);
+      __syncthreads();
+      for (int k0 = k_begin; k0 + BK < k_fast_end; k0 += BK) {
+        fa.load(ra, k0 + BK);
+        fb.load(rb, k0 + BK);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA block (the scheduler would sink them)
+        compute(As0, Bs0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (patch) patch_ones_row<T>(ra, m0, ones_row, tid);
+        store_tile<T, AMODE>(As0, ra, tid);
+        store_tile<T, BMODE>(Bs0, rb, tid);
+        __syncthreads();
+      }
+      compute(As0, Bs0);
+      __syncthreads();
+      k_done = k_fast_end;
+    }
+  }
+  // guarded loop: K tail of the fast case, and every tile of the other cases
+  for (int k0 = k_done; k0 < k_end; k0 += BK) {
+    if (a_fast && k0 + BK <= k_end) {
+      fa.load(ra, k0);
+      if (AMODE == 1 && ones_here) patch_ones_row<T>(ra, m0, ones_row, tid);
+    } else {
+      load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, k0, M_real, k_end, ones_row, tid);
+    }
+    if (b_fast && k0 + BK <= k_end) fb.load(rb, k0);
+    else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, k0, g.N, k_end, -1, tid);
+    store_tile<T, AMODE>(As0, ra, tid);
+    store_tile<T, BMODE>(Bs0, rb, tid);
+    __syncthreads();
+    compute(As0, Bs0);
     __syncthreads();
   }
 
