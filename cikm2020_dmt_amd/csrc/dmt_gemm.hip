@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int PERSIST_GRID = 256 * 3;   // 3 resident workgroups per CU (a multiple of the 8 XCDs)
 constexpr int LDT = 160;   // bf16 row-contiguous LDS image: [BK][LDT] (128 rows + 32 pad: 320 B = 256 + 64)
 
 template <typename T> struct Cfg;
@@ -43,7 +44,8 @@ struct GemmArgs {
   int out_f32;
   int vec_epi;
   int fast_ok;   // operand extents fit the 32-bit buffer offsets
-  int gx, gy, gz, inner, panels;   // XCD-aware block remap (see gemm_kernel)
+  int gx, gy, gz, inner, panels;   // XCD-aware block remap (see decode_tile)
+  int total_blocks;                // work ids (the grid is persistent: min(total_blocks, 3 workgroups per CU))
 };
 
 union Vec16 {
@@ -233,8 +235,42 @@ constexpr int SMEM_BYTES_OPER = 2 * OPER_BYTES;
 constexpr int SMEM_BYTES_EPI = 4 * EPI_WAVE_WORDS * 4;
 constexpr int SMEM_BYTES = SMEM_BYTES_OPER > SMEM_BYTES_EPI ? SMEM_BYTES_OPER : SMEM_BYTES_EPI;
 
+struct TileCoord {
+  int m0, n0, bt, ks, k_begin, k_end;
+  bool valid;
+};
+
+// XCD-aware mapping of the linear work id L to an output tile.  The dispatcher places workgroup b on XCD (b % 8) and the
+// persistent loop keeps L % 8 == b % 8; each XCD has a private L2.  All tiles that share an operand panel get ids with the
+// same (L % 8) and consecutive (L / 8), so they run concurrently on ONE XCD and the panel is fetched into that L2 once:
+//   no split-K : panel = (M tile, batch), swept over its N tiles          (A panel shared)
+//   split-K    : panel = K chunk, swept over its (N tile, M tile) pairs   (both operand chunks shared)
+// A wrong placement guess costs speed only, never correctness.
+__device__ __forceinline__ TileCoord decode_tile(const GemmArgs& g, int L) {
+  TileCoord t;
+  t.valid = false;
+  const int xcd = L & 7, jq = L >> 3;
+  const int pi = jq / g.inner, in = jq - pi * g.inner;
+  const int P = pi * 8 + xcd;
+  t.m0 = t.n0 = t.bt = t.ks = t.k_begin = t.k_end = 0;
+  if (P >= g.panels) return t;
+  int bx, by, bz;
+  if (g.split_k > 1) { bz = P; bx = in % g.gx; by = in / g.gx; }
+  else { by = P % g.gy; bz = P / g.gy; bx = in; }
+  t.bt = bz / g.split_k;
+  t.ks = bz - t.bt * g.split_k;
+  t.m0 = by * BM;
+  t.n0 = bx * BN;
+  t.k_begin = t.ks * g.k_per_split;
+  t.k_end = (t.k_begin + g.k_per_split < g.K) ? (t.k_begin + g.k_per_split) : g.K;
+  t.valid = (t.k_begin < t.k_end);
+  return t;
+}
+
+// Persistent kernel: a workgroup walks the work ids b, b + gridDim.x, ...; the first operand tiles of the NEXT output tile
+// are requested before the current tile's epilogue, so their latency hides behind the C stores.
 template <typename T, int AMODE, int BMODE>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_kernel(const GemmArgs g) {
   constexpr int BK = Cfg<T>::BK, LDK = Cfg<T>::LDK;
   // one buffer per operand; the epilogue staging reuses the same memory once the K loop is done
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -245,68 +281,27 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware remap of the 1-D grid.  The dispatcher places workgroup L on XCD (L % 8); each XCD has a private L2.
-  // All tiles that share an operand panel are given ids with the same (L % 8) and consecutive (L / 8), so they run
-  // concurrently on ONE XCD and the panel is fetched into that L2 once:
-  //   no split-K : panel = (M tile, batch), swept over its N tiles          (A panel shared)
-  //   split-K    : panel = K chunk, swept over its (N tile, M tile) pairs   (both operand chunks shared)
-  // A wrong placement guess costs speed only, never correctness.
-  const int L = blockIdx.x;
-  const int xcd = L & 7, jq = L >> 3;
-  const int pi = jq / g.inner, in = jq - pi * g.inner;
-  const int P = pi * 8 + xcd;
-  if (P >= g.panels) return;
-  int bx, by, bz;
-  if (g.split_k > 1) { bz = P; bx = in % g.gx; by = in / g.gx; }
-  else { by = P % g.gy; bz = P / g.gy; bx = in; }
-  const int bt = bz / g.split_k;
-  const int ks = bz - bt * g.split_k;
-  const int m0 = by * BM, n0 = bx * BN;
-  const int k_begin = ks * g.k_per_split;
-  const int k_end = (k_begin + g.k_per_split < g.K) ? (k_begin + g.k_per_split) : g.K;
-  if (k_begin >= k_end && g.split_k > 1) return;
-
-  const T* A = reinterpret_cast<const T*>(g.A) + (long long)bt * g.a_bs;
-  const T* Bp = reinterpret_cast<const T*>(g.B) + (long long)bt * g.b_bs;
   const int M_real = g.a_ones_row ? g.M - 1 : g.M;
   const int ones_row = g.a_ones_row ? g.M - 1 : -1;
 
   f32x16_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   Vec16 ra[Cfg<T>::NV], rb[Cfg<T>::NV];
-  const bool a_full = (m0 + BM <= M_real), b_full = (n0 + BN <= g.N);   // block-uniform
-  // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
-  // fast path per operand: full k-step and (k-contiguous: no ones row in this tile; row-contiguous: full tile)
-  // Row tails never need a predicate on the fast path: k-contiguous operands read rows past the end as 0 (buffer bounds
-  // check); row-contiguous operands read whatever follows in memory (or 0 past the allocation), but those tile rows only
-  // feed output rows / columns >= M / N, which the epilogue never stores.  The ones row is patched in after the load.
-  const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
-  const bool a_fast = g.fast_ok && (AMODE == 0 ? !ones_here : (AMODE == 1));
-  const bool b_fast = g.fast_ok && (BMODE == 0 || BMODE == 1);
-  (void)a_full; (void)b_full;
   FastLoad<T, (AMODE == 1 ? 1 : 0)> fa;
   FastLoad<T, (BMODE == 1 ? 1 : 0)> fb;
-  fa.init(A, g.a_rs, g.a_cs, m0, M_real, g.K, tid);
-  fb.init(Bp, g.b_cs, g.b_rs, n0, g.N, g.K, tid);
+
   // fragment of a 32-row sub-tile starting at row rb, k offset kk: lane l holds row rb + (l & 31), k = kk + 8*(l>>5) .. +8
-  auto frag = [&](const T* S, auto mode, int rb, int kk) -> bf16x8_t {
+  auto frag = [&](const T* S, auto mode, int rb0, int kk) -> bf16x8_t {
     if constexpr (decltype(mode)::value == 1) {
       // each 16-lane group reads a [4 k][16 rows] block; lane i points at k row (i >> 2), rows 4*(i & 3)..+4 and receives
       // the block's column i, i.e. 4 consecutive k of row i
       const int i16 = lane & 15, grp = lane >> 4;
-      const T* p = S + (kk + 8 * (grp >> 1) + (i16 >> 2)) * LDT + rb + 16 * (grp & 1) + 4 * (i16 & 3);
+      const T* p = S + (kk + 8 * (grp >> 1) + (i16 >> 2)) * LDT + rb0 + 16 * (grp & 1) + 4 * (i16 & 3);
       typedef __attribute__((address_space(3))) bf16x4_t* lds_p;
       const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * LDT));
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     } else {
-      return *reinterpret_cast<const bf16x8_t*>(&S[(rb + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
+      return *reinterpret_cast<const bf16x8_t*>(&S[(rb0 + (lane & 31)) * LDK + kk + 8 * (lane >> 5)]);
     }
   };
   auto compute = [&](const T* As, const T* Bs) {
@@ -340,18 +335,54 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
       }
     }
   };
+  // fast path per operand: full k-step and (k-contiguous: no ones row in this tile; row-contiguous: always).  Row tails
+  // never need a predicate on the fast path: k-contiguous operands read rows past the end as 0 (buffer bounds check);
+  // row-contiguous operands read whatever follows in memory (or 0 past the allocation), but those tile rows only feed
+  // output rows / columns >= M / N, which the epilogue never stores.  The ones row is patched in after the load.
+  auto all_fast = [&](const TileCoord& t) -> bool {
+    const bool ones_in = (ones_row >= t.m0 && ones_row < t.m0 + BM);
+    const bool a_f = g.fast_ok && (AMODE == 0 ? !ones_in : (AMODE == 1));
+    const bool b_f = g.fast_ok && (BMODE == 0 || BMODE == 1);
+    return a_f && b_f && (t.k_begin + BK <= t.k_end);
+  };
+  auto init_fast = [&](const TileCoord& t) {
+    fa.init(reinterpret_cast<const T*>(g.A) + (long long)t.bt * g.a_bs, g.a_rs, g.a_cs, t.m0, M_real, g.K, tid);
+    fb.init(reinterpret_cast<const T*>(g.B) + (long long)t.bt * g.b_bs, g.b_cs, g.b_rs, t.n0, g.N, g.K, tid);
+  };
 
-  // Software pipeline: the loads of tile k+1 are issued before tile k is multiplied and are only waited for (and, for the
-  // ones row, patched) when they are stored to LDS after the barrier that ends the multiply.  The all-fast case has its
-  // own loop with its last tile peeled: any merge of the load destinations with another path (the guarded loader, a
-  // conditional load) makes the compiler copy them right after issue, which waits for the loads before the MFMA block.
-  int k_done = k_begin;
-  if (a_fast && b_fast) {
-    const int k_fast_end = k_begin + ((k_end - k_begin) / BK) * BK;
-    if (k_fast_end > k_begin) {
+  bool pre = false;   // ra / rb already hold (or have in flight) the first k tile of the output tile about to start
+  const int G = (int)gridDim.x;
+  for (int L = (int)blockIdx.x; L < g.total_blocks; L += G) {
+    const TileCoord t = decode_tile(g, L);
+    if (!t.valid) continue;
+    const int m0 = t.m0, n0 = t.n0, bt = t.bt, ks = t.ks, k_begin = t.k_begin, k_end = t.k_end;
+    const T* A = reinterpret_cast<const T*>(g.A) + (long long)bt * g.a_bs;
+    const T* Bp = reinterpret_cast<const T*>(g.B) + (long long)bt * g.b_bs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B(k, n) = B[k*b_rs + n*b_cs]: the LDS "row" is n  =>  row stride = b_cs, k stride = b_rs
+    const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
+    const bool a_fast = g.fast_ok && (AMODE == 0 ? !ones_here : (AMODE == 1));
+    const bool b_fast = g.fast_ok && (BMODE == 0 || BMODE == 1);
+    if (!pre) init_fast(t);
+
+    // Software pipeline: the loads of tile k+1 are issued before tile k is multiplied and are only waited for (and, for
+    // the ones row, patched) when they are stored to LDS after the barrier that ends the multiply.  The all-fast case has
+    // its own loop with its last tile peeled: any merge of the load destinations with another path (the guarded loader, a
+    // conditional load) makes the compiler copy them right after issue, which waits for the loads before the MFMA block.
+    int k_done = k_begin;
+    if (all_fast(t)) {
+      const int k_fast_end = k_begin + ((k_end - k_begin) / BK) * BK;
       const bool patch = (AMODE == 1) && ones_here;
-      fa.load(ra, k_begin);
-      fb.load(rb, k_begin);
+      if (!pre) {
+        fa.load(ra, k_begin);
+        fb.load(rb, k_begin);
+      }
       if (patch) patch_ones_row<T>(ra, m0, ones_row, tid);
       store_tile<T, AMODE>(As0, ra, tid);
       store_tile<T, BMODE>(Bs0, rb, tid);
@@ -372,132 +403,148 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
       __syncthreads();
       k_done = k_fast_end;
     }
-  }
-  // guarded loop: K tail of the fast case, and every tile of the other cases
-  for (int k0 = k_done; k0 < k_end; k0 += BK) {
-    if (a_fast && k0 + BK <= k_end) {
-      fa.load(ra, k0);
-      if (AMODE == 1 && ones_here) patch_ones_row<T>(ra, m0, ones_row, tid);
-    } else {
-      load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, k0, M_real, k_end, ones_row, tid);
+    // guarded loop: K tail of the fast case, and every tile of the other cases
+    for (int k0 = k_done; k0 < k_end; k0 += BK) {
+      if (a_fast && k0 + BK <= k_end) {
+        fa.load(ra, k0);
+        if (AMODE == 1 && ones_here) patch_ones_row<T>(ra, m0, ones_row, tid);
+      } else {
+        load_tile<T, AMODE>(ra, A, g.a_rs, g.a_cs, m0, k0, M_real, k_end, ones_row, tid);
+      }
+      if (b_fast && k0 + BK <= k_end) fb.load(rb, k0);
+      else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, k0, g.N, k_end, -1, tid);
+      store_tile<T, AMODE>(As0, ra, tid);
+      store_tile<T, BMODE>(Bs0, rb, tid);
+      __syncthreads();
+      compute(As0, Bs0);
+      __syncthreads();
     }
-    if (b_fast && k0 + BK <= k_end) fb.load(rb, k0);
-    else load_tile<T, BMODE>(rb, Bp, g.b_cs, g.b_rs, n0, k0, g.N, k_end, -1, tid);
-    store_tile<T, AMODE>(As0, ra, tid);
-    store_tile<T, BMODE>(Bs0, rb, tid);
-    __syncthreads();
-    compute(As0, Bs0);
-    __syncthreads();
-  }
 
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const float* bias = g.bias ? g.bias + (long long)bt * g.bias_bs : nullptr;
-  const T* gate = g.gate ? reinterpret_cast<const T*>(g.gate) + (long long)bt * g.gate_bs : nullptr;
-  const bool add_bias = (bias != nullptr) && (ks == 0);
+    // request the first operand tiles of this workgroup's next output tile; they land while C is written
+    pre = false;
+    if (L + G < g.total_blocks) {
+      const TileCoord tn = decode_tile(g, L + G);
+      if (tn.valid && all_fast(tn)) {
+        init_fast(tn);
+        fa.load(ra, tn.k_begin);
+        fb.load(rb, tn.k_begin);
+        pre = true;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-  if constexpr (sizeof(T) == 2) {
-    if (g.vec_epi) {
-      // bf16 output, 16-byte aligned rows: stage 32 x 64 fp32 per wave in LDS (the operand tiles are dead), then
-      // every lane finishes 8 consecutive columns: vector gate / residual loads and ONE 16-byte store per row piece.
-      float* Cw = reinterpret_cast<float*>(smem) + wave * EPI_WAVE_WORDS;
-      const bf16_t* resid = g.resid ? reinterpret_cast<const bf16_t*>(g.resid) + (long long)bt * g.resid_bs : nullptr;
-      bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs;
-      const int cbase = n0 + wn * 64;
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const float* bias = g.bias ? g.bias + (long long)bt * g.bias_bs : nullptr;
+    const T* gate = g.gate ? reinterpret_cast<const T*>(g.gate) + (long long)bt * g.gate_bs : nullptr;
+    const bool add_bias = (bias != nullptr) && (ks == 0);
+
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+      if (g.vec_epi) {
+        // bf16 output, 16-byte aligned rows: stage 32 x 64 fp32 per wave in LDS (the operand tiles are dead), then
+        // every lane finishes 8 consecutive columns: vector gate / residual loads and ONE 16-byte store per row piece.
+        float* Cw = reinterpret_cast<float*>(smem) + wave * EPI_WAVE_WORDS;
+        const bf16_t* resid = g.resid ? reinterpret_cast<const bf16_t*>(g.resid) + (long long)bt * g.resid_bs : nullptr;
+        bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs;
+        const int cbase = n0 + wn * 64;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cl = j * 32 + (lane & 31);
-          const int col = cbase + cl;
-          const float bv = (add_bias && col < g.N) ? bias[col] : 0.f;
-          const bool relu = col < g.act_ncols;
+          for (int j = 0; j < 2; ++j) {
+            const int cl = j * 32 + (lane & 31);
+            const int col = cbase + cl;
+            const float bv = (add_bias && col < g.N) ? bias[col] : 0.f;
+            const bool relu = col < g.act_ncols;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float x = acc[i][j][r] + bv;
-            if (relu) x = fmaxf(x, 0.f);
-            Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + cl] = x;
+            for (int r = 0; r < 16; ++r) {
+              float x = acc[i][j][r] + bv;
+              if (relu) x = fmaxf(x, 0.f);
+              Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EPI_LD + cl] = x;
+            }
           }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int rbase = m0 + wm * 64 + i * 32;
+          __builtin_amdgcn_wave_barrier();
+          const int rbase = m0 + wm * 64 + i * 32;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int rl = it * 8 + (lane >> 3);
-          const int cl = (lane & 7) * 8;
-          const int row = rbase + rl, col = cbase + cl;
-          if (row < g.M && col < g.N) {
-            float x[8];
-            const float4 lo = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl]);
-            const float4 hi = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl + 4]);
-            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
-            if (col + 8 <= g.N) {
-              if (gate) {
-                Vec16 gv; gv.u = *reinterpret_cast<const uint4*>(gate + (long long)row * g.ldg + col);
+          for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3);
+            const int cl = (lane & 7) * 8;
+            const int row = rbase + rl, col = cbase + cl;
+            if (row < g.M && col < g.N) {
+              float x[8];
+              const float4 lo = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl]);
+              const float4 hi = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl + 4]);
+              x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+              if (col + 8 <= g.N) {
+                if (gate) {
+                  Vec16 gv; gv.u = *reinterpret_cast<const uint4*>(gate + (long long)row * g.ldg + col);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (!(bf2f(gv.h[e]) > 0.f)) x[e] = 0.f;
-              }
-              if (resid) {
-                Vec16 rv; rv.u = *reinterpret_cast<const uint4*>(resid + (long long)row * g.ldr + col);
+                  for (int e = 0; e < 8; ++e) if (!(bf2f(gv.h[e]) > 0.f)) x[e] = 0.f;
+                }
+                if (resid) {
+                  Vec16 rv; rv.u = *reinterpret_cast<const uint4*>(resid + (long long)row * g.ldr + col);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] += bf2f(rv.h[e]);
-              }
-              uint4 o;
-              o.x = cvt_pk_bf16(x[0], x[1]); o.y = cvt_pk_bf16(x[2], x[3]);
-              o.z = cvt_pk_bf16(x[4], x[5]); o.w = cvt_pk_bf16(x[6], x[7]);
-              *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o;
-            } else {
+                  for (int e = 0; e < 8; ++e) x[e] += bf2f(rv.h[e]);
+                }
+                uint4 o;
+                o.x = cvt_pk_bf16(x[0], x[1]); o.y = cvt_pk_bf16(x[2], x[3]);
+                o.z = cvt_pk_bf16(x[4], x[5]); o.w = cvt_pk_bf16(x[6], x[7]);
+                *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o;
+              } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                if (col + e < g.N) {
-                  float y = x[e];
-                  if (gate && !(bf2f(gate[(long long)row * g.ldg + col + e]) > 0.f)) y = 0.f;
-                  if (resid) y += bf2f(resid[(long long)row * g.ldr + col + e]);
-                  Cg[(long long)row * g.ldc + col + e] = f2bf(y);
+                for (int e = 0; e < 8; ++e) {
+                  if (col + e < g.N) {
+                    float y = x[e];
+                    if (gate && !(bf2f(gate[(long long)row * g.ldg + col + e]) > 0.f)) y = 0.f;
+                    if (resid) y += bf2f(resid[(long long)row * g.ldr + col + e]);
+                    Cg[(long long)row * g.ldc + col + e] = f2bf(y);
+                  }
                 }
               }
             }
           }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        done = true;
       }
-      return;
     }
-  }
 
+    if (!done)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (col >= g.N) continue;
-      const float bv = add_bias ? bias[col] : 0.f;
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        const float bv = add_bias ? bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        float x = acc[i][j][r] + bv;
-        if (col < g.act_ncols) x = fmaxf(x, 0.f);
-        if (gate) {
-          if (!(ldf<T>(gate + (long long)row * g.ldg + col) > 0.f)) x = 0.f;
-        }
-        if (row == ones_row) {
-          float* cl = g.c_last + (long long)bt * g.clast_bs;
-          if (g.split_k > 1 || g.accumulate) atomicAdd(cl + col, x); else cl[col] = x;
-          continue;
-        }
-        if (g.out_f32) {
-          float* Cp = reinterpret_cast<float*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
-          if (g.resid && ks == 0)
-            x += reinterpret_cast<const float*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col];
-          if (g.split_k > 1 || g.accumulate) atomicAdd(Cp, x); else *Cp = x;
-        } else {
-          bf16_t* Cp = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
-          if (g.resid)
-            x += bf2f(reinterpret_cast<const bf16_t*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col]);
-          *Cp = f2bf(x);
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row >= g.M) continue;
+          float x = acc[i][j][r] + bv;
+          if (col < g.act_ncols) x = fmaxf(x, 0.f);
+          if (gate) {
+            if (!(ldf<T>(gate + (long long)row * g.ldg + col) > 0.f)) x = 0.f;
+          }
+          if (row == ones_row) {
+            float* cl = g.c_last + (long long)bt * g.clast_bs;
+            if (g.split_k > 1 || g.accumulate) atomicAdd(cl + col, x); else cl[col] = x;
+            continue;
+          }
+          if (g.out_f32) {
+            float* Cp = reinterpret_cast<float*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
+            if (g.resid && ks == 0)
+              x += reinterpret_cast<const float*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col];
+            if (g.split_k > 1 || g.accumulate) atomicAdd(Cp, x); else *Cp = x;
+          } else {
+            bf16_t* Cp = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs + (long long)row * g.ldc + col;
+            if (g.resid)
+              x += bf2f(reinterpret_cast<const bf16_t*>(g.resid)[(long long)bt * g.resid_bs + (long long)row * g.ldr + col]);
+            *Cp = f2bf(x);
+          }
         }
       }
     }
+    __syncthreads();   // the staging area is the next tile's operand buffer
   }
 }
 
@@ -561,7 +608,8 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   if (split > 1) { g.inner = g.gx * g.gy; g.panels = g.gz; } else { g.inner = g.gx; g.panels = g.gy * g.gz; }
   const long long nblk = 8ll * g.inner * ((g.panels + 7) / 8);
   DMT_CHECK_ARG(nblk < 0x7FFFFFFFll, "dmt_gemm: grid too large");
-  dim3 grid((unsigned)nblk);
+  g.total_blocks = (int)nblk;
+  dim3 grid((unsigned)(nblk < PERSIST_GRID ? nblk : PERSIST_GRID));
   hipStream_t st = (hipStream_t)stream;
   // vectorised epilogue: bf16 in/out, no split / ones row, every row of C / gate / resid 16-byte aligned
   auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };

@@ -95,6 +95,10 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
 
 
 def _pick_split(tiles: int, red: int) -> int:
+    """Split-K factor of a weight-gradient GEMM.  Splitting only pays while the output tiles alone cannot fill the 256 CUs:
+    every extra split adds one fp32 atomic pass over the whole output (MMoE layer-0 dW, 25 MB: split 2 is 4x slower than 1)."""
+    if tiles >= 192:
+        return 1
     s = max(1, min(1024 // max(tiles, 1), red // 512))
     return int(max(1, min(s, 512)))
 

@@ -5,7 +5,10 @@ import torch
 from cikm2020_dmt_amd import ops
 dev = torch.device('cuda')
 shapes = [("ffn1_fwd", 204800, 1280, 320, 'kk'), ("ffn2_fwd", 204800, 320, 1280, 'kk'), ("qkv_fwd", 204800, 960, 320, 'kk'),
-          ("ffn1_dW", 321, 1280, 204800, 'mn'), ("ffn2_dW", 1281, 320, 204800, 'mn')]
+          ("ffn1_dW", 321, 1280, 204800, 'mn'), ("ffn2_dW", 1281, 320, 204800, 'mn'),
+          ("mmoe_dW", 3048, 2056, 4096, 'mn'), ("mmoe_dW/s1", 3048, 2056, 4096, 'mn1'), ("mmoe_dW/s4", 3048, 2056, 4096, 'mn4'),
+          ("exp1_dW", 513, 256, 4096, 'mn'), ("exp1_dW/s32", 513, 256, 4096, 'mn32'),
+          ("dec_ffn1", 4096, 1280, 320, 'kk')]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 for name, M, N, K, form in shapes:
     if form == 'kk':
@@ -13,7 +16,9 @@ for name, M, N, K, form in shapes:
         C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         f = lambda: ops.gemm(A, K, 1, B, 1, K, M, N, K, C, N)
     else:
-        x = torch.randn(K, M - 1, device=dev).to(torch.bfloat16); dy = torch.randn(K, N, device=dev).to(torch.bfloat16)
+        if len(form) > 2:
+            ops._pick_split = (lambda sp: (lambda tiles, red: sp))(int(form[2:]))
+        x = torch.randn(K, (M - 1 + 7) // 8 * 8, device=dev).to(torch.bfloat16)[:, :M - 1]; dy = torch.randn(K, N, device=dev).to(torch.bfloat16)
         f = lambda: ops.linear_backward_weight(x, dy, want_bias=True)
     for _ in range(3): f()
     torch.cuda.synchronize()
