@@ -228,6 +228,28 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
   return r;
 }
 
+// packed pair of bf16: relu (as int16 a bf16 is negative exactly when its sign bit is set) ...
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ unsigned pk_relu_bf16(unsigned x) {
+  s16x2_t v = __builtin_bit_cast(s16x2_t, x);
+  const s16x2_t z = {0, 0};
+  v = __builtin_elementwise_max(v, z);
+  return __builtin_bit_cast(unsigned, v);
+}
+// ... and the 0xFFFF / 0 mask of "element > 0"
+__device__ __forceinline__ unsigned pk_pos_mask_bf16(unsigned g) {
+  s16x2_t v = __builtin_bit_cast(s16x2_t, g);
+  const s16x2_t z = {0, 0}, one = {1, 1};
+  v = __builtin_elementwise_max(__builtin_elementwise_min(v, one), z);   // 1 where > 0 else 0
+  return __builtin_bit_cast(unsigned, v) * 0xFFFFu;                        // 0x0001 -> 0xFFFF per half (no carry between halves)
+}
+
+// 16-byte non-temporal load through a buffer descriptor (data streamed once must not displace the operand panels in L2)
+__device__ __forceinline__ uint4 load_nt16(__amdgpu_buffer_rsrc_t r, int voff) {
+  auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 2);
+  return make_uint4((unsigned)v[0], (unsigned)v[1], (unsigned)v[2], (unsigned)v[3]);
+}
+
 constexpr int EPI_LD = 68;                       // fp32 words per staged epilogue row (64 + 4 pad)
 constexpr int EPI_WAVE_WORDS = 32 * EPI_LD;      // one wave stages 32 rows x 64 cols at a time
 constexpr int OPER_BYTES = 64 * LDT * 2;          // one operand tile: bf16 [64][160] (mode 1) >= [128][72] (mode 0) >= fp32 [128][20]
@@ -548,6 +570,327 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
 }
 
+// =====================================================================================================================
+// Direct-to-LDS variant for the forward / input-gradient GEMMs: bf16, BOTH operands k-contiguous, K % 64 == 0, bf16 C,
+// no split-K.  ds_write_b128 moves only ~79 B/clk/CU, so staging a 32 KB k-step through VGPRs costs more LDS time than
+// its 16 MFMAs per wave take; here `buffer_load_dwordx4 ... lds` writes the operand tiles into LDS without a VGPR pass.
+//   * LDS image per operand: [128 rows][64 k] bf16, 128-byte rows, NO padding (the DMA destination is wave-uniform base
+//     + lane * 16); the 16-byte slot s of row r holds logical k chunk s ^ ((r >> 1) & 7).  The swizzle is applied on the
+//     per-lane GLOBAL address (still whole 128-byte lines per row) and makes the ds_read_b128 fragment reads (32 rows x
+//     16 B per half-wave) conflict-free for the hardware's 16-lane groups.
+//   * two LDS stages; the DMA for k-step i+1 (or for the first k-step of the workgroup's NEXT output tile) is issued
+//     before k-step i is multiplied and is only waited for with a counted vmcnt(8) (8 DMA instructions per wave per
+//     stage) -- raw s_barrier, never __syncthreads, which would drain the queue.
+//   * MFMA operands are swapped (D^T = B A^T), so a lane ends up with 4 CONSECUTIVE columns of one row per register
+//     quad: the epilogue adds bias / relu in registers and stages packed bf16 (ds_write_b64) -- or fp32 quads when a
+//     residual must be added before the single rounding -- then finishes rows with 16-byte gate loads and stores.
+//   * the whole bias vector (N <= 2048) is put in LDS once per (persistent) workgroup.
+constexpr int GL_STAGE_BYTES = 34816;   // A tile 16 KB | B tile 16 KB | 2 KB slack: = 4 waves x [32][68] fp32 of epilogue staging
+constexpr int GL_MAX_N = 2048;
+constexpr int GL_SMEM = 2 * GL_STAGE_BYTES + GL_MAX_N * 4;
+constexpr int GL_GRID = 256 * 2;        // 2 resident workgroups per CU (77 KB of LDS each)
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_glds_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[GL_SMEM];   // the ONLY LDS object (a second one de-pipelines the DMA)
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * GL_STAGE_BYTES);
+
+  for (int c = tid; c < GL_MAX_N; c += NT) bias_lds[c] = (g.bias != nullptr && c < g.N) ? g.bias[c] : 0.f;
+
+  // loader: wave w, round p fills LDS bytes [(4p + w) * 1024, +1024) of an operand tile = rows 8(4p + w) .. +8
+  const int lrow = wave * 8 + (lane >> 3);
+  const int lchunk = (lane & 7) ^ ((lrow >> 1) & 7);   // (32p + lrow) >> 1 & 7 does not depend on p
+  const int a_voff = (int)(((long long)lrow * g.a_rs + lchunk * 8) * 2);
+  const int b_voff = (int)(((long long)lrow * g.b_cs + lchunk * 8) * 2);
+  const int a_pstep = (int)(32 * g.a_rs * 2), b_pstep = (int)(32 * g.b_cs * 2);
+  // fragment reads: lane l, row (l & 31) of a 32-row block, k chunk 2*(kk/16) + (l >> 5) -> slot = chunk ^ ((row >> 1) & 7)
+  const int fr_base = (lane & 31) * 128;
+  const int fr_y = ((((lane >> 1) & 7) ^ (lane >> 5))) * 16;
+
+  auto make_rsrc = [&](const T* base, long long rows_left, long long rs) {
+    long long bytes = rows_left > 0 ? ((rows_left - 1) * rs + g.K) * 2 : 0;
+    bytes = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+  };
+  auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0) {
+    unsigned char* sb = smem + stage * GL_STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(sb + p * 4096), 16, a_voff, k0 * 2 + p * a_pstep, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, b_voff, k0 * 2 + p * b_pstep, 0, 0);
+  };
+
+  f32x16_t acc[2][2];
+  auto compute = [&](int stage) {
+    const unsigned char* As = smem + stage * GL_STAGE_BYTES + wm * 64 * 128 + fr_base;
+    const unsigned char* Bs = smem + stage * GL_STAGE_BYTES + 16384 + wn * 64 * 128 + fr_base;
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      const int ko = (kk * 2) ^ fr_y;
+      bf16x8_t af[2], bfv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + i * 4096 + ko);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfv[j] = *reinterpret_cast<const bf16x8_t*>(Bs + j * 4096 + ko);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfv[j], af[i], acc[i][j], 0, 0, 0);   // swapped: D^T
+    }
+  };
+
+  const T* Ag = reinterpret_cast<const T*>(g.A);
+  const T* Bg = reinterpret_cast<const T*>(g.B);
+  const bf16_t* gate = reinterpret_cast<const bf16_t*>(g.gate);
+  const bf16_t* resid = reinterpret_cast<const bf16_t*>(g.resid);
+  bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
+  const int nk = g.K / 64;
+  const int G = (int)gridDim.x;
+  int cur = 0;
+  bool pre = false;
+  bool relaxed = false;   // the only VMEM ops younger than the prefetched stage are >= 8 C stores of the previous epilogue
+  __syncthreads();   // bias_lds
+  // work id L = 8 * (pi * inner + in) + xcd  ->  M panel P = 8 * pi + xcd, N tile `in` (no split-K, no batch here).
+  // L advances by G = 8 * gq per tile, so (pi, in) are updated incrementally: no integer division in the tile loop.
+  const int gq = G >> 3;
+  const int q_step = gq / g.inner, r_step = gq - q_step * g.inner;
+  const int xcd = (int)blockIdx.x & 7;
+  int pi = ((int)blockIdx.x >> 3) / g.inner, in = ((int)blockIdx.x >> 3) - pi * g.inner;
+  for (int L = (int)blockIdx.x; L < g.total_blocks; L += G) {
+    const int P = pi * 8 + xcd;
+    const int m0 = P * BM, n0 = in * BN;
+    // the next tile of this workgroup
+    int pi_n = pi + q_step, in_n = in + r_step;
+    if (in_n >= g.inner) { in_n -= g.inner; ++pi_n; }
+    const int Pn = pi_n * 8 + xcd;
+    pi = pi_n; in = in_n;
+    if (P >= g.panels) break;   // P grows with L: nothing valid follows
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ag + (long long)m0 * g.a_rs, g.M - m0, g.a_rs);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bg + (long long)n0 * g.b_cs, g.N - n0, g.b_cs);
+    long long c_bytes = (long long)(g.M - m0) * g.ldc * 2;
+    c_bytes = c_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : c_bytes;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(Cg + (long long)m0 * g.ldc, 0, (int)(unsigned)c_bytes, 0x00020000);
+    // gate / residual rows of this tile (streamed once: non-temporal).  Only the interior fast path uses them.
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(gate ? gate + (long long)m0 * g.ldg : Cg), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(resid ? resid + (long long)m0 * g.ldr : Cg), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (!pre) issue(cur, ra, rb, 0);
+    // ONE barrier per k-step: after it, stage `cur` has landed for every wave and every wave has left stage cur^1 (its
+    // previous multiply, or the previous tile's epilogue staging), so the next DMA can be aimed at cur^1 right away.
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      // (in-order completion: "at most 8 outstanding" already implies the stage has landed; the stores drain behind the multiply)
+      if (relaxed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      relaxed = false;
+      __builtin_amdgcn_s_barrier();
+      issue(cur ^ 1, ra, rb, (kt + 1) * 64);
+      compute(cur);
+      cur ^= 1;
+    }
+    // last k-step: the DMA queue is kept busy with the first k-step of this workgroup's next output tile
+    if (relaxed) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    relaxed = false;
+    __builtin_amdgcn_s_barrier();
+    pre = false;
+    if (L + G < g.total_blocks && Pn < g.panels) {
+      const int m0n = Pn * BM, n0n = in_n * BN;
+      issue(cur ^ 1, make_rsrc(Ag + (long long)m0n * g.a_rs, g.M - m0n, g.a_rs), make_rsrc(Bg + (long long)n0n * g.b_cs, g.N - n0n, g.b_cs), 0);
+      pre = true;
+    }
+    compute(cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done reading stage `cur`: it becomes the epilogue staging area
+
+    // ---- epilogue (stage `cur` is free: it is the staging area).  Swapped C layout of the 32x32 MFMA:
+    //      output row = lane & 31, output col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    unsigned char* stg = smem + cur * GL_STAGE_BYTES + wave * (32 * EPI_LD * 4);
+    const int ml = lane & 31, h4 = 4 * (lane >> 5);
+    const int cbase = n0 + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = m0 + wm * 64 + i * 32;
+      if (resid == nullptr) {
+        bf16_t* Sw = reinterpret_cast<bf16_t*>(stg);   // [32][72] bf16
+        // relu on the rounded value: as int16, a bf16 is negative exactly when its sign bit is set
+        const int relu_mode = (cbase + 64 <= g.act_ncols) ? 1 : (cbase >= g.act_ncols ? 0 : 2);   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = j * 32 + 8 * q + h4;
+            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[cbase + nl]);
+            float x0 = acc[i][j][4 * q + 0] + bv.x, x1 = acc[i][j][4 * q + 1] + bv.y;
+            float x2 = acc[i][j][4 * q + 2] + bv.z, x3 = acc[i][j][4 * q + 3] + bv.w;
+            if (relu_mode == 2) {
+              const int cg0 = cbase + nl;
+              if (cg0 + 0 < g.act_ncols) x0 = fmaxf(x0, 0.f);
+              if (cg0 + 1 < g.act_ncols) x1 = fmaxf(x1, 0.f);
+              if (cg0 + 2 < g.act_ncols) x2 = fmaxf(x2, 0.f);
+              if (cg0 + 3 < g.act_ncols) x3 = fmaxf(x3, 0.f);
+            }
+            uint2 o;
+            o.x = cvt_pk_bf16(x0, x1);
+            o.y = cvt_pk_bf16(x2, x3);
+            if (relu_mode == 1) {
+              o.x = pk_relu_bf16(o.x);
+              o.y = pk_relu_bf16(o.y);
+            }
+            *reinterpret_cast<uint2*>(&Sw[ml * 72 + nl]) = o;
+          }
+        __builtin_amdgcn_wave_barrier();
+        const bool interior = (rbase + 32 <= g.M) && (cbase + 64 <= g.N);   // wave-uniform
+        if (interior) {
+          const int cl = (lane & 7) * 8;
+          const long long rrow = rbase + (lane >> 3);
+          uint4 v[4], gv[4];
+          if (gate) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) gv[it] = load_nt16(rg, (int)((((long long)(wm * 64 + i * 32 + it * 8 + (lane >> 3))) * g.ldg + cbase + cl) * 2));
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const uint4*>(&Sw[(it * 8 + (lane >> 3)) * 72 + cl]);
+          if (gate) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              v[it].x &= pk_pos_mask_bf16(gv[it].x); v[it].y &= pk_pos_mask_bf16(gv[it].y);
+              v[it].z &= pk_pos_mask_bf16(gv[it].z); v[it].w &= pk_pos_mask_bf16(gv[it].w);
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            u32x4_t o = {v[it].x, v[it].y, v[it].z, v[it].w};
+            const int voff = (int)((((long long)(wm * 64 + i * 32 + it * 8 + (lane >> 3))) * g.ldc + cbase + cl) * 2);
+            // C is written once and not read by this kernel: non-temporal, so it does not push the operand panels out of L2
+            __builtin_amdgcn_raw_buffer_store_b128(o, rc, voff, 0, 2);
+          }
+        } else {
+#pragma unroll 1
+          for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3), cl = (lane & 7) * 8;
+            const int row = rbase + rl, col = cbase + cl;
+            if (row < g.M && col < g.N) {
+              Vec16 v;
+              v.u = *reinterpret_cast<const uint4*>(&Sw[rl * 72 + cl]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (col + e < g.N) {
+                  bf16_t y = v.h[e];
+                  if (gate && !(bf2f(gate[(long long)row * g.ldg + col + e]) > 0.f)) y = 0;
+                  Cg[(long long)row * g.ldc + col + e] = y;
+                }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        float* Cw = reinterpret_cast<float*>(stg);     // [32][68] fp32: bias, relu, gate, residual, THEN one rounding
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = j * 32 + 8 * q + h4;
+            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[cbase + nl]);
+            float4 x;
+            x.x = acc[i][j][4 * q + 0] + bv.x; x.y = acc[i][j][4 * q + 1] + bv.y;
+            x.z = acc[i][j][4 * q + 2] + bv.z; x.w = acc[i][j][4 * q + 3] + bv.w;
+            const int cg0 = cbase + nl;
+            if (cg0 + 0 < g.act_ncols) x.x = fmaxf(x.x, 0.f);
+            if (cg0 + 1 < g.act_ncols) x.y = fmaxf(x.y, 0.f);
+            if (cg0 + 2 < g.act_ncols) x.z = fmaxf(x.z, 0.f);
+            if (cg0 + 3 < g.act_ncols) x.w = fmaxf(x.w, 0.f);
+            *reinterpret_cast<float4*>(&Cw[ml * EPI_LD + nl]) = x;
+          }
+        __builtin_amdgcn_wave_barrier();
+        const bool interior = (rbase + 32 <= g.M) && (cbase + 64 <= g.N);   // wave-uniform
+        if (interior) {
+          const int cl = (lane & 7) * 8;
+          uint4 gv[4], rv[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const long long rloc = wm * 64 + i * 32 + it * 8 + (lane >> 3);
+            rv[it] = load_nt16(rr, (int)((rloc * g.ldr + cbase + cl) * 2));
+            if (gate) gv[it] = load_nt16(rg, (int)((rloc * g.ldg + cbase + cl) * 2));
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3);
+            float4 lo = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl]);
+            float4 hi = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl + 4]);
+            if (gate) {
+              const unsigned m0_ = pk_pos_mask_bf16(gv[it].x), m1_ = pk_pos_mask_bf16(gv[it].y), m2_ = pk_pos_mask_bf16(gv[it].z), m3_ = pk_pos_mask_bf16(gv[it].w);
+              lo.x = (m0_ & 0xFFFFu) ? lo.x : 0.f; lo.y = (m0_ >> 16) ? lo.y : 0.f; lo.z = (m1_ & 0xFFFFu) ? lo.z : 0.f; lo.w = (m1_ >> 16) ? lo.w : 0.f;
+              hi.x = (m2_ & 0xFFFFu) ? hi.x : 0.f; hi.y = (m2_ >> 16) ? hi.y : 0.f; hi.z = (m3_ & 0xFFFFu) ? hi.z : 0.f; hi.w = (m3_ >> 16) ? hi.w : 0.f;
+            }
+            lo.x += __uint_as_float(rv[it].x << 16); lo.y += __uint_as_float(rv[it].x & 0xFFFF0000u);
+            lo.z += __uint_as_float(rv[it].y << 16); lo.w += __uint_as_float(rv[it].y & 0xFFFF0000u);
+            hi.x += __uint_as_float(rv[it].z << 16); hi.y += __uint_as_float(rv[it].z & 0xFFFF0000u);
+            hi.z += __uint_as_float(rv[it].w << 16); hi.w += __uint_as_float(rv[it].w & 0xFFFF0000u);
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            u32x4_t o = {cvt_pk_bf16(lo.x, lo.y), cvt_pk_bf16(lo.z, lo.w), cvt_pk_bf16(hi.x, hi.y), cvt_pk_bf16(hi.z, hi.w)};
+            const int voff = (int)((((long long)(wm * 64 + i * 32 + rl)) * g.ldc + cbase + cl) * 2);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rc, voff, 0, 2);
+          }
+        } else {
+#pragma unroll 1
+          for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3), cl = (lane & 7) * 8;
+            const int row = rbase + rl, col = cbase + cl;
+            if (row < g.M && col < g.N) {
+              float x[8];
+              const float4 lo = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl]);
+              const float4 hi = *reinterpret_cast<const float4*>(&Cw[rl * EPI_LD + cl + 4]);
+              x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+              if (col + 8 <= g.N) {
+                if (gate) {
+                  Vec16 gv;
+                  gv.u = *reinterpret_cast<const uint4*>(gate + (long long)row * g.ldg + col);
+#pragma unroll
+                  for (int e = 0; e < 8; ++e)
+                    if (!(bf2f(gv.h[e]) > 0.f)) x[e] = 0.f;
+                }
+                Vec16 rv;
+                rv.u = *reinterpret_cast<const uint4*>(resid + (long long)row * g.ldr + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += bf2f(rv.h[e]);
+                uint4 o;
+                o.x = cvt_pk_bf16(x[0], x[1]); o.y = cvt_pk_bf16(x[2], x[3]);
+                o.z = cvt_pk_bf16(x[4], x[5]); o.w = cvt_pk_bf16(x[6], x[7]);
+                *reinterpret_cast<uint4*>(Cg + (long long)row * g.ldc + col) = o;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (col + e < g.N) {
+                    float y = x[e];
+                    if (gate && !(bf2f(gate[(long long)row * g.ldg + col + e]) > 0.f)) y = 0.f;
+                    y += bf2f(resid[(long long)row * g.ldr + col + e]);
+                    Cg[(long long)row * g.ldc + col + e] = f2bf(y);
+                  }
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    relaxed = pre && (m0 + wm * 64 + 64 <= g.M) && (cbase + 64 <= g.N);
+    cur ^= 1;   // the next tile's first k-step is (arriving) in the other stage; its first barrier also ends this staging
+  }
+}
+
 template <typename T>
 void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
 #define DMT_GEMM_CASE(AM, BMo) \
@@ -622,7 +965,15 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
     const long long a_v_bytes = (g.a_mode == 1 ? 64ll * d->a_cs : 128ll * d->a_rs) * esz, b_v_bytes = (g.b_mode == 1 ? 64ll * d->b_rs : 128ll * d->b_cs) * esz;
     g.fast_ok = (a_k_bytes + a_v_bytes < 0x7FFFFFFFll && b_k_bytes + b_v_bytes < 0x7FFFFFFFll) ? 1 : 0;
   }
-  if (d->in_dtype == DMT_F32) launch_gemm<float>(g, grid, st); else launch_gemm<bf16_t>(g, grid, st);
+  const bool glds = d->in_dtype == DMT_BF16 && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && g.fast_ok && batch == 1 &&
+                    (d->K % 64 == 0) && d->N <= GL_MAX_N;
+  if (glds) {
+    hipLaunchKernelGGL(gemm_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
+  } else if (d->in_dtype == DMT_F32) {
+    launch_gemm<float>(g, grid, st);
+  } else {
+    launch_gemm<bf16_t>(g, grid, st);
+  }
   DMT_CHECK_LAUNCH("dmt_gemm");
   return DMT_OK;
 }
