@@ -212,7 +212,27 @@ __device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, 
   return u.v;
 }
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // hardware round-to-nearest-even pair conversion
+  unsigned r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+constexpr float LOG2E = 1.44269504088896340736f;
+
+// Dropout keep bits of this lane's 32 score slots of query q: bit (16 kt + r) <-> key 32 kt + (r & 3) + 8 (r >> 2) + 4 half.
+// Same counter as drop_factor(): flat index into the [B, H, Tq, Tk] weight tensor (low 32 bits).
+__device__ __forceinline__ unsigned drop_bits(const AttnArgs& a, int b, int h, int q, int half) {
+  if (!a.drop_on) return 0xFFFFFFFFu;
+  const unsigned base = (unsigned)((b * a.H + h) * a.Tq + q) * (unsigned)a.Tk + 4u * half;
+  unsigned bits = 0;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    const unsigned key = (e >> 4) * 32 + ((e & 15) & 3) + 8 * ((e & 15) >> 2);
+    bits |= (dmt_drop_keep(a.drop_seed, base + key, a.drop_thr) ? 1u : 0u) << e;
+  }
+  return bits;
+}
 
 constexpr int TLD = 72;   // row stride (elements) of a transposed [dh][64 rows] bf16 LDS tile: 144 B = 9 x 16 B (odd)
 
@@ -316,11 +336,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
           acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ[qt][s2], acc[kt][qt], 0, 0, 0);
   }
 
-  // ---- masked softmax over keys, per query column
+  // ---- masked softmax over keys, per query column.  Scores are kept in log2 units (scale folded into one multiply,
+  //      v_exp_f32 is exp2); masked keys get the reference's padding value, so an all-masked row is uniform as there.
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
-  const float sc = sqrtf((float)DH);
+  const float kscale = LOG2E / sqrtf((float)DH);
+  const int kl = klen - 4 * half, tk = Tk - 4 * half;   // slot constant c: key = c + 4 half
   bf16x8_t pB[2][4];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -330,10 +352,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float x = acc[kt][qt][r] / sc;
-        if (key >= klen) x = PADDING_NUM;
-        if (key >= Tk) x = -3.0e38f;
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float x = acc[kt][qt][r] * kscale;
+        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+        x = (c >= tk) ? -3.0e38f : x;
         acc[kt][qt][r] = x;
         m = fmaxf(m, x);
       }
@@ -343,26 +365,31 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float e = (key < Tk) ? expf(acc[kt][qt][r] - m) : 0.f;
+        const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);   // slots past Tk: exp2(-3e38 - m) = 0
         acc[kt][qt][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 32, 64);
+    const float inv_sum = __builtin_amdgcn_rcpf(sum);
     const bool qpad = (q >= qlen);
+    const unsigned keep = drop_bits(a, b, h, q, half);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       union { bf16x8_t v; unsigned w[4]; } f;
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {
         const int r0 = 8 * (u & 1) + i;
-        float p0 = acc[u >> 1][qt][r0] / sum, p1 = acc[u >> 1][qt][r0 + 1] / sum;
-        const int k0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+        float p0 = acc[u >> 1][qt][r0] * inv_sum, p1 = acc[u >> 1][qt][r0 + 1] * inv_sum;
+        const int c0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2);
         if (qpad) {      // query mask applied AFTER the softmax (reference behaviour)
-          p0 = (k0 < Tk) ? PADDING_NUM : 0.f;
-          p1 = (k0 + 1 < Tk) ? PADDING_NUM : 0.f;
+          p0 = (c0 < tk) ? PADDING_NUM : 0.f;
+          p1 = (c0 + 1 < tk) ? PADDING_NUM : 0.f;
         }
-        if (a.drop_on) { p0 *= drop_factor(a, b, h, q, k0); p1 *= drop_factor(a, b, h, q, k0 + 1); }
+        if (a.drop_on) {
+          const int e0 = (u >> 1) * 16 + r0;
+          p0 = ((keep >> e0) & 1u) ? p0 * a.drop_inv : 0.f;
+          p1 = ((keep >> (e0 + 1)) & 1u) ? p1 * a.drop_inv : 0.f;
+        }
         f.w[i >> 1] = pack_bf16(p0, p1);
       }
       pB[qt][u] = f.v;
@@ -471,72 +498,60 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
   stage_transposed<DH>(dOt, dOg, a.do_rs, Tq, lane);
   stage_transposed<DH>(Qt, Qg, a.q_rs, Tq, lane);
 
-  f32x16_t acc[2][2], dp[2][2];
+  // K / V row fragments of both key tiles stay in registers across the two query tiles
+  bf16x8_t aK[2][NK], aV[2][NK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < 2; ++t) {
+    const int row = t * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; dp[i][j][r] = 0.f; }
-  {
-    bf16x8_t aK[2][NK], bQ[2][NK];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 32 + l31;
-#pragma unroll
-      for (int s2 = 0; s2 < NK; ++s2) {
-        const int j0 = s2 * 16 + 8 * half;
-        aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
-        bQ[t][s2] = load_frag8(Qg + (long long)row * a.q_rs, j0, row < Tq, DH);
-      }
+    for (int s2 = 0; s2 < NK; ++s2) {
+      const int j0 = s2 * 16 + 8 * half;
+      aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
+      aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
     }
-#pragma unroll
-    for (int s2 = 0; s2 < NK; ++s2)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ[qt][s2], acc[kt][qt], 0, 0, 0);
   }
-  {
-    bf16x8_t aV[2][NK], bD[2][NK];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 32 + l31;
-#pragma unroll
-      for (int s2 = 0; s2 < NK; ++s2) {
-        const int j0 = s2 * 16 + 8 * half;
-        aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
-        bD[t][s2] = load_frag8(dOg + (long long)row * a.do_rs, j0, row < Tq, DH);
-      }
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < NK; ++s2)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          dp[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD[qt][s2], dp[kt][qt], 0, 0, 0);
-  }
-
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
-  const float sc = sqrtf((float)DH);
-  bf16x8_t dsB[2][4];
+  const float kscale = LOG2E / sqrtf((float)DH), inv_sc = 1.0f / sqrtf((float)DH);
+  const int kl = klen - 4 * half, tk = Tk - 4 * half;   // slot constant c: key = c + 4 half
+  bf16x8_t dsB[2][4];     // dS  (B operand of dQ^T, later copied to LDS as [key][q])
+  unsigned pP[2][16];     // P as it feeds dV (query mask and dropout applied), packed pairs of accumulator slots
+  // one query tile (32 queries x 64 keys) at a time: 64 accumulator registers live instead of 128
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qt * 32 + l31;
+    f32x16_t acc[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[kt][r] = 0.f; dp[kt][r] = 0.f; }
+    {
+      bf16x8_t bQ[NK], bD[NK];
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) {
+        const int j0 = s2 * 16 + 8 * half;
+        bQ[s2] = load_frag8(Qg + (long long)q * a.q_rs, j0, q < Tq, DH);
+        bD[s2] = load_frag8(dOg + (long long)q * a.do_rs, j0, q < Tq, DH);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ[s2], acc[kt], 0, 0, 0);   // S^T = K Q^T
+          dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD[s2], dp[kt], 0, 0, 0);     // dP^T = V dO^T
+        }
+    }
     float m = -3.0e38f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float x = acc[kt][qt][r] / sc;
-        if (key >= klen) x = PADDING_NUM;
-        if (key >= Tk) x = -3.0e38f;
-        acc[kt][qt][r] = x;
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float x = acc[kt][r] * kscale;
+        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+        x = (c >= tk) ? -3.0e38f : x;
+        acc[kt][r] = x;
         m = fmaxf(m, x);
       }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -545,21 +560,24 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float e = (key < Tk) ? expf(acc[kt][qt][r] - m) : 0.f;
-        acc[kt][qt][r] = e;
+        const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
+        acc[kt][r] = e;
         sum += e;
       }
     sum += __shfl_xor(sum, 32, 64);
+    const float inv_sum = __builtin_amdgcn_rcpf(sum);
+    const unsigned keep = drop_bits(a, b, h, q, half);
     float dot = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = acc[kt][qt][r] / sum;
-        acc[kt][qt][r] = pv;
-        if (a.drop_on) dp[kt][qt][r] *= drop_factor(a, b, h, q, kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-        dot += pv * dp[kt][qt][r];
+        const float pv = acc[kt][r] * inv_sum;
+        acc[kt][r] = pv;
+        float gq = dp[kt][r];
+        if (a.drop_on) gq = ((keep >> (kt * 16 + r)) & 1u) ? gq * a.drop_inv : 0.f;   // gradient w.r.t. the pre-dropout weights
+        dp[kt][r] = gq;
+        dot += pv * gq;
       }
     dot += __shfl_xor(dot, 32, 64);
     const bool qpad = (q >= qlen);
@@ -567,13 +585,13 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float pv = acc[kt][qt][r];
-        float ds = (key < klen) ? pv * (dp[kt][qt][r] - dot) / sc : 0.f;   // no gradient into masked keys
-        if (qpad) { ds = 0.f; pv = (key < Tk) ? PADDING_NUM : 0.f; }       // constant rows: gradient reaches V only
-        if (a.drop_on) pv *= drop_factor(a, b, h, q, key);                 // dropped weights feed dV
-        dp[kt][qt][r] = ds;
-        acc[kt][qt][r] = pv;
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float pv = acc[kt][r];
+        float ds = (c < kl) ? pv * (dp[kt][r] - dot) * inv_sc : 0.f;      // no gradient into masked keys
+        if (qpad) { ds = 0.f; pv = (c < tk) ? PADDING_NUM : 0.f; }        // constant rows: gradient reaches V only
+        if (a.drop_on) pv = ((keep >> (kt * 16 + r)) & 1u) ? pv * a.drop_inv : 0.f;   // dropped weights feed dV
+        dp[kt][r] = ds;
+        acc[kt][r] = pv;
       }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -581,10 +599,14 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {
         const int r0 = 8 * (u & 1) + i;
-        f.w[i >> 1] = pack_bf16(dp[u >> 1][qt][r0], dp[u >> 1][qt][r0 + 1]);
+        f.w[i >> 1] = pack_bf16(dp[u >> 1][r0], dp[u >> 1][r0 + 1]);
       }
       dsB[qt][u] = f.v;
     }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) pP[qt][kt * 8 + (r >> 1)] = pack_bf16(acc[kt][r], acc[kt][r + 1]);
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -615,7 +637,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        PL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = f2bf(acc[kt][qt][r]);
+        PL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(pP[qt][kt * 8 + (r >> 1)] >> (16 * (r & 1)));
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
@@ -641,8 +663,11 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        DL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = f2bf(dp[kt][qt][r]);
+      for (int r = 0; r < 16; ++r) {
+        union { bf16x8_t v; unsigned w[4]; } f;
+        f.v = dsB[qt][2 * kt + (r >> 3)];
+        DL[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(f.w[(r & 7) >> 1] >> (16 * (r & 1)));
+      }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
