@@ -891,6 +891,147 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// =====================================================================================================================
+// Direct-to-LDS variant for the weight-gradient GEMMs dW[M,N] (+)= A B with BOTH operands row-contiguous
+// (A(m,k) = X[k][m], B(k,n) = dY[k][n]: the reduction runs over the strided dim), bf16 operands, fp32 C, split-K.
+//   * LDS image per operand and stage: [64 k][128 rows] bf16 exactly as it lies in memory (256-byte k rows, DMA
+//     destination lane-linear), except that the 64-byte chunk c of k row r is stored at chunk c ^ (r & 3): the four k rows
+//     a ds_read_b64_tr_b16 group touches (same chunk) then sit in four different bank quarters.  The transpose to
+//     k-contiguous MFMA fragments is done by the transpose-read, as in gemm_kernel's mode 1.
+//   * the all-ones row that yields the bias gradient is a COLUMN of this image: in the one M tile that holds it, 64 threads
+//     rewrite that column after the DMA has landed (one extra barrier per k-step, that tile only).
+//   * same 2-stage DMA pipeline / persistent tile loop as gemm_glds_kernel; epilogue = fp32 atomics (split-K / accumulate).
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dw_glds_kernel(const GemmArgs g) {
+  constexpr int STAGE = 32768;   // A image 16 KB | B image 16 KB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M_real = g.a_ones_row ? g.M - 1 : g.M;
+  const int ones_row = g.a_ones_row ? g.M - 1 : -1;
+
+  // loader: wave w, round p fills bytes [(4p + w) * 1024, +1024) of an operand image = k rows 4(4p + w) .. +4
+  const int lr = wave * 4 + (lane >> 4);                       // k row (round 0)
+  const int lchunk = ((lane & 15) >> 2) ^ ((lane >> 4) & 3);   // logical 64-byte chunk landing in this lane's slot
+  const int a_voff = (int)(((long long)lr * g.a_cs + lchunk * 32 + (lane & 3) * 8) * 2);
+  const int b_voff = (int)(((long long)lr * g.b_rs + lchunk * 32 + (lane & 3) * 8) * 2);
+  const long long a_kb = g.a_cs * 2, b_kb = g.b_rs * 2;        // bytes per unit of k
+  // transpose-read fragments: 16-lane group grp reads a [4 k][16 rows] block; lane i16 points at k row (i16 >> 2)
+  const int i16 = lane & 15, grp = lane >> 4;
+  const int fr_lane = (8 * (grp >> 1) + (i16 >> 2)) * 256 + 32 * (grp & 1) + 8 * (i16 & 3);
+  int fr_chunk[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) fr_chunk[c] = ((c ^ (i16 >> 2)) * 64) + fr_lane;
+
+  auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0) {
+    unsigned char* sb = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(sb + p * 4096), 16, a_voff, (int)((k0 + p * 16) * a_kb), 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, b_voff, (int)((k0 + p * 16) * b_kb), 0, 0);
+  };
+  f32x16_t acc[2][2];
+  auto frag = [&](const unsigned char* S, int chunk, int kk) -> bf16x8_t {
+    const unsigned char* q = S + kk * 256 + fr_chunk[chunk];
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(q));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(q + 4 * 256));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto compute = [&](int stage) {
+    const unsigned char* As = smem + stage * STAGE;
+    const unsigned char* Bs = As + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      bf16x8_t af[2], bfv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = frag(As, wm * 2 + i, kk);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfv[j] = frag(Bs, wn * 2 + j, kk);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto rsrc_of = [&](const T* base, long long k_stride, int row0, int rows_real) {
+    long long bytes = ((long long)(g.K - 1) * k_stride + (rows_real - row0)) * 2;
+    bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + row0), 0, (int)(unsigned)bytes, 0x00020000);
+  };
+
+  const T* Ag = reinterpret_cast<const T*>(g.A);
+  const T* Bg = reinterpret_cast<const T*>(g.B);
+  const int G = (int)gridDim.x;
+  int cur = 0;
+  bool pre = false;
+  for (int L = (int)blockIdx.x; L < g.total_blocks; L += G) {
+    const TileCoord t = decode_tile(g, L);
+    if (!t.valid) continue;
+    const int m0 = t.m0, n0 = t.n0, ks = t.ks;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(Ag, g.a_cs, m0, M_real);
+    const __amdgpu_buffer_rsrc_t rb = rsrc_of(Bg, g.b_rs, n0, g.N);
+    const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
+    const int ones_ml = ones_row - m0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (!pre) issue(cur, ra, rb, t.k_begin);
+    pre = false;
+    for (int k0 = t.k_begin; k0 < t.k_end; k0 += 64) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // stage `cur` landed for every wave; every wave has left stage cur^1
+      if (k0 + 64 < t.k_end) {
+        issue(cur ^ 1, ra, rb, k0 + 64);
+      } else if (L + G < g.total_blocks) {   // last k-step: request the first stage of this workgroup's next tile
+        const TileCoord tn = decode_tile(g, L + G);
+        if (tn.valid) {
+          issue(cur ^ 1, rsrc_of(Ag, g.a_cs, tn.m0, M_real), rsrc_of(Bg, g.b_rs, tn.n0, g.N), tn.k_begin);
+          pre = true;
+        }
+      }
+      if (ones_here) {                       // the bias-gradient row: column `ones_ml` of the A image := 1.0
+        if (tid < 64) {
+          unsigned char* q = smem + cur * STAGE + tid * 256 + (((ones_ml >> 5) ^ (tid & 3)) * 64) + (ones_ml & 31) * 2;
+          *reinterpret_cast<bf16_t*>(q) = (bf16_t)0x3F80;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      compute(cur);
+      cur ^= 1;
+    }
+    // (the next k-step's barrier orders these reads of the stage against its next DMA: that DMA is only issued after it)
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool atomic = (g.split_k > 1) || g.accumulate;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row >= g.M) continue;
+          const float x = acc[i][j][r];
+          float* dst = (row == ones_row) ? (g.c_last + col) : (reinterpret_cast<float*>(g.C) + (long long)row * g.ldc + col);
+          if (atomic) atomicAdd(dst, x); else *dst = x;
+        }
+      }
+    (void)ks;
+  }
+}
+
 template <typename T>
 void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
 #define DMT_GEMM_CASE(AM, BMo) \
@@ -967,7 +1108,11 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   }
   const bool glds = d->in_dtype == DMT_BF16 && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && g.fast_ok && batch == 1 &&
                     (d->K % 64 == 0) && d->N <= GL_MAX_N;
-  if (glds) {
+  const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok && batch == 1 &&
+                       (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
+  if (dw_glds) {
+    hipLaunchKernelGGL(gemm_dw_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
+  } else if (glds) {
     hipLaunchKernelGGL(gemm_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
   } else if (d->in_dtype == DMT_F32) {
     launch_gemm<float>(g, grid, st);
