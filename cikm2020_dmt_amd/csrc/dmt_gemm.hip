@@ -922,9 +922,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // transpose-read fragments: 16-lane group grp reads a [4 k][16 rows] block; lane i16 points at k row (i16 >> 2)
   const int i16 = lane & 15, grp = lane >> 4;
   const int fr_lane = (8 * (grp >> 1) + (i16 >> 2)) * 256 + 32 * (grp & 1) + 8 * (i16 & 3);
-  int fr_chunk[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) fr_chunk[c] = ((c ^ (i16 >> 2)) * 64) + fr_lane;
+  auto fr_chunk = [&](int c) { return ((c ^ (i16 >> 2)) * 64) + fr_lane; };   // (no array: a dynamically indexed one is promoted to LDS)
 
   auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0) {
     unsigned char* sb = smem + stage * STAGE + wave * 1024;
@@ -936,29 +934,46 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, b_voff, (int)((k0 + p * 16) * b_kb), 0, 0);
   };
   f32x16_t acc[2][2];
-  auto frag = [&](const unsigned char* S, int chunk, int kk) -> bf16x8_t {
-    const unsigned char* q = S + kk * 256 + fr_chunk[chunk];
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(q));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(q + 4 * 256));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
+  // The fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) for an LDS-DMA in
+  // flight (it cannot tell the two stages apart), which would serialise the DMA of k-step i+1 with the multiply of k-step i.
+  // Reads of 16-k slice s+1 are issued before slice s is multiplied; LDS returns in order, so "at most 8 outstanding"
+  // means slice s has arrived.  The waits name the registers they release ("+v") so no MFMA is scheduled above them.
+  const unsigned lds0 = (unsigned)(unsigned long long)((lds_vp)smem);
+  const unsigned aA0 = lds0 + fr_chunk(wm * 2 + 0), aA1 = lds0 + fr_chunk(wm * 2 + 1);
+  const unsigned aB0 = lds0 + 16384 + fr_chunk(wn * 2 + 0), aB1 = lds0 + 16384 + fr_chunk(wn * 2 + 1);
+#define DMT_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define DMT_TR_SLICE(R, so, kk)                                                                             \
+  DMT_TR_READ(R[0], aA0 + so, (kk) * 256); DMT_TR_READ(R[1], aA0 + so, (kk) * 256 + 1024);                    \
+  DMT_TR_READ(R[2], aA1 + so, (kk) * 256); DMT_TR_READ(R[3], aA1 + so, (kk) * 256 + 1024);                    \
+  DMT_TR_READ(R[4], aB0 + so, (kk) * 256); DMT_TR_READ(R[5], aB0 + so, (kk) * 256 + 1024);                    \
+  DMT_TR_READ(R[6], aB1 + so, (kk) * 256); DMT_TR_READ(R[7], aB1 + so, (kk) * 256 + 1024);
+#define DMT_TR_WAIT(R, n) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]))
+#define DMT_TR_MFMA(R)                                                                                      \
+  {                                                                                                         \
+    const bf16x8_t a0 = __builtin_shufflevector(R[0], R[1], 0, 1, 2, 3, 4, 5, 6, 7), a1 = __builtin_shufflevector(R[2], R[3], 0, 1, 2, 3, 4, 5, 6, 7); \
+    const bf16x8_t b0 = __builtin_shufflevector(R[4], R[5], 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(R[6], R[7], 0, 1, 2, 3, 4, 5, 6, 7); \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                           \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                           \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);                           \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                           \
+  }
   auto compute = [&](int stage) {
-    const unsigned char* As = smem + stage * STAGE;
-    const unsigned char* Bs = As + 16384;
-#pragma unroll
-    for (int kk = 0; kk < 64; kk += 16) {
-      bf16x8_t af[2], bfv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = frag(As, wm * 2 + i, kk);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bfv[j] = frag(Bs, wn * 2 + j, kk);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfv[j], acc[i][j], 0, 0, 0);
-    }
+    const unsigned so = (unsigned)stage * STAGE;
+    bf16x4_t r0[8], r1[8];
+    DMT_TR_SLICE(r0, so, 0)
+    DMT_TR_SLICE(r1, so, 16)
+    DMT_TR_WAIT(r0, 8);
+    DMT_TR_MFMA(r0)
+    DMT_TR_SLICE(r0, so, 32)
+    DMT_TR_WAIT(r1, 8);
+    DMT_TR_MFMA(r1)
+    DMT_TR_SLICE(r1, so, 48)
+    DMT_TR_WAIT(r0, 8);
+    DMT_TR_MFMA(r0)
+    DMT_TR_WAIT(r1, 0);
+    DMT_TR_MFMA(r1)
   };
+#undef DMT_TR_READ
   auto rsrc_of = [&](const T* base, long long k_stride, int row0, int rows_real) {
     long long bytes = ((long long)(g.K - 1) * k_stride + (rows_real - row0)) * 2;
     bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
@@ -989,6 +1004,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int k0 = t.k_begin; k0 < t.k_end; k0 += 64) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();          // stage `cur` landed for every wave; every wave has left stage cur^1
+      if (ones_here) {                       // the bias-gradient row: column `ones_ml` of the A image := 1.0 (no DMA is in flight here)
+        if (tid < 64) {
+          unsigned char* q = smem + cur * STAGE + tid * 256 + (((ones_ml >> 5) ^ (tid & 3)) * 64) + (ones_ml & 31) * 2;
+          *reinterpret_cast<bf16_t*>(q) = (bf16_t)0x3F80;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       if (k0 + 64 < t.k_end) {
         issue(cur ^ 1, ra, rb, k0 + 64);
       } else if (L + G < g.total_blocks) {   // last k-step: request the first stage of this workgroup's next tile
@@ -997,14 +1020,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           issue(cur ^ 1, rsrc_of(Ag, g.a_cs, tn.m0, M_real), rsrc_of(Bg, g.b_rs, tn.n0, g.N), tn.k_begin);
           pre = true;
         }
-      }
-      if (ones_here) {                       // the bias-gradient row: column `ones_ml` of the A image := 1.0
-        if (tid < 64) {
-          unsigned char* q = smem + cur * STAGE + tid * 256 + (((ones_ml >> 5) ^ (tid & 3)) * 64) + (ones_ml & 31) * 2;
-          *reinterpret_cast<bf16_t*>(q) = (bf16_t)0x3F80;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
       }
       compute(cur);
       cur ^= 1;
