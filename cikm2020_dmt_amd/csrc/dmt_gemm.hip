@@ -585,6 +585,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 //     quad: the epilogue adds bias / relu in registers and stages packed bf16 (ds_write_b64) -- or fp32 quads when a
 //     residual must be added before the single rounding -- then finishes rows with 16-byte gate loads and stores.
 //   * the whole bias vector (N <= 2048) is put in LDS once per (persistent) workgroup.
+// Tried and rejected (measured on the 204800-row shapes): a 256 x 128 tile with 8 waves and THREE DMA stages (two k-steps in
+// flight, 25 % less operand traffic per FLOP) is 5-20 % slower -- the k-step is not DMA-latency bound; hand-ordered fragment
+// double buffering in compute() is re-scheduled by hipcc and changes nothing.
 constexpr int GL_STAGE_BYTES = 34816;   // A tile 16 KB | B tile 16 KB | 2 KB slack: = 4 waves x [32][68] fp32 of epilogue staging
 constexpr int GL_MAX_N = 2048;
 constexpr int GL_SMEM = 2 * GL_STAGE_BYTES + GL_MAX_N * 4;
