@@ -29,14 +29,16 @@ class GatherDesc(C.Structure):
     _fields_ = [("B", c_i32), ("n_features", c_i32), ("feat", GatherFeature * DMT_MAX_FEATURES), ("n_seq", c_i32),
                 ("seq_out", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("pos", c_vp * DMT_MAX_SEQS),
                 ("tar_out", c_vp), ("d_model", c_i32), ("seq_scale", c_f32), ("pooled", c_vp), ("ld_pooled", c_i64),
-                ("dense", c_vp), ("n_dense", c_i32), ("out_dtype", c_i32)]
+                ("dense", c_vp), ("n_dense", c_i32), ("out_dtype", c_i32),
+                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32)]
 
 
 class EmbGradDesc(C.Structure):
     _fields_ = [("B", c_i32), ("n_features", c_i32), ("feat", GatherFeature * DMT_MAX_FEATURES),
                 ("row_base", c_i32 * DMT_MAX_FEATURES), ("entry_base", c_i32 * (DMT_MAX_FEATURES + 1)),
                 ("total_rows", c_i32), ("dseq", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("dtar", c_vp),
-                ("dpooled", c_vp), ("ld_pooled", c_i64), ("d_model", c_i32), ("seq_scale", c_f32), ("grad_dtype", c_i32)]
+                ("dpooled", c_vp), ("ld_pooled", c_i64), ("d_model", c_i32), ("seq_scale", c_f32), ("grad_dtype", c_i32),
+                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32)]
 
 
 class GemmDesc(C.Structure):
@@ -96,6 +98,7 @@ _SIGS = {
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
+    "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
 }
 

@@ -36,6 +36,8 @@ struct GGroup {
   long long ld;
   const float* dense;
   int n_dense;
+  uint32_t drop_seed, drop_thr;   // block-input dropout fused into the sequence rows (drop_inv == 0: off)
+  float drop_inv;
   int Tmax;         // LDS staging width
   int npc;          // pooled chunks per example
   int CP;           // power-of-two chunk slots per reduction row
@@ -142,6 +144,11 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
       if (g.pos) ld_row<VEC>(g.pos + (long long)t * g.d_model + col, p);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) v[k] = g.scale * v[k] + p[k];
+      if (g.drop_inv != 0.f) {
+        const uint32_t flat = (uint32_t)(((long long)b * g.seq_T + t) * g.d_model + col);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = dmt_drop_keep(g.drop_seed, flat + k, g.drop_thr) ? v[k] * g.drop_inv : 0.f;
+      }
       st_vec<OutT, VEC>(out + (long long)t * g.d_model + col, v);
     }
   }
@@ -288,7 +295,11 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   // ---- phase A
   const GT_* my_src = nullptr;
   float my_scale = 0.f;
-  int my_dim = 0, my_seg = -1;
+  int my_dim = 0, my_seg = -1;      // my_dim bit 16: the fused block-input dropout mask applies to this entry
+  uint32_t my_dseed = 0, my_flat = 0;
+  const bool drop_on = (d.seq_drop_keep > 0.f && d.seq_drop_keep < 1.f);
+  const uint32_t drop_thr = (uint32_t)(d.seq_drop_keep * 16777216.0f);
+  const float drop_inv = drop_on ? 1.f / d.seq_drop_keep : 1.f;
   if (e < n) {
     const uint32_t key = skeys[e];
     if (key < (uint32_t)d.total_rows) {
@@ -315,8 +326,11 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
         my_scale = d.seq_scale;
         if (F.seq_id == DMT_SEQ_TARGET)
           my_src = reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + F.seq_off;
-        else
-          my_src = reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) + ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off;
+        else {
+          const long long flat = ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off;
+          my_src = reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) + flat;
+          if (drop_on) { my_dim |= 1 << 16; my_dseed = d.seq_drop_seed[F.seq_id]; my_flat = (uint32_t)flat; my_scale *= drop_inv; }
+        }
       }
     }
   }
@@ -337,9 +351,14 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
       const unsigned lo = __shfl(my_lo, i, 64), hi = __shfl(my_hi, i, 64);
       sc[k] = __shfl(my_scale, i, 64);
       sg[k] = __shfl(my_seg, i, 64);
-      dm[k] = __shfl(my_dim, i, 64);
+      const int dmf = __shfl(my_dim, i, 64);
+      dm[k] = dmf & 0xFFFF;
       const GT_* src = reinterpret_cast<const GT_*>(((unsigned long long)hi << 32) | lo);
       v[k] = (lane < dm[k]) ? ldf<GT_>(src + lane) : 0.f;
+      if (drop_on && (dmf >> 16)) {   // wave-uniform
+        const uint32_t sd = __shfl(my_dseed, i, 64), fl = __shfl(my_flat, i, 64);
+        if (!dmt_drop_keep(sd, fl + lane, drop_thr)) v[k] = 0.f;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -411,6 +430,7 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
     g.B = d->B;
     g.nfeat = 0;
     g.seq_out = nullptr;
+    g.drop_seed = 0; g.drop_thr = 0; g.drop_inv = 0.f;
     g.seq_T = 0;
     g.pos = nullptr;
     g.d_model = d->d_model > 0 ? d->d_model : 4;
@@ -448,6 +468,11 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
     } else if (seq_id >= 0) {
       DMT_CHECK_ARG(seq_id < d->n_seq && d->seq_out[seq_id] != nullptr, "dmt_gather_fwd: seq_out[%d] missing", seq_id);
       g.seq_out = d->seq_out[seq_id]; g.seq_T = d->seq_T[seq_id]; g.pos = d->pos[seq_id];
+      if (d->seq_drop_keep > 0.f && d->seq_drop_keep < 1.f) {
+        g.drop_seed = d->seq_drop_seed[seq_id];
+        g.drop_thr = (uint32_t)(d->seq_drop_keep * 16777216.0f);
+        g.drop_inv = 1.f / d->seq_drop_keep;
+      }
       if (g.seq_T > g.Tmax) g.Tmax = g.seq_T;
       if (g.pos && ((uintptr_t)g.pos) % 16 != 0) vec4 = false;
     }

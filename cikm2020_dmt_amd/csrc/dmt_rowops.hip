@@ -320,6 +320,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(long long rows, long long c
   atomicAdd(out + c, s * scale);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_drop_kernel(long long rows, long long cols, const T* __restrict__ x, float scale,
+                                                          float* __restrict__ out, int rows_per_block, uint32_t seed, uint32_t thr24) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  for (long long r = r0; r < r1; ++r)
+    if (dmt_drop_keep(seed, (uint32_t)(r * cols + c), thr24)) s += ldf<T>(x + r * cols + c);
+  atomicAdd(out + c, s * scale);
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = f2bf(src[i]);
@@ -520,6 +533,23 @@ extern "C" int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const voi
     hipLaunchKernelGGL((relu_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)dy,
                        (long long)lddy, (const bf16_t*)y, (long long)ldy, (bf16_t*)dz, (long long)lddz);
   DMT_CHECK_LAUNCH("dmt_relu_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, float scale, float* out, uint32_t seed,
+                               float keep_prob, void* stream) {
+  DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum_drop: bad argument");
+  DMT_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "dmt_colsum_drop: keep_prob must be in (0, 1]");
+  const int rpb = 64;
+  dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
+  DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum_drop: too many rows");
+  const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((colsum_drop_kernel<float>), grid, dim3(256), 0, st, (long long)rows, (long long)cols, (const float*)x, scale / keep_prob, out, rpb, seed, thr);
+  else
+    hipLaunchKernelGGL((colsum_drop_kernel<bf16_t>), grid, dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)x, scale / keep_prob, out, rpb, seed, thr);
+  DMT_CHECK_LAUNCH("dmt_colsum_drop");
   return DMT_OK;
 }
 

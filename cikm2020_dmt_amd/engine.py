@@ -151,6 +151,13 @@ class GatherFn(torch.autograd.Function):
         desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
         desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
         desc.out_dtype = ops.dt_code(cdt)
+        # block-input dropout of every sequence (TransformerModel.py:101) is applied by the gather itself; its gradient by the
+        # consumers of dX (dmt_embgrad_reduce, dmt_colsum_drop) -- same counter mask as ops.dropout(x, rate, seed, 10*s)
+        seeds, keep = engine._input_dropout(n_seq)
+        for s in range(n_seq):
+            desc.seq_drop_seed[s] = seeds[s]
+        desc.seq_drop_keep = keep
+        ctx.drop = (seeds, keep)
         with ops._Timed("gather_fwd", engine.gather_bytes(batch, seq_T)):
             L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
         ctx.engine, ctx.batch, ctx.inv, ctx.seq_T = engine, batch, inv, seq_T
@@ -175,9 +182,14 @@ class GatherFn(torch.autograd.Function):
         dpos = []
         for s in range(n_seq):
             g = torch.zeros(ctx.pos_shapes[s], dtype=F32, device=dev)
-            ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
+            seeds, keep = ctx.drop
+            if 0.0 < keep < 1.0:
+                L.call("dmt_colsum_drop", ops.dt_code(dX[s].dtype), B, ctx.seq_T[s] * d, ops.p(dX[s]), 1.0, ops.p(g), int(seeds[s]), float(keep),
+                       ops.stream_ptr())
+            else:
+                ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
             dpos.append(g)
-        engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz)
+        engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz, ctx.drop)
         return (None, None, *dpos)
 
 
@@ -311,7 +323,7 @@ class DMTEngine:
     def encode_prepared(self, x, lens, i):
         """TransformerModel.encode after the input prep (x = sqrt(d)*seq_emb + P, fused into the gather)."""
         blk = trans_prefix(i) + "num_blocks_0/"
-        x = ops.dropout(x, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 0)     # TransformerModel.py:101
+        # TransformerModel.py:101 dropout(enc): already applied by the gather (GatherFn), stream id 10 * i + 0
         x = self.mha_self(x, lens, blk, 10 * i + 2)
         return self.ff(x, blk + "positionwise_feedforward/")
 
@@ -447,10 +459,21 @@ class DMTEngine:
         batch._prep = prep
         return prep
 
-    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz):
+    def _input_dropout(self, n_seq):
+        """(per-sequence site seeds, keep probability) of the block-input dropout; keep = 0.0 when dropout is off."""
+        rate = self.spec.get("dropout_rate", 0.0)
+        if self.dropout_step_seed is None or not rate:
+            return [0] * n_seq, 0.0
+        return [ops.site_seed(self.dropout_step_seed, 10 * s + 0) for s in range(n_seq)], 1.0 - rate
+
+    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz, drop=None):
         plan = self.plan
         prep = self.prepare(batch)
         desc, n = prep["desc"], prep["n"]
+        seeds, keep = drop if drop is not None else ([0] * len(dX), 0.0)
+        for s in range(len(dX)):
+            desc.seq_drop_seed[s] = seeds[s]
+        desc.seq_drop_keep = keep
         for i in range(len(plan.items)):
             desc.feat[i].inv_wsum = inv[i].data_ptr()
         for s in range(len(dX)):

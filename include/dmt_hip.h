@@ -85,6 +85,11 @@ typedef struct {
   const float* dense;               /* fp32 [B, n_dense] 'features' or NULL                          */
   int32_t n_dense;                  /* copied to pooled[:, 0:n_dense]                                */
   int32_t out_dtype;                /* dtype of seq_out / tar_out / pooled                           */
+  /* Block-input dropout fused into the sequence outputs (TransformerModel.py:101  tf.layers.dropout(enc, rate, training)):
+   * seq_out[s] element i (flat index into [B, seq_T[s], d_model]) is kept iff the counter hash of
+   * (i ^ seq_drop_seed[s]) passes seq_drop_keep, and scaled by 1/keep; seq_drop_keep <= 0 or >= 1: off.  */
+  uint32_t seq_drop_seed[DMT_MAX_SEQS];
+  float seq_drop_keep;
 } dmt_gather_desc;
 
 int dmt_gather_fwd(const dmt_gather_desc* d, void* stream);
@@ -114,6 +119,9 @@ typedef struct {
   int32_t d_model;
   float seq_scale;
   int32_t grad_dtype;
+  /* the same dropout mask as dmt_gather_desc, applied to dseq[s] while it is read (gradient of the fused dropout) */
+  uint32_t seq_drop_seed[DMT_MAX_SEQS];
+  float seq_drop_keep;
 } dmt_embgrad_desc;
 
 /* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e.            */
@@ -304,6 +312,10 @@ int dmt_cast_transpose_bf16(int32_t rows, int32_t cols, const float* src, int64_
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
 int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
                void* stream);
+/* out[c] += scale * sum_r mask(r*cols + c) * x[r, c] / keep  with the dmt_dropout counter mask (flat index r*cols + c, x must be
+ * dense: ldx == cols): the gradient of the learned positions behind the dropout fused into dmt_gather_fwd. */
+int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, float scale, float* out, uint32_t seed,
+                    float keep_prob, void* stream);
 
 /* Streaming 200-threshold confusion histogram behind tf.metrics.auc (run_dnn.py:228-241):
  * hist[(label?1:0) * (n_thr+1) + #thresholds below pred] += 1 (int64).                                */
