@@ -802,6 +802,197 @@ __global__ __launch_bounds__(256) void attn_q1_kernel(const AttnArgs a) {
   }
 }
 
+// ---- bf16 single-query attention with lanes ALONG the head dim: 16 lanes x 16 bytes cover one key row (dh <= 128), four
+// rows per wave instruction, so every K / V (and dK / dV) row moves in coalesced 16-byte pieces and is read exactly ONCE:
+// the rows stay in registers between the score pass and the P.V / dQ pass (Tk <= 64: 16 iterations of 4 rows).
+//   s[k]  : 8-term partial dot per lane, reduced over the 16 lanes of the row group
+//   P.V   : lane accumulates its 8 columns over its rows; the 4 row groups are summed at the end
+// Same arithmetic as attn_q1_kernel (IEEE division, expf): it is memory bound either way.
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+}
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float cross_group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float cross_group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+
+template <int DH, bool BWD>
+__global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
+  constexpr int CPR = DH / 8;      // 16-byte chunks per row
+  constexpr int NIT = 16;          // 4 rows per iteration, Tk <= 64
+  const int lane = threadIdx.x & 63;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long long)a.B * a.H) return;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int g = lane >> 4, c = lane & 15;
+  const bool cact = c < CPR;
+  const int Tk = a.Tk;
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : 1;
+  const float sc = sqrtf((float)DH);
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH + c * 8;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH + c * 8;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH + c * 8;
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+
+  uint4 Kr[NIT], Vr[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * 4 + g;
+    const bool ok = cact && (k < Tk);
+    Kr[it] = (it * 4 < Tk && ok) ? *reinterpret_cast<const uint4*>(Kg + (long long)k * a.k_rs) : z4;
+    Vr[it] = (it * 4 < Tk && ok) ? *reinterpret_cast<const uint4*>(Vg + (long long)k * a.v_rs) : z4;
+  }
+  float q[8], dO[8];
+  {
+    const uint4 qu = cact ? *reinterpret_cast<const uint4*>(Qg) : z4;
+    unpack8(qu, q);
+    if constexpr (BWD) {
+      const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH + c * 8;
+      const uint4 du = cact ? *reinterpret_cast<const uint4*>(dOg) : z4;
+      unpack8(du, dO);
+    }
+  }
+  float s[NIT], dP[NIT];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    s[it] = -3.0e38f; dP[it] = 0.f;
+    if (it * 4 < Tk) {     // wave-uniform
+      float kf[8];
+      unpack8(Kr[it], kf);
+      float d0 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d0 = fmaf(q[e], kf[e], d0);
+      d0 = group16_sum(d0);
+      const int k = it * 4 + g;
+      float x = d0 / sc;
+      if (k >= klen) x = PADDING_NUM;
+      if (k >= Tk) x = -3.0e38f;
+      s[it] = x;
+      m = fmaxf(m, x);
+      if constexpr (BWD) {
+        float vf[8];
+        unpack8(Vr[it], vf);
+        float d1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d1 = fmaf(dO[e], vf[e], d1);
+        dP[it] = group16_sum(d1);
+      }
+    }
+  }
+  m = cross_group_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int k = it * 4 + g;
+    const float e = (it * 4 < Tk && k < Tk) ? expf(s[it] - m) : 0.f;
+    s[it] = e;
+    sum += e;
+  }
+  sum = cross_group_sum(sum);       // every lane of a group carries the same e: one copy per row, four groups
+  const bool qpad = (0 >= qlen);
+
+  if constexpr (!BWD) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it * 4 < Tk) {
+        const int k = it * 4 + g;
+        float pk = s[it] / sum;
+        if (qpad) pk = PADDING_NUM;                 // query mask applied AFTER the softmax (reference behaviour, F13)
+        pk *= drop_factor(a, b, h, 0, k);
+        if (k >= Tk) pk = 0.f;
+        float vf[8];
+        unpack8(Vr[it], vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(pk, vf[e], o[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = cross_group_sum(o[e]);
+    if (g == 0 && cact) {
+      if (a.resid) {
+        float rf[8];
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.resid) + (long long)b * a.r_bs + h * DH + c * 8), rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += rf[e];
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + (long long)b * a.o_bs + h * DH + c * 8) = pack8(o);
+    }
+  } else {
+    // dot = sum_k p[k] dP[k] (after the dropout factor), ds, then dK / dV rows and dQ
+    float pd[NIT];
+    float dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = it * 4 + g;
+      const float Dk = (it * 4 < Tk) ? drop_factor(a, b, h, 0, k) : 0.f;
+      const float pk = s[it] / sum;
+      dP[it] *= Dk;                                  // gradient w.r.t. the pre-dropout weights
+      pd[it] = Dk;
+      s[it] = pk;
+      if (it * 4 < Tk && k < Tk) dot += pk * dP[it];
+    }
+    dot = cross_group_sum(dot);
+    float dq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] = 0.f;
+    bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH + c * 8;
+    bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH + c * 8;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it * 4 < Tk) {
+        const int k = it * 4 + g;
+        float pk = s[it], ds = 0.f;
+        if (!qpad) ds = (k < klen) ? pk * (dP[it] - dot) / sc : 0.f;   // no gradient into masked keys
+        else pk = PADDING_NUM;                                          // constant rows: gradient reaches V only
+        pk *= pd[it];                                                   // dropped weights feed dV
+        if (cact && k < Tk) {
+          float ok[8], ov[8], kf[8];
+          unpack8(Kr[it], kf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ok[e] = ds * q[e]; ov[e] = pk * dO[e]; dq[e] = fmaf(ds, kf[e], dq[e]); }
+          *reinterpret_cast<uint4*>(dKg + (long long)k * a.dk_rs) = pack8(ok);
+          *reinterpret_cast<uint4*>(dVg + (long long)k * a.dv_rs) = pack8(ov);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] = cross_group_sum(dq[e]);
+    if (g == 0 && cact) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.dQ) + (long long)b * a.dq_bs + h * DH + c * 8) = pack8(dq);
+  }
+}
+
+template <bool BWD>
+int launch_q1v(const AttnArgs& a, hipStream_t st) {
+  const unsigned nb = (unsigned)cdiv64((long long)a.B * a.H, 4);
+  switch (a.dh) {
+    case 16: hipLaunchKernelGGL((attn_q1v_kernel<16, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((attn_q1v_kernel<32, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((attn_q1v_kernel<64, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 80: hipLaunchKernelGGL((attn_q1v_kernel<80, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// 16-byte pieces: base, batch and row strides 16-byte aligned
+static bool q1v_aligned(const void* q, long long s0, long long s1) {
+  return q == nullptr || (((uintptr_t)q) % 16 == 0 && s0 % 8 == 0 && s1 % 8 == 0);
+}
+
 template <typename T, bool BWD>
 int launch_q1(const AttnArgs& a, hipStream_t st) {
   const unsigned nb = (unsigned)cdiv64((long long)a.B * a.H, 4);
@@ -890,6 +1081,8 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->Tq == 1 && q1_aligned(d->dtype, d->Q, d->q_bs, d->q_rs, d->dh) && q1_aligned(d->dtype, d->K, d->k_bs, d->k_rs, d->dh) &&
       q1_aligned(d->dtype, d->V, d->v_bs, d->v_rs, d->dh)) {
+    // (the lanes-along-dh kernel attn_q1v_kernel<.., false> measured 2x SLOWER than this one for the forward: 128 vs 65 us,
+    //  65 us = K and V read once at 4 TB/s; it pays only in the backward, which also writes dK / dV rows)
     const int r1 = (d->dtype == DMT_F32) ? launch_q1<float, false>(a, st) : launch_q1<bf16_t, false>(a, st);
     if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_fwd(q1)"); return DMT_OK; }
   }
@@ -940,6 +1133,12 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
     if (f1.Tq == 1 && q1_aligned(f1.dtype, f1.Q, f1.q_bs, f1.q_rs, f1.dh) && q1_aligned(f1.dtype, f1.K, f1.k_bs, f1.k_rs, f1.dh) &&
         q1_aligned(f1.dtype, f1.V, f1.v_bs, f1.v_rs, f1.dh) && q1_aligned(f1.dtype, d->dout, d->do_bs, d->do_rs, f1.dh) &&
         q1_aligned(f1.dtype, d->dK, d->dk_bs, d->dk_rs, f1.dh) && q1_aligned(f1.dtype, d->dV, d->dv_bs, d->dv_rs, f1.dh)) {
+      if (f1.dtype == DMT_BF16 && f1.Tk <= 64 && q1v_aligned(f1.Q, f1.q_bs, f1.q_rs) && q1v_aligned(f1.K, f1.k_bs, f1.k_rs) &&
+          q1v_aligned(f1.V, f1.v_bs, f1.v_rs) && q1v_aligned(d->dout, d->do_bs, d->do_rs) && q1v_aligned(d->dQ, d->dq_bs, d->dq_rs) &&
+          q1v_aligned(d->dK, d->dk_bs, d->dk_rs) && q1v_aligned(d->dV, d->dv_bs, d->dv_rs) && launch_q1v<true>(a, st) == 0) {
+        DMT_CHECK_LAUNCH("dmt_attn_bwd(q1v)");
+        return DMT_OK;
+      }
       const int r1 = (f1.dtype == DMT_F32) ? launch_q1<float, true>(a, st) : launch_q1<bf16_t, true>(a, st);
       if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_bwd(q1)"); return DMT_OK; }
     }
