@@ -375,9 +375,10 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
 }
 
+template <typename RT>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
                                                           const int* __restrict__ seg, long long n, uint32_t invalid,
-                                                          const float* __restrict__ in_rows, float* __restrict__ out_rows,
+                                                          const RT* __restrict__ in_rows, float* __restrict__ out_rows,
                                                           int max_dim) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
         acc = 0.f;
         cur_seg = sg;
       }
-      if (j < max_dim) acc += in_rows[(long long)ev * max_dim + j];
+      if (j < max_dim) acc += ldf<RT>(in_rows + (long long)ev * max_dim + j);
     }
     if (cur_seg >= 0 && j < max_dim) atomicAdd(&out_rows[(long long)cur_seg * max_dim + j], acc);
   }
@@ -573,8 +574,19 @@ extern "C" int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sort
   DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows && out_rows, "dmt_rows_reduce: null argument");
   if (n == 0) return DMT_OK;
   const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
-  hipLaunchKernelGGL(rows_reduce_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
+  hipLaunchKernelGGL((rows_reduce_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
                      (long long)n, invalid_key, in_rows, out_rows, max_dim);
   DMT_CHECK_LAUNCH("dmt_rows_reduce");
+  return DMT_OK;
+}
+
+extern "C" int dmt_rows_reduce_bf16(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
+                                    uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* stream) {
+  DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows_bf16 && out_rows, "dmt_rows_reduce_bf16: null argument");
+  if (n == 0) return DMT_OK;
+  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
+  hipLaunchKernelGGL((rows_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
+                     (long long)n, invalid_key, reinterpret_cast<const bf16_t*>(in_rows_bf16), out_rows, max_dim);
+  DMT_CHECK_LAUNCH("dmt_rows_reduce_bf16");
   return DMT_OK;
 }

@@ -63,7 +63,8 @@ class Trainer:
         uniq, n_uniq, grad_rows, _cap = sparse
         n = int(n_uniq.item())
         eng, st = self.engine, self.store
-        all_k, all_r, cap = parallel.allgather_sparse(uniq, grad_rows, n, st.total_rows)
+        wire = torch.bfloat16 if st.compute_dtype == torch.bfloat16 else None    # bf16 mode: gradient rows travel as bf16
+        all_k, all_r, cap = parallel.allgather_sparse(uniq, grad_rows, n, st.total_rows, transport_dtype=wire)
         N = all_k.numel()
         vals = torch.arange(N, dtype=torch.int32, device=all_k.device)
         keys_s = eng._buf("m_keys_s", (N,), torch.int32)
@@ -73,8 +74,8 @@ class Trainer:
         capm = min(N, st.total_rows)
         out_rows = eng._buf("m_rows", (capm, grad_rows.shape[1]), torch.float32)
         out_rows.zero_()
-        L.call("dmt_rows_reduce", ops.p(keys_s), ops.p(vals_s), ops.p(seg), N, st.total_rows, ops.p(all_r), ops.p(out_rows),
-               int(grad_rows.shape[1]), ops.stream_ptr())
+        L.call("dmt_rows_reduce_bf16" if all_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(keys_s), ops.p(vals_s), ops.p(seg), N,
+               st.total_rows, ops.p(all_r), ops.p(out_rows), int(grad_rows.shape[1]), ops.stream_ptr())
         return (uniq2, n_uniq2, out_rows, capm)
 
     def train_step(self, batch: DeviceBatch):

@@ -146,6 +146,9 @@ int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, c
  * out_rows[seg_id[e]] += in_rows[sorted_vals[e]].                                                    */
 int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
                     uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream);
+/* The same with bf16 in_rows (the transport format of the data-parallel exchange in bf16 mode; the sum stays fp32). */
+int dmt_rows_reduce_bf16(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
+                         uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[m,n] = epi( sum_k A(m,k) * B(k,n) ),  A(m,k) = A[m*a_rs + k*a_cs],

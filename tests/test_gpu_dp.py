@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, steps):
+def _worker(rank, world, port, q, steps, bf16=False):
     import torch.distributed as dist
     from cikm2020_dmt_amd.train import Trainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, steps):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
-    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False)
     tr.store.load_state(P)
     losses = []
     for s in range(steps):
@@ -76,3 +76,38 @@ def test_two_rank_train_steps_match_oracle(cuda):
     n_off = sum(int((np.abs(got[k] - P[k]) > 2e-5).sum()) for k in P)
     worst = max(float(np.abs(got[k] - P[k]).max()) for k in P)
     assert n_off <= 1e-4 * total and worst < 5e-4, (n_off, total, worst)
+
+
+def test_two_rank_bf16_mode_replicas_identical_and_close_to_oracle(cuda):
+    """bf16 mode: the per-rank gradient rows travel as bf16 (dmt_rows_reduce_bf16); both ranks must still hold the identical
+    replica, and the result stays inside the bf16 tolerance of the fp64 oracle."""
+    world, steps = 2, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps, True)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+    so, sp = small_specs()
+    P = {k: v.copy() for k, v in O.init_params(so, seed=5).items()}
+    adam = O.TFAdam(lr=1e-3)
+    ref_losses = []
+    for s in range(steps):
+        Gs, Ls = [], []
+        for r in range(world):
+            inputs, mask, _ = make_batch(sp, 6, seed=700 + 10 * s + r, lengths="ragged", weights="random")
+            l, _lg, G = OT.loss_and_grads(P, inputs, mask, so)
+            Gs.append(G); Ls.append(l)
+        adam.apply(P, {k: (Gs[0][k] + Gs[1][k]) / world for k in Gs[0]})
+        ref_losses.append(np.mean(Ls))
+    assert np.abs(np.array(res[0][1]) - np.array(ref_losses)).max() < 3e-2     # bf16 forward tolerance on the loss
+    got = res[0][2]
+    # one Adam step moves every touched parameter by ~lr regardless of the gradient's magnitude: after 2 steps |dp| <= ~2e-3
+    worst = max(float(np.abs(got[k] - P[k]).max()) for k in P)
+    assert worst < 5e-3, worst

@@ -159,3 +159,28 @@ def test_lazy_adam_is_bitwise_equal_to_dense_sweep(cuda):
     assert np.array_equal(oa_p.view(np.uint32), ob_p.view(np.uint32))
     assert np.array_equal(a.tab_m.cpu().numpy().view(np.uint32), b.tab_m.cpu().numpy().view(np.uint32))
     assert np.array_equal(a.tab_v.cpu().numpy().view(np.uint32), b.tab_v.cpu().numpy().view(np.uint32))
+
+
+def test_rows_reduce_bf16_matches_fp32_reduce_of_rounded_rows(cuda):
+    """DP merge in bf16 mode: out[seg[e]] += bf16 in_rows[vals[e]] with fp32 accumulation."""
+    import ctypes as C
+    from cikm2020_dmt_amd import _lib as L, ops
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    N, D, R = 1000, 24, 37
+    keys = torch.randint(0, R, (N,), dtype=torch.int32, device=dev)
+    keys[::17] = R                                   # invalid entries (padding of shorter ranks)
+    order = torch.argsort(keys.to(torch.int64), stable=True)
+    skeys = keys[order].contiguous()
+    svals = order.to(torch.int32).contiguous()
+    uniq, inv = torch.unique(skeys.to(torch.int64), return_inverse=True)
+    seg = inv.to(torch.int32).contiguous()
+    rows = torch.randn(N, D, device=dev)
+    rows_lp = rows.to(torch.bfloat16).contiguous()
+    out = torch.zeros(len(uniq), D, device=dev)
+    L.call("dmt_rows_reduce_bf16", ops.p(skeys), ops.p(svals), ops.p(seg), N, R, ops.p(rows_lp), ops.p(out), D, ops.stream_ptr())
+    ref = torch.zeros(len(uniq), D, device=dev)
+    valid = skeys < R
+    ref.index_add_(0, inv[valid], rows_lp.float()[order][valid])
+    n_valid_rows = int((uniq < R).sum())
+    assert torch.allclose(out[:n_valid_rows], ref[:n_valid_rows], atol=1e-5, rtol=1e-5)
