@@ -98,6 +98,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
     if rank != 0:
         return
 
@@ -131,7 +134,10 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(sp, args)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def cpu_baseline(sp, args):
