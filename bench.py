@@ -50,12 +50,20 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); the HIP path has no CPU fallback")
+    # test hooks (a one-GPU box cannot run RCCL with two ranks): DMT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
+    # DMT_DIST_BACKEND=gloo swaps the transport.  The driver's runs use neither.
+    if os.environ.get("DMT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("DMT_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from cikm2020_dmt_amd import ops
     from cikm2020_dmt_amd import spec as S

@@ -147,7 +147,7 @@ def linear_backward_input(dz, w: Weight, gate=None, resid=None, out=None):
 def _grad_view(leaf):
     """The fp32 gradient-arena view behind a parameter leaf (or a basic slice of one), if it can be accumulated into
     in place: 2-D with unit inner stride, or 1-D contiguous."""
-    g = getattr(leaf, "grad", None)
+    g = leaf.grad if getattr(leaf, "is_leaf", False) else None      # (.grad of a non-leaf view only warns)
     if g is None:
         base = getattr(leaf, "_base", None)
         if base is None or base.grad is None or leaf.dim() != base.dim():
