@@ -59,30 +59,59 @@ __device__ __forceinline__ int find_table(const dmt_table_map& tm, int row) {
   return t;
 }
 
+// Sparse-row kernels: grid-stride over the distinct rows (the count is device-side, so a capacity-sized grid would be
+// mostly empty blocks), FOUR rows per wavefront: a 16-lane group owns one row and moves it in 16-byte pieces (dim % 4 == 0;
+// other widths take the scalar tail), so a wave has 4 x (p, m, v, grad) row reads in flight instead of one.
+constexpr int SPARSE_GRID = 256 * 8;
+
+__device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ void st4(float* q, const float4& x) { *reinterpret_cast<float4*>(q) = x; }
+
 __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
                                                           float* __restrict__ v, int* __restrict__ last_step,
                                                           const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
                                                           const float* __restrict__ grad_rows, int max_dim, float gscale,
                                                           const float* __restrict__ state, const float* __restrict__ lr_hist,
                                                           float b1, float b2, float eps) {
-  const int lane = threadIdx.x & 63;
-  const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (u >= n_uniq[0]) return;
-  const int row = (int)uniq[u];
-  const int t = find_table(tm, row);
-  const int dim = tm.dim[t];
+  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+  const long long n = n_uniq[0];
   const int step = reinterpret_cast<const int*>(state)[3];
-  const int last = last_step[row];
+  const float a = state[2];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
-  for (int j = lane; j < dim; j += 64) {
-    const long long off = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim + j;
-    float pv = p[off], mv = m[off], vv = v[off];
-    catch_up(pv, mv, vv, last + 1, step - 1, lr_hist, c1, c2, eps);
-    adam_update(pv, mv, vv, grad_rows[u * max_dim + j] * gscale, state[2], c1, c2, eps);
-    p[off] = pv; m[off] = mv; v[off] = vv;
+  const long long groups = (long long)gridDim.x * 16;   // 16-lane groups in the grid
+  for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
+    const int row = (int)uniq[u];
+    const int t = find_table(tm, row);
+    const int dim = tm.dim[t];
+    const int last = last_step[row];
+    const long long base = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim;
+    const float* gr = grad_rows + u * max_dim;
+    if ((dim & 3) == 0 && (max_dim & 3) == 0) {
+      for (int j = c * 4; j < dim; j += 64) {
+        float4 pv = ld4(p + base + j), mv = ld4(m + base + j), vv = ld4(v + base + j);
+        const float4 gv = ld4(gr + j);
+        if (last + 1 <= step - 1) {
+          catch_up(pv.x, mv.x, vv.x, last + 1, step - 1, lr_hist, c1, c2, eps);
+          catch_up(pv.y, mv.y, vv.y, last + 1, step - 1, lr_hist, c1, c2, eps);
+          catch_up(pv.z, mv.z, vv.z, last + 1, step - 1, lr_hist, c1, c2, eps);
+          catch_up(pv.w, mv.w, vv.w, last + 1, step - 1, lr_hist, c1, c2, eps);
+        }
+        adam_update(pv.x, mv.x, vv.x, gv.x * gscale, a, c1, c2, eps);
+        adam_update(pv.y, mv.y, vv.y, gv.y * gscale, a, c1, c2, eps);
+        adam_update(pv.z, mv.z, vv.z, gv.z * gscale, a, c1, c2, eps);
+        adam_update(pv.w, mv.w, vv.w, gv.w * gscale, a, c1, c2, eps);
+        st4(p + base + j, pv); st4(m + base + j, mv); st4(v + base + j, vv);
+      }
+    } else {
+      for (int j = c; j < dim; j += 16) {
+        float pv = p[base + j], mv = m[base + j], vv = v[base + j];
+        catch_up(pv, mv, vv, last + 1, step - 1, lr_hist, c1, c2, eps);
+        adam_update(pv, mv, vv, gr[j] * gscale, a, c1, c2, eps);
+        p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
+      }
+    }
+    if (c == 0) last_step[row] = step;   // only this group touches the row (rows are distinct): the read above is long done
   }
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) last_step[row] = step;
 }
 
 __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
@@ -90,26 +119,41 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
                                                            const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
                                                            const float* __restrict__ state, const float* __restrict__ lr_hist,
                                                            float b1, float b2, float eps) {
-  const int lane = threadIdx.x & 63;
-  const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (u >= n_uniq[0]) return;
-  const int row = (int)uniq[u];
+  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+  const long long n = n_uniq[0];
   const int step = reinterpret_cast<const int*>(state)[3];
-  const int last = last_step[row];
-  if (last >= step) return;
-  const int t = find_table(tm, row);
-  const int dim = tm.dim[t];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
-  for (int j = lane; j < dim; j += 64) {
-    const long long off = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim + j;
-    float pv = p[off], mv = m[off], vv = v[off];
-    if (mv != 0.f || vv != 0.f) {
-      catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
-      p[off] = pv; m[off] = mv; v[off] = vv;
+  const long long groups = (long long)gridDim.x * 16;
+  for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
+    const int row = (int)uniq[u];
+    const int last = last_step[row];
+    if (last >= step) continue;
+    const int t = find_table(tm, row);
+    const int dim = tm.dim[t];
+    const long long base = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim;
+    if ((dim & 3) == 0) {
+      for (int j = c * 4; j < dim; j += 64) {
+        float4 pv = ld4(p + base + j), mv = ld4(m + base + j), vv = ld4(v + base + j);
+        const bool live = (mv.x != 0.f) | (vv.x != 0.f) | (mv.y != 0.f) | (vv.y != 0.f) | (mv.z != 0.f) | (vv.z != 0.f) | (mv.w != 0.f) | (vv.w != 0.f);
+        if (live) {
+          catch_up(pv.x, mv.x, vv.x, last + 1, step, lr_hist, c1, c2, eps);
+          catch_up(pv.y, mv.y, vv.y, last + 1, step, lr_hist, c1, c2, eps);
+          catch_up(pv.z, mv.z, vv.z, last + 1, step, lr_hist, c1, c2, eps);
+          catch_up(pv.w, mv.w, vv.w, last + 1, step, lr_hist, c1, c2, eps);
+          st4(p + base + j, pv); st4(m + base + j, mv); st4(v + base + j, vv);
+        }
+      }
+    } else {
+      for (int j = c; j < dim; j += 16) {
+        float pv = p[base + j], mv = m[base + j], vv = v[base + j];
+        if (mv != 0.f || vv != 0.f) {
+          catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
+          p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
+        }
+      }
     }
+    if (c == 0) last_step[row] = step;
   }
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) last_step[row] = step;
 }
 
 __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
@@ -171,7 +215,8 @@ extern "C" int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m,
                                     float beta2, float eps, void* stream) {
   DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && grad_rows && state && lr_hist, "dmt_adam_sparse_rows: null argument");
   DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_sparse_rows: bad table map / max_uniq");
-  const unsigned nb = (unsigned)cdiv64(max_uniq, 4);
+  const long long need = cdiv64(max_uniq, 16);
+  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
   hipLaunchKernelGGL(adam_sparse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
                      grad_rows, max_dim, grad_scale, state, lr_hist, beta1, beta2, eps);
   DMT_CHECK_LAUNCH("dmt_adam_sparse_rows");
@@ -183,7 +228,8 @@ extern "C" int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m
                                      const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
   DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && state && lr_hist, "dmt_adam_catchup_rows: null argument");
   DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_catchup_rows: bad table map / max_uniq");
-  const unsigned nb = (unsigned)cdiv64(max_uniq, 4);
+  const long long need = cdiv64(max_uniq, 16);
+  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
   hipLaunchKernelGGL(adam_catchup_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
                      state, lr_hist, beta1, beta2, eps);
   DMT_CHECK_LAUNCH("dmt_adam_catchup_rows");
