@@ -569,6 +569,28 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
   return DMT_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ rows, const int32_t* __restrict__ n_rows, long long extra,
+                                                        long long max_rows, int row_elems) {
+  long long n = (long long)n_rows[0] + extra;
+  n = n > max_rows ? max_rows : n;
+  const long long total = n * row_elems;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += stride) {
+    if (i + 4 <= total && (row_elems & 3) == 0) *reinterpret_cast<float4*>(rows + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else
+      for (long long j = i; j < total && j < i + 4; ++j) rows[j] = 0.f;
+  }
+}
+
+extern "C" int dmt_zero_rows(float* rows, const int32_t* n_rows, int64_t extra, int64_t max_rows, int32_t row_elems, void* stream) {
+  DMT_CHECK_ARG(rows && n_rows && max_rows >= 0 && row_elems > 0 && extra >= 0, "dmt_zero_rows: bad argument");
+  DMT_CHECK_ARG((((uintptr_t)rows) & 15) == 0, "dmt_zero_rows: rows must be 16-byte aligned");
+  if (max_rows == 0) return DMT_OK;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, rows, n_rows, (long long)extra, (long long)max_rows, row_elems);
+  DMT_CHECK_LAUNCH("dmt_zero_rows");
+  return DMT_OK;
+}
+
 extern "C" int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
                                uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream) {
   DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows && out_rows, "dmt_rows_reduce: null argument");

@@ -483,7 +483,8 @@ class DMTEngine:
         desc.dpooled, desc.ld_pooled = dz.data_ptr(), dz.stride(0)
         desc.grad_dtype = ops.dt_code(dz.dtype)
         grad_rows = self._buf("grad_rows", (prep["cap"], plan.max_dim), F32)
-        grad_rows.zero_()
+        # only the first n_uniq rows are accumulated into (segment ids are < n_uniq); the count lives on the device
+        L.call("dmt_zero_rows", ops.p(grad_rows), ops.p(prep["n_uniq"]), 0, prep["cap"], plan.max_dim, ops.stream_ptr())
         L.call("dmt_embgrad_reduce", C.byref(desc), ops.p(prep["keys_s"]), ops.p(prep["vals_s"]), ops.p(prep["seg"]), n,
                ops.p(grad_rows), plan.max_dim, ops.stream_ptr())
         self.sparse = (prep["uniq"], prep["n_uniq"], grad_rows, prep["cap"])

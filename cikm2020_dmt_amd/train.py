@@ -73,7 +73,7 @@ class Trainer:
         uniq2, n_uniq2 = uniq2.clone(), n_uniq2.clone()
         capm = min(N, st.total_rows)
         out_rows = eng._buf("m_rows", (capm, grad_rows.shape[1]), torch.float32)
-        out_rows.zero_()
+        L.call("dmt_zero_rows", ops.p(out_rows), ops.p(n_uniq2), 0, capm, int(grad_rows.shape[1]), ops.stream_ptr())
         L.call("dmt_rows_reduce_bf16" if all_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(keys_s), ops.p(vals_s), ops.p(seg), N,
                st.total_rows, ops.p(all_r), ops.p(out_rows), int(grad_rows.shape[1]), ops.stream_ptr())
         return (uniq2, n_uniq2, out_rows, capm)

@@ -142,6 +142,10 @@ int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_k
 int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
                        const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream);
 
+/* rows[0 : min(n_rows[0] + extra, max_rows), 0 : row_elems] = 0 with the row count read ON THE DEVICE (the number of distinct rows
+ * of a step is only known there): clears what the reduce kernels will accumulate into instead of the whole capacity. */
+int dmt_zero_rows(float* rows, const int32_t* n_rows, int64_t extra, int64_t max_rows, int32_t row_elems, void* stream);
+
 /* Same reduction for already-materialised rows (data-parallel merge of per-rank sparse gradients):
  * out_rows[seg_id[e]] += in_rows[sorted_vals[e]].                                                    */
 int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
