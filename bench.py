@@ -125,6 +125,18 @@ def main():
                 "bound": "mfma", "achieved": round(fl_g / t_g / 1e12, 2) if t_g > 0 else None, "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl_g / t_g / 1e12 / peak, 4) if t_g > 0 else None, "traffic": None,
                 "avg_launch_us": round(t_g / max(n_g, 1) * 1e6, 2), "time_share": round(t_g / dt, 3)}
+    alg_bytes = sum(prof.get("gemm_bytes", [])) / max(n_g, 1)
+    roofline["algorithmic_bytes_per_launch"] = int(alg_bytes)
+    # HBM bytes per launch from the PMC counters cannot be collected from inside this process; the committed measurement of
+    # the same command (profiles/*_gemm_traffic.json, made by scripts/pmc_traffic.py from two rocprofv3 --pmc passes) is quoted
+    tfile = os.path.join(ROOT, "profiles", "r01d_gemm_traffic.json")
+    if args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            roofline["traffic"] = int(tj["hbm_bytes_per_launch"])
+            roofline["traffic_source"] = "profiles/r01d_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command)"
+        except Exception:
+            pass
     gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",
               "achieved": round(by_ga / t_ga / 1e9, 1) if t_ga > 0 else None, "peak": 8000.0, "unit": "GB/s",
               "frac": round(by_ga / t_ga / 8e12, 4) if t_ga > 0 else None, "avg_launch_us": round(t_ga / max(n_ga, 1) * 1e6, 2),

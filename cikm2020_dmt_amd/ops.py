@@ -90,6 +90,12 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
     d.split_k, d.batch = split_k, batch
     d.accumulate = 1 if accumulate else 0
     d.a_bs, d.b_bs, d.c_bs, d.bias_bs, d.gate_bs, d.resid_bs, d.clast_bs = a_bs, b_bs, c_bs, bias_bs, gate_bs, resid_bs, clast_bs
+    if PROFILE is not None:
+        # algorithmic HBM bytes of this launch: every operand read once, C written once (split-K: one fp32 pass per split)
+        esz, osz, nb = A.element_size(), out.element_size(), max(batch, 1)
+        byt = nb * ((M * K + K * N) * esz + M * N * osz * max(split_k, 1))
+        byt += nb * M * N * esz * ((gate is not None) + (resid is not None))
+        PROFILE.setdefault("gemm_bytes", []).append(float(byt))
     with _Timed("gemm_%s" % ("bf16" if A.dtype == BF16 else "f32"), 2.0 * M * N * K * max(batch, 1)):
         L.call("dmt_gemm", C.byref(d), stream_ptr())
 
