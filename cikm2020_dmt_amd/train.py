@@ -49,6 +49,19 @@ class Trainer:
         self.engine.dropout_step_seed = (self.dropout_seed + self.opt.global_step + 7919 * rank) if self.dropout else None
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
+        self._early = None
+        if _W > 1:
+            # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
+            # final the moment dL/dz exists (91 % of the dense parameters): its all-reduce runs on the collective's own stream
+            # while the three Transformer backward passes are still computing (run_dnn.py:45-80 average_gradients).
+            z = self.engine.intermediates.get("zbuf")
+            off = self.store.leaves["mmoe_layers/l0_cat_weights"].offset
+            if z is not None and z.requires_grad:
+                def _hook(g, off=off):
+                    if self._early is None:
+                        self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True))
+                    return g
+                z.register_hook(_hook)
         loss.backward()
         self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
@@ -83,9 +96,15 @@ class Trainer:
         rank, W = parallel.world()
         sparse = self.engine.sparse
         if W > 1:
-            work = parallel.allreduce_dense_(self.store.grads, async_op=True)
+            early, self._early = getattr(self, "_early", None), None
+            self.early_allreduce_used = early is not None
+            if early is not None:
+                works = [early[1], parallel.allreduce_dense_(self.store.grads[: early[0]], async_op=True)]
+            else:
+                works = [parallel.allreduce_dense_(self.store.grads, async_op=True)]
             sparse = self.merge_sparse(sparse)
-            work.wait()
+            for w in works:
+                w.wait()
             loss = parallel.mean_scalar(loss)
         self.opt.step(sparse, grad_scale=1.0 / W)
         return loss

@@ -35,6 +35,7 @@ def _worker(rank, world, port, q, steps, bf16=False):
     for s in range(steps):
         inputs, mask, _ = make_batch(sp, 6, seed=700 + 10 * s + rank, lengths="ragged", weights="random")
         losses.append(float(tr.train_step(tr.make_batch(inputs, mask))))
+    assert tr.early_allreduce_used          # the MMoE / tower slice was reduced from the dL/dz hook, during backward
     tr.opt.flush_tables()
     torch.cuda.synchronize()
     q.put((rank, losses, tr.store.state_dict()))
