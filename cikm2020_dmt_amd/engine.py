@@ -300,8 +300,8 @@ class DMTEngine:
         """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "self-attention/"
-        qkv = ops.linear(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"))
-        s1 = ops.AttnFn.apply(qkv, None, x, lens, lens, H, d, True, *self._attn_drop(stream))
+        s1 = ops.SelfAttnBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"), lens, H,
+                                       *self._attn_drop(stream))
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
     def mha_cross(self, q_in, mem, q_lens, k_lens, blk, stream=3):

@@ -376,6 +376,50 @@ class AttnFn(torch.autograd.Function):
         return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None
 
 
+class SelfAttnBlockFn(torch.autograd.Function):
+    """s = concat_h softmax(mask(QK^T/sqrt(dh))) V + x  with (Q|K|V) = x Wqkv + b: multihead_attention(x, x, x) before its LayerNorm
+    (TransformerModel_util.py:160-207) as ONE autograd node, so that dx = dqkv Wqkv^T + ds leaves the input-gradient GEMM's epilogue
+    (as two nodes autograd adds the residual gradient in a separate pass over [B, T, d])."""
+
+    @staticmethod
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, lens, H, drop_seed, drop_keep):
+        _chk3(x, "x")
+        B, T, d = x.shape
+        x2 = x.reshape(-1, d)
+        qkv = linear_forward(x2, w, b_leaf).reshape(B, T, 3 * d)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        out = torch.empty((B, T, d), dtype=x.dtype, device=x.device)
+        desc = _attn_desc(x.dtype, B, H, d // H, T, T, q, k, v, lens, lens, x, out)
+        desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
+        L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+        ctx.save_for_backward(x2, qkv, lens)
+        ctx.w, ctx.leaves, ctx.H, ctx.drop = w, (w_leaf, b_leaf), H, (int(drop_seed), float(drop_keep))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, qkv, lens = ctx.saved_tensors
+        B, T, d3 = qkv.shape
+        d = d3 // 3
+        if dout.stride(2) != 1 or dout.stride(1) != d:
+            dout = dout.contiguous()
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+        bd = L.AttnBwdDesc()
+        bd.f = _attn_desc(q.dtype, B, ctx.H, d // ctx.H, T, T, q, k, v, lens, lens, None, None)
+        bd.f.drop_seed, bd.f.drop_keep = ctx.drop
+        bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
+        bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
+        bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
+        bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
+        L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+        dz = dqkv.reshape(-1, d3)
+        dx = linear_backward_input(dz, ctx.w, resid=dout.reshape(-1, d)).reshape(B, T, d) if ctx.needs_input_grad[0] else None
+        dW, db = linear_backward_weight(x2, dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
+        return dx, dW, db, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 class LNFn(torch.autograd.Function):
     @staticmethod
