@@ -354,14 +354,11 @@ class DMTEngine:
         K = self.plan.K
         g1 = ops.linear(z[:, :K], self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
                         self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0])
-        outs = []
-        for e in range(E):
-            h = g1[:, e * units[0]:(e + 1) * units[0]]
-            for li in range(1, len(units)):
-                nm = "mmoe_layers/expert-%d/expert-layer-%d/" % (e, li)
-                h = ops.linear(h, self._lf(nm + "weights"), self._lf(nm + "biases"), self._w(nm + "weights"), relu=True)
-            outs.append(h)
-        expert = torch.cat(outs, dim=1)
+        expert = g1[:, : E * units[0]]          # [B, E * u0]: the four experts' layer-0 outputs side by side
+        for li in range(1, len(units)):
+            nms = ["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)]
+            expert = ops.expert_layer(expert, [self._w(n + "weights") for n in nms], [self._lf(n + "weights") for n in nms],
+                                      [self._lf(n + "biases") for n in nms])
         glogit = g1[:, E * units[0]: E * units[0] + T * E]
         mix, gates = ops.MixFn.apply(expert, glogit, E, units[-1], T)
         self.intermediates["gates"] = gates

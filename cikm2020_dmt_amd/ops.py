@@ -238,6 +238,90 @@ def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=N
     return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype)
 
 
+def _uniform_stride(ts):
+    """Element distance between consecutive tensors of a list if it is the same for all (same dtype/shape/strides), else None."""
+    if len(ts) == 1:
+        return 0
+    esz = ts[0].element_size()
+    d0 = (ts[1].data_ptr() - ts[0].data_ptr())
+    for a, b in zip(ts[:-1], ts[1:]):
+        if b.data_ptr() - a.data_ptr() != d0 or a.shape != b.shape or a.stride() != b.stride() or a.dtype != b.dtype:
+            return None
+    return d0 // esz if d0 % esz == 0 and d0 > 0 else None
+
+
+class ExpertLayerFn(torch.autograd.Function):
+    """y[:, e*N:(e+1)*N] = relu(x[:, e*K:(e+1)*K] W_e + b_e) for all experts e in ONE batched GEMM (forward, input gradient and
+    weight gradient each): the expert-layer-li (li >= 1) dense_layer calls of expert_gate (mmoe_transformer.py:59-79), whose
+    per-expert launches (M = batch, N <= 256) are launch-latency bound."""
+
+    @staticmethod
+    def forward(ctx, x, ws, w_leaves, b_leaves):
+        E = len(ws)
+        M = x.shape[0]
+        K, N = ws[0].f32.shape
+        assert x.shape[1] == E * K
+        ldx = _row_major2d(x, "x")
+        y = torch.empty((M, E * N), dtype=x.dtype, device=x.device)
+        Bs = [w.lp_t for w in ws] if x.dtype == BF16 else [w.f32 for w in ws]
+        sb, sbias = _uniform_stride(Bs), _uniform_stride(list(b_leaves))
+        if sb is not None and sbias is not None:
+            if x.dtype == BF16:
+                gemm(x, ldx, 1, Bs[0], 1, Bs[0].stride(0), M, N, K, y, E * N, bias=b_leaves[0], act_ncols=N, batch=E, a_bs=K, b_bs=sb, c_bs=N,
+                     bias_bs=sbias)
+            else:
+                gemm(x, ldx, 1, Bs[0], Bs[0].stride(0), 1, M, N, K, y, E * N, bias=b_leaves[0], act_ncols=N, batch=E, a_bs=K, b_bs=sb, c_bs=N,
+                     bias_bs=sbias)
+        else:
+            for e in range(E):
+                linear_forward(x[:, e * K:(e + 1) * K], ws[e], b_leaves[e], act_ncols=N, out=y[:, e * N:(e + 1) * N])
+        ctx.ws, ctx.leaves = ws, (tuple(w_leaves), tuple(b_leaves))
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        ws, (w_leaves, b_leaves) = ctx.ws, ctx.leaves
+        E = len(ws)
+        M = x.shape[0]
+        K, N = ws[0].f32.shape
+        dz = dy.to(x.dtype) if dy.dtype != x.dtype else dy
+        dz = relu_bwd_(dz.clone() if dz.data_ptr() == dy.data_ptr() else dz, y, E * N)
+        ldx, ldz = _row_major2d(x, "x"), _row_major2d(dz, "dz")
+        # ---- dx_e = dz_e W_e^T
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, E * K), dtype=dz.dtype, device=dz.device)
+            Wm = [w.lp for w in ws] if dz.dtype == BF16 else [w.f32 for w in ws]
+            sw = _uniform_stride(Wm)
+            if sw is not None:
+                gemm(dz, ldz, 1, Wm[0], 1, Wm[0].stride(0), M, K, N, dx, E * K, batch=E, a_bs=N, b_bs=sw, c_bs=K)
+            else:
+                for e in range(E):
+                    linear_backward_input(dz[:, e * N:(e + 1) * N], ws[e], out=dx[:, e * K:(e + 1) * K])
+        # ---- dW_e += x_e^T dz_e, db_e += colsum(dz_e): straight into the gradient arena
+        gws = [_grad_view(l) for l in w_leaves]
+        gbs = [_grad_view(l) for l in b_leaves]
+        ok = all(g is not None for g in gws) and all(g is not None for g in gbs)
+        sg, sgb = (_uniform_stride(gws), _uniform_stride(gbs)) if ok else (None, None)
+        if sg is not None and sgb is not None:
+            rows = K + 1
+            tiles = E * ((rows + 127) // 128) * ((N + 127) // 128)
+            gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gws[0], gws[0].stride(0), ones_row=True, c_last=gbs[0], split_k=_pick_split(tiles, M),
+                 accumulate=True, batch=E, a_bs=K, b_bs=N, c_bs=sg, clast_bs=sgb)
+            return dx, None, None, None
+        outs = [linear_backward_weight(x[:, e * K:(e + 1) * K], dz[:, e * N:(e + 1) * N], want_bias=True, w_leaf=w_leaves[e], b_leaf=b_leaves[e])
+                for e in range(E)]
+        if any(o[0] is not None for o in outs):
+            raise RuntimeError("ExpertLayerFn: parameter leaves without an in-place gradient view are not supported")
+        return dx, None, None, None
+
+
+def expert_layer(x, ws, w_leaves, b_leaves):
+    return ExpertLayerFn.apply(x, list(ws), list(w_leaves), list(b_leaves))
+
+
 class FFNFn(torch.autograd.Function):
     """s = relu(x W1 + b1) W2 + b2 + x  (TransformerModel_util.py:222-230 before the LayerNorm)."""
 

@@ -183,6 +183,17 @@ class VariableStore:
         bf = self.compute_dtype == torch.bfloat16
         self.lp = torch.zeros(P, dtype=torch.bfloat16, device=dev) if bf else None
         self._w2d: List[str] = []
+        # the experts' layer-li weights (li >= 1) are multiplied as ONE batched GEMM: their transposed bf16 shadows live in one
+        # [E, N, Kpad] block (uniform batch stride); the fp32 / plain-bf16 leaves are already equally spaced in the arena
+        batched_t: Dict[str, torch.Tensor] = {}
+        if bf:
+            E_, units_ = self.spec["num_experts"], self.spec["hidden_units_bottom"]
+            for li in range(1, len(units_)):
+                kk, nn = units_[li - 1], units_[li]
+                kpad = (kk + 7) // 8 * 8
+                blk = torch.zeros((E_, nn, kpad), dtype=torch.bfloat16, device=dev)
+                for e in range(E_):
+                    batched_t["mmoe_layers/expert-%d/expert-layer-%d/weights" % (e, li)] = blk[e][:, :kk]
         for name, info in self.leaves.items():
             t = self.params[info.offset: info.offset + info.numel].view(info.shape).detach()
             t.requires_grad_(True)
@@ -192,7 +203,8 @@ class VariableStore:
                 lp = self.lp[info.offset: info.offset + info.numel].view(info.shape) if bf else None
                 # transposed shadow [N, K] with the row stride padded to 8 elements (16-byte rows for vector loads, e.g. K = 3047)
                 kpad = (info.shape[0] + 7) // 8 * 8
-                lp_t = torch.zeros((info.shape[1], kpad), dtype=torch.bfloat16, device=dev)[:, : info.shape[0]] if bf else None
+                lp_t = (batched_t[name] if name in batched_t else
+                        torch.zeros((info.shape[1], kpad), dtype=torch.bfloat16, device=dev)[:, : info.shape[0]]) if bf else None
                 self.weight[name] = Weight(t.detach(), lp, lp_t)
                 self._w2d.append(name)
         self.table: Dict[str, torch.Tensor] = {}
