@@ -212,11 +212,7 @@ __device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, 
   return u.v;
 }
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // hardware round-to-nearest-even pair conversion
-  unsigned r;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return dmt_pack_bf16(lo, hi); }
 
 constexpr float LOG2E = 1.44269504088896340736f;
 
@@ -470,7 +466,7 @@ __device__ __forceinline__ void store_rows_T(const f32x16_t (&o)[2], bf16_t* __r
 //   dQ^T = K^T dS^T                           (B = dS from registers, A = K^T from the LDS tile)
 //   dV^T = dO^T P,  dK^T = Q^T dS             (P, dS transposed through LDS as [key][q]; A = dO^T / Q^T from LDS tiles)
 template <int DH>
-__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(const AttnArgs a) {
   constexpr int NK = (DH + 15) / 16;
   constexpr int NDT = (DH + 31) / 32;
   constexpr int DHS = DH + 4;
@@ -481,13 +477,16 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
   const int b = (int)(wid / a.H), h = (int)(wid % a.H);
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
-  // three LDS regions; the [key][q] copies of P and dS reuse the K^T and dO^T regions once those are dead
+  // TWO LDS regions (20.7 KB per wave => 7 waves per CU): Tt holds ONE transposed operand tile at a time (K^T for dQ, then
+  // dO^T for dV, then Q^T for dK -- each is staged right before its product), PD holds P and later dS as [key][q].
   constexpr int REG = (DH > 64 ? DH : 64) * TLD;
-  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* dOt = Kt + REG;
-  bf16_t* Qt = dOt + REG;
-  bf16_t* PL = Kt;
-  bf16_t* DL = dOt;
+  bf16_t* Tt = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* PD = Tt + REG;
+  bf16_t* Kt = Tt;
+  bf16_t* dOt = Tt;
+  bf16_t* Qt = Tt;
+  bf16_t* PL = PD;
+  bf16_t* DL = PD;
 
   const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
   const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
@@ -495,21 +494,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
   const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
 
   stage_transposed<DH>(Kt, Kg, a.k_rs, Tk, lane);
-  stage_transposed<DH>(dOt, dOg, a.do_rs, Tq, lane);
-  stage_transposed<DH>(Qt, Qg, a.q_rs, Tq, lane);
 
-  // K / V row fragments of both key tiles stay in registers across the two query tiles
-  bf16x8_t aK[2][NK], aV[2][NK];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = t * 32 + l31;
-#pragma unroll
-    for (int s2 = 0; s2 < NK; ++s2) {
-      const int j0 = s2 * 16 + 8 * half;
-      aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
-      aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
-    }
-  }
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
@@ -527,6 +512,18 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[kt][r] = 0.f; dp[kt][r] = 0.f; }
     {
+      // K / V row fragments are re-read per query tile (L1/L2 hits): keeping them live costs 80 registers and the second wave per SIMD
+      bf16x8_t aK[2][NK], aV[2][NK];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = t * 32 + l31;
+#pragma unroll
+        for (int s2 = 0; s2 < NK; ++s2) {
+          const int j0 = s2 * 16 + 8 * half;
+          aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
+          aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
+        }
+      }
       bf16x8_t bQ[NK], bD[NK];
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) {
@@ -627,10 +624,11 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     store_rows_T<DH>(o, dQg, a.dq_rs, dt, l31, half, Tq);
   }
 
-  // ---- dV^T = dO^T P   (reduction over queries, natural k slots).  P goes to LDS as [key][q] over the dead K^T tile.
+  // ---- dV^T = dO^T P   (reduction over queries, natural k slots).  dO^T replaces the dead K^T tile; P goes to LDS as [key][q].
   bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
   bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
   __builtin_amdgcn_wave_barrier();
+  stage_transposed<DH>(dOt, dOg, a.do_rs, Tq, lane);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -656,8 +654,9 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const AttnArgs a) {
     }
     store_rows_T<DH>(ov, dVg, a.dv_rs, dt, l31, half, Tk);
   }
-  // ---- dK^T = Q^T dS.  dS goes to LDS as [key][q] over the dead dO^T tile.
+  // ---- dK^T = Q^T dS.  Q^T replaces the dead dO^T tile; dS replaces P.
   __builtin_amdgcn_wave_barrier();
+  stage_transposed<DH>(Qt, Qg, a.q_rs, Tq, lane);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -1151,7 +1150,7 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
                          al8(d->dout, d->do_bs, d->do_rs) && al8(d->dQ, d->dq_bs, d->dq_rs) && al8(d->dK, d->dk_bs, d->dk_rs) &&
                          al8(d->dV, d->dv_bs, d->dv_rs);
     if (mfma_ok) {
-      const size_t ldsm = (size_t)3 * (f.dh > 64 ? f.dh : 64) * 72 * 2;
+      const size_t ldsm = ((size_t)(f.dh > 64 ? f.dh : 64) * 72 + 64 * 72) * 2;   // one transposed tile + one [key][q] tile
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
       switch (f.dh) {
         case 16: hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), dim3(nbm), dim3(64), ldsm, st, a); break;

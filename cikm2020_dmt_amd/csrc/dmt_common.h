@@ -36,6 +36,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed pair of bf16 (round to nearest even): compiles to ONE v_cvt_pk_bf16_f32 that hipcc schedules itself
+// (an inline-asm cvt feeding an MFMA / LDS store needs hand-placed wait states: wrong results were seen under register pressure)
+typedef __bf16 dmt_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float dmt_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dmt_pack_bf16(float lo, float hi) {
+  const dmt_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dmt_bf16x2_t));
+}
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }

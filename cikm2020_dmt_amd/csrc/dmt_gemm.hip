@@ -222,11 +222,7 @@ __device__ __forceinline__ void patch_ones_row(Vec16 (&reg)[Cfg<T>::NV], int row
   }
 }
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) { return dmt_pack_bf16(lo, hi); }
 
 // packed pair of bf16: relu (as int16 a bf16 is negative exactly when its sign bit is set) ...
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
