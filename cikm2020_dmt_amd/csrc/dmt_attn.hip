@@ -28,6 +28,7 @@ struct AttnArgs {
   unsigned drop_seed, drop_thr;
   float drop_inv;
   int drop_on;
+  int vec16;   // bf16 MFMA path: every operand row is 16-byte aligned and dh % 8 == 0
 };
 
 __device__ __forceinline__ float drop_factor(const AttnArgs& a, int b, int h, int q, int key) {
@@ -201,10 +202,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnArgs a) {
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-__device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, int j0, bool row_ok, int dh) {
-  union { bf16x8_t v; uint2 h[2]; } u;
+__device__ __forceinline__ bf16x8_t load_frag8(const bf16_t* __restrict__ rowp, int j0, bool row_ok, int dh, bool vec16 = false) {
+  union { bf16x8_t v; uint2 h[2]; uint4 q; } u;
   u.h[0] = make_uint2(0u, 0u);
   u.h[1] = make_uint2(0u, 0u);
+  if (vec16) {   // wave-uniform: dh % 8 == 0 and 16-byte aligned rows -> one request per lane instead of two
+    if (row_ok && j0 + 8 <= dh) u.q = *reinterpret_cast<const uint4*>(rowp + j0);
+    return u.v;
+  }
   if (row_ok) {
     if (j0 + 4 <= dh) u.h[0] = *reinterpret_cast<const uint2*>(rowp + j0);
     if (j0 + 8 <= dh) u.h[1] = *reinterpret_cast<const uint2*>(rowp + j0 + 4);
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) {
         const int j0 = s2 * 16 + 8 * half;
-        aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
-        bQ[t][s2] = load_frag8(Qg + (long long)row * a.q_rs, j0, row < Tq, DH);
+        aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH, a.vec16 != 0);
+        bQ[t][s2] = load_frag8(Qg + (long long)row * a.q_rs, j0, row < Tq, DH, a.vec16 != 0);
       }
     }
 #pragma unroll
@@ -520,16 +525,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int s2 = 0; s2 < NK; ++s2) {
           const int j0 = s2 * 16 + 8 * half;
-          aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH);
-          aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH);
+          aK[t][s2] = load_frag8(Kg + (long long)row * a.k_rs, j0, row < Tk, DH, a.vec16 != 0);
+          aV[t][s2] = load_frag8(Vg + (long long)row * a.v_rs, j0, row < Tk, DH, a.vec16 != 0);
         }
       }
       bf16x8_t bQ[NK], bD[NK];
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) {
         const int j0 = s2 * 16 + 8 * half;
-        bQ[s2] = load_frag8(Qg + (long long)q * a.q_rs, j0, q < Tq, DH);
-        bD[s2] = load_frag8(dOg + (long long)q * a.do_rs, j0, q < Tq, DH);
+        bQ[s2] = load_frag8(Qg + (long long)q * a.q_rs, j0, q < Tq, DH, a.vec16 != 0);
+        bD[s2] = load_frag8(dOg + (long long)q * a.do_rs, j0, q < Tq, DH, a.vec16 != 0);
       }
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2)
@@ -1025,6 +1030,7 @@ int fill_args(AttnArgs& a, const dmt_attn_desc* d) {
   a.drop_thr = a.drop_on ? (unsigned)(d->drop_keep * 16777216.0f) : 0u;
   a.drop_inv = a.drop_on ? 1.f / d->drop_keep : 1.f;
   a.dout = nullptr; a.dQ = a.dK = a.dV = nullptr;
+  a.vec16 = 0;
   a.do_bs = a.do_rs = a.dq_bs = a.dq_rs = a.dk_bs = a.dk_rs = a.dv_bs = a.dv_rs = 0;
   return 0;
 }
@@ -1091,6 +1097,7 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
                        al8(d->Q, d->q_bs, d->q_rs) && al8(d->K, d->k_bs, d->k_rs) && al8(d->V, d->v_bs, d->v_rs) &&
                        al8(d->resid, d->r_bs, d->r_rs) && al8(d->out, d->o_bs, d->o_rs);
   if (mfma_ok) {
+    a.vec16 = (d->dh % 8 == 0 && q1v_aligned(d->Q, d->q_bs, d->q_rs) && q1v_aligned(d->K, d->k_bs, d->k_rs) && q1v_aligned(d->V, d->v_bs, d->v_rs)) ? 1 : 0;
     const int nwm = 4;
     const size_t ldsm = (size_t)nwm * d->dh * 72 * 2;
     const unsigned nb = (unsigned)cdiv64((long long)d->B * d->H, nwm);
@@ -1150,6 +1157,8 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
                          al8(d->dout, d->do_bs, d->do_rs) && al8(d->dQ, d->dq_bs, d->dq_rs) && al8(d->dK, d->dk_bs, d->dk_rs) &&
                          al8(d->dV, d->dv_bs, d->dv_rs);
     if (mfma_ok) {
+      a.vec16 = (f.dh % 8 == 0 && q1v_aligned(f.Q, f.q_bs, f.q_rs) && q1v_aligned(f.K, f.k_bs, f.k_rs) && q1v_aligned(f.V, f.v_bs, f.v_rs) &&
+                 q1v_aligned(d->dout, d->do_bs, d->do_rs)) ? 1 : 0;
       const size_t ldsm = ((size_t)(f.dh > 64 ? f.dh : 64) * 72 + 64 * 72) * 2;   // one transposed tile + one [key][q] tile
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
       switch (f.dh) {
