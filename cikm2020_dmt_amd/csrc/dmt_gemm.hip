@@ -583,7 +583,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 //   * the whole bias vector (N <= 2048) is put in LDS once per (persistent) workgroup.
 // Tried and rejected (measured on the 204800-row shapes): a 256 x 128 tile with 8 waves and THREE DMA stages (two k-steps in
 // flight, 25 % less operand traffic per FLOP) is 5-20 % slower -- the k-step is not DMA-latency bound; hand-ordered fragment
-// double buffering in compute() is re-scheduled by hipcc and changes nothing.
+// double buffering in compute() is re-scheduled by hipcc and changes nothing; 8 waves per 128 x 128 tile (32 x 64 per wave, 4 waves
+// per SIMD at 127 VGPRs) is equal or slower too (0.296 / 0.265 / 0.197 ms): the extra fragment reads per MFMA cancel the extra
+// latency hiding.  Counters for this kernel (profiles/r01d_*): MFMA busy 31 %, LDS active 28 %, waves 40 % in waitcnt/barrier and
+// 32 % in issue stalls.
 constexpr int GL_STAGE_BYTES = 34816;   // A tile 16 KB | B tile 16 KB | 2 KB slack: = 4 waves x [32][68] fp32 of epilogue staging
 constexpr int GL_MAX_N = 2048;
 constexpr int GL_SMEM = 2 * GL_STAGE_BYTES + GL_MAX_N * 4;
