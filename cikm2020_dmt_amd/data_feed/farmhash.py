@@ -4,7 +4,7 @@ tf.contrib.lookup.index_table_from_tensor(num_oov_buckets=...) uses for out-of-v
 
 Third-party algorithm restated from Google FarmHash (farmhash.cc, namespace farmhashna), the version vendored by
 tensorflow==1.12; TensorFlow is absent here, so this is pinned only by FarmHash's structural constants and the
-documented example tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) == [2, 0, 1]
+documented example tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) == [0, 2, 2]
 (tests/test_host.py).
 """
 from __future__ import annotations

@@ -62,6 +62,28 @@ class DeviceBatch:
         lb = torch.as_tensor(np.asarray(label, dtype=np.float32)).to(device) if label is not None else None
         return DeviceBatch(B, feats, dense, m, lb)
 
+    @staticmethod
+    def from_columns(cols: dict, spec: dict, device) -> "DeviceBatch":
+        """cols: the output of data_feed.native.BatchParser.parse (libdmt_input.so): per id feature f  f -> int32 [B,T],
+        f+'Wts' -> float32 [B,T], f+'/lens' -> int32 [B];  'features' [B,F], 'mask' [B,5], 'label' [B,1].
+        Same batch as from_inputs(..., pad_to=T): the weights column is dropped when every weight is 1 (unweighted mean)."""
+        dense = torch.as_tensor(cols["features"]).to(device, non_blocking=True)
+        B = dense.shape[0]
+        names = [f for (_n, _r, _d, f, _s) in spec["embedding_list"]] + [f for (_n, _r, _d, f, _s) in spec["embedding_list_bias"]]
+        feats = {}
+        for f in dict.fromkeys(names):
+            idx, lens, w = cols[f], cols[f + "/lens"], cols.get(f + "Wts")
+            T = idx.shape[1]
+            wts = None
+            if w is not None:
+                valid = np.arange(T)[None, :] < lens[:, None]
+                if valid.any() and not np.all(w[valid] == 1.0):
+                    wts = torch.as_tensor(w).to(device, non_blocking=True)
+            feats[f] = FeatureColumn(torch.as_tensor(idx).to(device, non_blocking=True), wts, torch.as_tensor(lens).to(device, non_blocking=True), T)
+        m = torch.as_tensor(cols["mask"]).to(device, non_blocking=True) if "mask" in cols else None
+        lb = torch.as_tensor(cols["label"][:, 0]).to(device, non_blocking=True) if "label" in cols else None
+        return DeviceBatch(B, feats, dense, m, lb)
+
 
 # ------------------------------------------------------------------------------------------------ gather
 class _GatherPlan:
