@@ -337,6 +337,11 @@ int parse_one(const ParseCtx& cx, const uint8_t* payload, uint64_t len, int b) {
           if (dst == nullptr) continue;
           const int rc = decode_float_list(lst, dst, T, n, F.name);
           if (rc != DMT_IN_OK) return rc;
+          if (it->is_wts && F.n_wts_not_one) {
+            int bad = 0;
+            for (int k = 0; k < n; ++k) bad += (dst[k] != 1.0f);
+            if (bad) __atomic_fetch_add(F.n_wts_not_one, bad, __ATOMIC_RELAXED);
+          }
           if (F.vocab == nullptr && n != T && n != 0)
             return fail(DMT_IN_ERR_RANGE, "float feature '%s' has %d values, expected %d (record %d)", F.name, n, T, b);
         }

@@ -29,7 +29,7 @@ class InputError(RuntimeError):
 
 class FeatureSpec(C.Structure):
     _fields_ = [("name", C.c_char_p), ("vocab", C.c_void_p), ("max_len", C.c_int32), ("idx", C.c_void_p), ("wts", C.c_void_p),
-                ("lens", C.c_void_p), ("dense", C.c_void_p)]
+                ("lens", C.c_void_p), ("dense", C.c_void_p), ("n_wts_not_one", C.c_void_p)]
 
 
 def load():
@@ -131,24 +131,50 @@ class BatchParser:
         self.id_features = list(id_features)
         self.float_features = list(float_features)
         self.n_threads = n_threads if n_threads > 0 else min(os.cpu_count() or 1, 16)
+        self.pinned = False      # set True to get the batch columns in one page-locked buffer (DeviceBatch.from_columns uploads it once)
         self._lib = load()
 
     def _alloc(self, B: int):
+        """All output columns of a batch in ONE host buffer (pinned when torch + a GPU are present, so the batch goes up in a single
+        asynchronous copy): layout[name] = (byte offset, dtype, shape).  `out` holds numpy views into it."""
+        layout, off = {}, 0
+
+        def add(name, dtype, shape):
+            nonlocal off
+            off = (off + 63) // 64 * 64
+            layout[name] = (off, dtype, shape)
+            off += int(np.prod(shape)) * np.dtype(dtype).itemsize
+
+        for (name, _v, T) in self.id_features:
+            add(name, np.int32, (B, T)); add(name + "Wts", np.float32, (B, T)); add(name + "/lens", np.int32, (B,))
+        add("__wts_not_one__", np.int32, (len(self.id_features),))
+        for (name, n) in self.float_features:
+            add(name, np.float32, (B, n))
+        total = (off + 63) // 64 * 64
+        tbuf = None
+        if self.pinned:
+            import torch
+            tbuf = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            raw = tbuf.numpy()
+        else:
+            raw = np.empty(total, np.uint8)
         out: Dict[str, np.ndarray] = {}
+        for name, (o, dt, shape) in layout.items():
+            out[name] = raw[o:o + int(np.prod(shape)) * np.dtype(dt).itemsize].view(dt).reshape(shape)
+        out["__wts_not_one__"][:] = 0
         specs = (FeatureSpec * (len(self.id_features) + len(self.float_features)))()
         keep = []
+        cnt = out["__wts_not_one__"]
         for i, (name, vocab, T) in enumerate(self.id_features):
-            idx = np.empty((B, T), np.int32); wts = np.empty((B, T), np.float32); lens = np.empty((B,), np.int32)
-            out[name], out[name + "Wts"], out[name + "/lens"] = idx, wts, lens
             nm = name.encode()
             keep.append(nm)
-            specs[i] = FeatureSpec(nm, vocab._h, T, idx.ctypes.data, wts.ctypes.data, lens.ctypes.data, None)
+            specs[i] = FeatureSpec(nm, vocab._h, T, out[name].ctypes.data, out[name + "Wts"].ctypes.data, out[name + "/lens"].ctypes.data, None,
+                                   cnt.ctypes.data + 4 * i)
         for j, (name, n) in enumerate(self.float_features):
-            d = np.empty((B, n), np.float32)
-            out[name] = d
             nm = name.encode()
             keep.append(nm)
-            specs[len(self.id_features) + j] = FeatureSpec(nm, None, n, None, None, None, d.ctypes.data)
+            specs[len(self.id_features) + j] = FeatureSpec(nm, None, n, None, None, None, out[name].ctypes.data, None)
+        out["__buffer__"] = (tbuf if tbuf is not None else raw, layout, [f for (f, _v, _t) in self.id_features])
         return out, specs, keep
 
     def parse(self, payloads: List[bytes]) -> Dict[str, np.ndarray]:
@@ -174,7 +200,7 @@ class BatchParser:
                         break
                     if n < batch_size:
                         if not drop_remainder:
-                            yield {k: v[:n] for k, v in out.items()}
+                            yield {k: (v[:n] if isinstance(v, np.ndarray) and not k.startswith("__") else v) for k, v in out.items() if k != "__buffer__"}
                         break
                     yield out
             finally:

@@ -67,9 +67,31 @@ class DeviceBatch:
         """cols: the output of data_feed.native.BatchParser.parse (libdmt_input.so): per id feature f  f -> int32 [B,T],
         f+'Wts' -> float32 [B,T], f+'/lens' -> int32 [B];  'features' [B,F], 'mask' [B,5], 'label' [B,1].
         Same batch as from_inputs(..., pad_to=T): the weights column is dropped when every weight is 1 (unweighted mean)."""
+        names = [f for (_n, _r, _d, f, _s) in spec["embedding_list"]] + [f for (_n, _r, _d, f, _s) in spec["embedding_list_bias"]]
+        packed = cols.get("__buffer__")
+        if packed is not None and isinstance(packed[0], torch.Tensor):
+            # one (asynchronous, page-locked) upload of the whole batch; the columns are views of the device copy
+            hbuf, layout, id_feats = packed
+            dbuf = hbuf.to(device, non_blocking=True)
+            tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
+
+            def view(name):
+                o, dt, shape = layout[name]
+                n = int(np.prod(shape)) * np.dtype(dt).itemsize
+                return dbuf[o:o + n].view(tdt[np.dtype(dt)]).view(*shape)
+
+            not_one = cols["__wts_not_one__"]
+            feats = {}
+            for f in dict.fromkeys(names):
+                T = layout[f][2][1]
+                wts = view(f + "Wts") if int(not_one[id_feats.index(f)]) != 0 else None
+                feats[f] = FeatureColumn(view(f), wts, view(f + "/lens"), T)
+            dense = view("features")
+            m = view("mask") if "mask" in layout else None
+            lb = view("label")[:, 0] if "label" in layout else None
+            return DeviceBatch(dense.shape[0], feats, dense, m, lb)
         dense = torch.as_tensor(cols["features"]).to(device, non_blocking=True)
         B = dense.shape[0]
-        names = [f for (_n, _r, _d, f, _s) in spec["embedding_list"]] + [f for (_n, _r, _d, f, _s) in spec["embedding_list_bias"]]
         feats = {}
         for f in dict.fromkeys(names):
             idx, lens, w = cols[f], cols[f + "/lens"], cols.get(f + "Wts")

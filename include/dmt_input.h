@@ -68,6 +68,8 @@ typedef struct {
   float* wts;      /* [B, max_len] or NULL */
   int32_t* lens;   /* [B] */
   float* dense;    /* [B, max_len] (float features) */
+  int32_t* n_wts_not_one;   /* optional: incremented (atomically) by the number of parsed weights != 1.0 -- 0 at the end means the
+                               feature is an unweighted mean and the caller may drop the weights column */
 } dmt_feature_spec;
 
 int dmt_parse_batch(const uint8_t* const* payloads, const uint64_t* payload_lens, int32_t B, const dmt_feature_spec* feats,

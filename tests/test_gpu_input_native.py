@@ -1,0 +1,59 @@
+"""Records on disk -> libdmt_input.so -> DeviceBatch.from_columns -> HIP forward: bit-identical to the in-memory batch."""
+import numpy as np
+import pytest
+import torch
+
+from cikm2020_dmt_amd.data_feed import native, tfrecord
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from cikm2020_dmt_amd.engine import DeviceBatch
+from cikm2020_dmt_amd.train import Trainer
+from tests.util import small_specs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_from_native_parsed_records_is_bit_identical(cuda, tmp_path):
+    _so, sp = small_specs()
+    B = 24
+    inputs, mask, label = make_batch(sp, B, seed=21, lengths="ragged", weights="random")
+    emb = list(sp["embedding_list"]) + list(sp["embedding_list_bias"])
+    feats = list(dict.fromkeys(e[3] for e in emb))
+    name_of = {e[3]: e[0] for e in reversed(emb)}
+    vocabs = {}
+    for (name, rows, _d, _f, _s) in emb:
+        vocabs.setdefault(name, native.Vocab(["k%d" % i for i in range(rows)], rows))
+    rows_of = {f: inputs[f].rows() for f in feats}
+    wrows_of = {f: inputs[f + "Wts"].rows() for f in feats}
+    recs = []
+    for b in range(B):
+        ex = {"features": inputs["features"][b].astype(np.float32), "mask": mask[b].astype(np.float32), "label": np.array([label[b]], np.float32)}
+        for f in feats:
+            ex[f] = [("k%d" % int(i)).encode() for i in rows_of[f][b]]
+            ex[f + "Wts"] = np.asarray(wrows_of[f][b], np.float32)
+        recs.append(tfrecord.encode_example(ex))
+    path = str(tmp_path / "part-r-00000")
+    tfrecord.write_records(path, recs)
+    max_lens = {f: max(int(inputs[f].dense_shape[1]), 1) for f in feats}
+    parser = native.BatchParser([(f, vocabs[name_of[f]], max_lens[f]) for f in feats], [("features", sp["feature_dimension"]), ("mask", 5), ("label", 1)], n_threads=2)
+    batches = list(parser.batches([path], B))
+    assert len(batches) == 1
+    parser.pinned = True                                  # packed page-locked buffer, single upload, device-side views
+    batches_p = list(parser.batches([path], B))
+    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=3)
+    b_nat = DeviceBatch.from_columns(batches[0], sp, cuda)
+    b_ref = tr.make_batch(inputs, mask, label, pad_to=max_lens)
+    tr.sync_rows(b_ref)
+    (c1, o1), y1 = tr.engine.inference(b_ref)
+    tr.sync_rows(b_nat)
+    (c2, o2), y2 = tr.engine.inference(b_nat)
+    assert torch.equal(c1, c2) and torch.equal(o1, o2) and torch.equal(y1, y2)
+    assert torch.equal(b_nat.mask, b_ref.mask) and torch.equal(b_nat.label, b_ref.label)
+    b_pin = DeviceBatch.from_columns(batches_p[0], sp, cuda)
+    for f in b_nat.feats:
+        a, p = b_nat.feats[f], b_pin.feats[f]
+        assert torch.equal(a.idx, p.idx) and torch.equal(a.lens, p.lens) and (a.wts is None) == (p.wts is None), f
+        if a.wts is not None:
+            assert torch.equal(a.wts, p.wts), f
+    tr.sync_rows(b_pin)
+    (c3, o3), y3 = tr.engine.inference(b_pin)
+    assert torch.equal(c1, c3) and torch.equal(o1, o3) and torch.equal(y1, y3)
