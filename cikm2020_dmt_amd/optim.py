@@ -84,6 +84,18 @@ class TFAdam:
                ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps,
                ops.stream_ptr())
 
+    def reset_slots(self, global_step: int = 0):
+        """What restoring a reference checkpoint leaves behind: tf.train.Saver(var_list=trainable_variables()) (run_dnn.py:258-261)
+        stores neither the Adam slots nor beta1_power/beta2_power, so a resumed run starts them from their initial values while
+        global_step (parsed from the checkpoint name, run_dnn.py:119-122) keeps driving the learning-rate schedule."""
+        s = self.store
+        for t in (s.adam_m, s.adam_v, s.tab_m, s.tab_v, s.last_step, self.lr_hist):
+            t.zero_()
+        self.state.zero_()
+        self.state[0], self.state[1] = self.b1, self.b2
+        self.global_step = int(global_step)
+        self._step_base = int(global_step)
+
     def flush_tables(self):
         """Replay pending zero-gradient updates on every table row (before checkpoint / full-table export)."""
         s = self.store
