@@ -276,20 +276,10 @@ __device__ __forceinline__ bf16x8_t frag_T_rows(const bf16_t* __restrict__ Xt, i
   return *reinterpret_cast<const bf16x8_t*>(Xt + j * TLD + 16 * u + 8 * half);
 }
 
-// (legacy) A fragment from a NATURAL [64][DHS] tile, 2-byte reads: element i = tile[16u + (i&3) + 8(i>>2) + 4*half][j]
-template <int DHS>
-__device__ __forceinline__ bf16x8_t lds_frag_keyslots(const bf16_t* __restrict__ tile, int u, int half, int j) {
-  union { bf16x8_t v; bf16_t e[8]; } f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) f.e[i] = tile[(16 * u + (i & 3) + 8 * (i >> 2) + 4 * half) * DHS + j];
-  return f.v;
-}
-
 template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   constexpr int NK = (DH + 15) / 16;
   constexpr int NDT = (DH + 31) / 32;
-  constexpr int DHS = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -436,15 +426,6 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   }
 }
 
-// A fragment with NATURAL k slots from a [64][DHS] tile: element i = tile[16u + 8*half + i][j]
-template <int DHS>
-__device__ __forceinline__ bf16x8_t lds_frag_rows(const bf16_t* __restrict__ tile, int u, int half, int j) {
-  union { bf16x8_t v; bf16_t e[8]; } f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) f.e[i] = tile[(16 * u + 8 * half + i) * DHS + j];
-  return f.v;
-}
-
 // Store an O^T-style accumulator pair (rows = head-dim in registers, column = lane's row of the output matrix).
 template <int DH>
 __device__ __forceinline__ void store_rows_T(const f32x16_t (&o)[2], bf16_t* __restrict__ base, long long rs, int dt, int l31,
@@ -474,7 +455,6 @@ template <int DH>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_mfma_kernel(const AttnArgs a) {
   constexpr int NK = (DH + 15) / 16;
   constexpr int NDT = (DH + 31) / 32;
-  constexpr int DHS = DH + 4;
   constexpr int PLD = 72;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
