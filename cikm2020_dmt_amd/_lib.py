@@ -64,6 +64,11 @@ class AttnBwdDesc(C.Structure):
                 ("dv_rs", c_i64)]
 
 
+class CastJob(C.Structure):
+    _fields_ = [("src", c_vp), ("dst_plain", c_vp), ("dst_t", c_vp), ("ld_src", c_i64), ("ld_plain", c_i64), ("ld_t", c_i64),
+                ("rows", c_i32), ("cols", c_i32), ("tile_begin", c_i32), ("tiles_x", c_i32)]
+
+
 class TableMap(C.Structure):
     _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
                 ("elem_off", c_i64 * DMT_MAX_TABLES)]
@@ -99,6 +104,7 @@ _SIGS = {
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "dmt_cast_transpose_bf16_batched": [c_i32, c_vp, c_i32, c_vp],
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],

@@ -24,6 +24,7 @@ extern "C" int dmt_struct_size(int which) {
     case 4: return (int)sizeof(dmt_attn_desc);
     case 5: return (int)sizeof(dmt_attn_bwd_desc);
     case 6: return (int)sizeof(dmt_table_map);
+    case 7: return (int)sizeof(dmt_cast_job);
     default: return -1;
   }
 }

@@ -437,6 +437,28 @@ __global__ __launch_bounds__(256) void colsum_drop_kernel(long long rows, long l
   atomicAdd(out + c, s * scale);
 }
 
+// bf16, cols % 8 == 0: one 16-byte load per lane per row, eight running sums, eight atomics at the end
+__global__ __launch_bounds__(256) void colsum_drop_v8_kernel(long long rows, long long cols, const bf16_t* __restrict__ x, float scale,
+                                                             float* __restrict__ out, int rows_per_block, uint32_t seed, uint32_t thr24) {
+  const long long c = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= cols) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long r = r0; r < r1; ++r) {
+    const uint4 v = *(const uint4*)(x + r * cols + c);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t base = (uint32_t)(r * cols + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
+      if (dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) atomicAdd(out + c + i, s[i] * scale);
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = f2bf(src[i]);
@@ -462,6 +484,36 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(int rows, int cols,
     for (int cc = ty; cc < 32; cc += 8) {
       const int c = c0 + cc, r = r0 + tx;
       if (r < rows && c < cols) dt[(long long)c * ldt + r] = tile[tx][cc];
+    }
+  }
+}
+
+// every 2-D weight of the model in ONE launch: block -> (job, 32x32 tile) through the jobs' tile prefix (n_jobs is a few dozen)
+__global__ __launch_bounds__(256) void cast_transpose_batched_kernel(int n_jobs, const dmt_cast_job* __restrict__ jobs) {
+  __shared__ bf16_t tile[32][33];
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].tile_begin) ++j;
+  const dmt_cast_job jb = jobs[j];
+  const int t = (int)blockIdx.x - jb.tile_begin;
+  const int c0 = (t % jb.tiles_x) * 32, r0 = (t / jb.tiles_x) * 32;
+  const float* __restrict__ src = jb.src;
+  bf16_t* __restrict__ dp = (bf16_t*)jb.dst_plain;
+  bf16_t* __restrict__ dt = (bf16_t*)jb.dst_t;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < jb.rows && c < jb.cols) {
+      v = f2bf(src[(long long)r * jb.ld_src + c]);
+      if (dp) dp[(long long)r * jb.ld_plain + c] = v;
+    }
+    tile[rr][tx] = v;
+  }
+  __syncthreads();
+  if (dt) {
+    for (int cc = ty; cc < 32; cc += 8) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (r < jb.rows && c < jb.cols) dt[(long long)c * jb.ld_t + r] = tile[tx][cc];
     }
   }
 }
@@ -662,6 +714,14 @@ extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const 
   DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum_drop: too many rows");
   const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_BF16 && cols % 8 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 256) {
+    const int rpb8 = 16;
+    dim3 g8((unsigned)cdiv64(cols / 8, 256), (unsigned)cdiv64(rows, rpb8));
+    DMT_CHECK_ARG(g8.y <= 65535, "dmt_colsum_drop: too many rows");
+    hipLaunchKernelGGL(colsum_drop_v8_kernel, g8, dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)x, scale / keep_prob, out, rpb8, seed, thr);
+    DMT_CHECK_LAUNCH("dmt_colsum_drop");
+    return DMT_OK;
+  }
   if (dtype == DMT_F32)
     hipLaunchKernelGGL((colsum_drop_kernel<float>), grid, dim3(256), 0, st, (long long)rows, (long long)cols, (const float*)x, scale / keep_prob, out, rpb, seed, thr);
   else
@@ -699,6 +759,13 @@ extern "C" int dmt_cast_transpose_bf16(int32_t rows, int32_t cols, const float* 
   hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, src, (long long)ld_src,
                      (bf16_t*)dst_plain, (long long)ld_plain, (bf16_t*)dst_t, (long long)ld_t);
   DMT_CHECK_LAUNCH("dmt_cast_transpose_bf16");
+  return DMT_OK;
+}
+
+extern "C" int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_job* jobs_dev, int32_t total_tiles, void* stream) {
+  DMT_CHECK_ARG(n_jobs > 0 && jobs_dev && total_tiles > 0, "dmt_cast_transpose_bf16_batched: bad argument");
+  hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, n_jobs, jobs_dev);
+  DMT_CHECK_LAUNCH("dmt_cast_transpose_bf16_batched");
   return DMT_OK;
 }
 

@@ -630,6 +630,28 @@ def cast_shadow(src_f32_2d, dst_plain, dst_t):
            dst_plain.stride(0) if dst_plain is not None else 0, p(dst_t), dst_t.stride(0) if dst_t is not None else 0, stream_ptr())
 
 
+def cast_shadow_jobs(triples, device):
+    """Device job table for cast_shadow_batched: triples of (fp32 master [K, N], bf16 plain or None, bf16 transposed or None)."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import CastJob
+    jobs = (CastJob * len(triples))()
+    tiles = 0
+    for j, (src, dp, dt) in enumerate(triples):
+        rows, cols = src.shape
+        tx, ty = (cols + 31) // 32, (rows + 31) // 32
+        jobs[j] = CastJob(p(src), p(dp), p(dt), src.stride(0), dp.stride(0) if dp is not None else 0,
+                          dt.stride(0) if dt is not None else 0, rows, cols, tiles, tx)
+        tiles += tx * ty
+    raw = np.frombuffer(C.string_at(C.addressof(jobs), C.sizeof(jobs)), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device), len(triples), tiles
+
+
+def cast_shadow_batched(table):
+    dev_jobs, n, tiles = table
+    L.call("dmt_cast_transpose_bf16_batched", n, p(dev_jobs), tiles, stream_ptr())
+
+
 def colsum(x2d, scale=1.0, out=None):
     rows, cols = x2d.shape
     if out is None:

@@ -254,9 +254,10 @@ class VariableStore:
         """fp32 masters -> bf16 plain + transposed shadows (after init / load / every optimizer step)."""
         if self.compute_dtype != torch.bfloat16:
             return
-        for name in self._w2d:
-            w = self.weight[name]
-            ops.cast_shadow(w.f32, w.lp, w.lp_t)
+        if getattr(self, "_cast_jobs", None) is None:
+            self._cast_jobs = ops.cast_shadow_jobs([(self.weight[n].f32, self.weight[n].lp, self.weight[n].lp_t) for n in self._w2d],
+                                                   self.device)
+        ops.cast_shadow_batched(self._cast_jobs)
 
     def zero_grad(self):
         self.grads.zero_()

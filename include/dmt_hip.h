@@ -315,6 +315,17 @@ int dmt_cast_bf16(int64_t n, const float* src, void* dst, void* stream);
 int dmt_cast_transpose_bf16(int32_t rows, int32_t cols, const float* src, int64_t ld_src, void* dst_plain,
                             int64_t ld_plain, void* dst_t, int64_t ld_t, void* stream);
 
+/* The same for every 2-D weight of the model in one launch (after each optimizer step): jobs_dev is a device array;
+ * job j owns the 32x32 tiles [tile_begin, tile_begin + tiles_x*tiles_y), total_tiles = sum over jobs.          */
+typedef struct dmt_cast_job {
+  const float* src;
+  void* dst_plain;   /* may be NULL */
+  void* dst_t;       /* may be NULL */
+  int64_t ld_src, ld_plain, ld_t;
+  int32_t rows, cols, tile_begin, tiles_x;
+} dmt_cast_job;
+int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_job* jobs_dev, int32_t total_tiles, void* stream);
+
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
 int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,

@@ -184,3 +184,46 @@ def test_rows_reduce_bf16_matches_fp32_reduce_of_rounded_rows(cuda):
     ref.index_add_(0, inv[valid], rows_lp.float()[order][valid])
     n_valid_rows = int((uniq < R).sum())
     assert torch.allclose(out[:n_valid_rows], ref[:n_valid_rows], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,dtype", [(512, 50 * 320, torch.bfloat16), (300, 10 * 24, torch.bfloat16), (64, 50 * 24, torch.float32)])
+def test_colsum_drop_equals_column_sum_of_dropped_gradient(cuda, rows, cols, dtype):
+    """Learned-position gradient under block-input dropout (TransformerModel.py:101 + TransformerModel_util.py:296-306):
+    sum_b (dX * mask / keep)[b, :] with the counter mask dmt_dropout applies for the same seed -- both the 16-byte and the
+    scalar kernel."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((rows, cols), generator=g).to(dtype).to(cuda)
+    seed, keep = 0x1234567, 0.9
+    dropped = torch.empty_like(x)
+    L.call("dmt_dropout", ops.dt_code(dtype), x.numel(), ops.p(x), ops.p(dropped), seed, keep, ops.stream_ptr())
+    mask = (dropped != 0) | (x == 0)
+    want = (x.double() * mask / keep).sum(0)
+    out = torch.zeros(cols, dtype=torch.float32, device=cuda)
+    L.call("dmt_colsum_drop", ops.dt_code(dtype), rows, cols, ops.p(x), 1.0, ops.p(out), seed, keep, ops.stream_ptr())
+    torch.cuda.synchronize()
+    assert 0.85 < mask.float().mean().item() < 0.95
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_batched_cast_transpose_equals_per_weight_casts(cuda):
+    """One launch for every 2-D weight (ragged shapes, padded transposed strides) == the per-weight kernel, bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(9)
+    shapes = [(3047, 72), (320, 960), (33, 31), (1, 5), (64, 64)]
+    triples, want = [], []
+    for i, (k, n) in enumerate(shapes):
+        src = torch.randn((k, n), generator=g).to(cuda)
+        kpad = (k + 7) // 8 * 8
+        dp = torch.zeros((k, n), dtype=torch.bfloat16, device=cuda) if i != 2 else None
+        dt = torch.zeros((n, kpad), dtype=torch.bfloat16, device=cuda)[:, :k] if i != 3 else None
+        triples.append((src, dp, dt))
+        want.append(src.to(torch.bfloat16))
+    table = ops.cast_shadow_jobs(triples, cuda)
+    ops.cast_shadow_batched(table)
+    torch.cuda.synchronize()
+    for (src, dp, dt), w in zip(triples, want):
+        if dp is not None:
+            assert torch.equal(dp, w)
+        if dt is not None:
+            assert torch.equal(dt, w.t())
