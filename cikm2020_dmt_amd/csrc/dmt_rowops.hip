@@ -437,26 +437,36 @@ __global__ __launch_bounds__(256) void colsum_drop_kernel(long long rows, long l
   atomicAdd(out + c, s * scale);
 }
 
-// bf16, cols % 8 == 0: one 16-byte load per lane per row, eight running sums, eight atomics at the end
+// bf16, cols % 8 == 0: a block owns 512 columns (64 lanes x 16 bytes); its 4 waves take interleaved rows, their partial sums
+// meet in LDS and leave as ONE atomic per column per block
 __global__ __launch_bounds__(256) void colsum_drop_v8_kernel(long long rows, long long cols, const bf16_t* __restrict__ x, float scale,
                                                              float* __restrict__ out, int rows_per_block, uint32_t seed, uint32_t thr24) {
-  const long long c = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
-  if (c >= cols) return;
+  __shared__ float part[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long c = ((long long)blockIdx.x * 64 + lane) * 8;
   const long long r0 = (long long)blockIdx.y * rows_per_block;
   const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long long r = r0; r < r1; ++r) {
-    const uint4 v = *(const uint4*)(x + r * cols + c);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t base = (uint32_t)(r * cols + c);
+  if (c < cols) {
+    for (long long r = r0 + wave; r < r1; r += 4) {
+      const uint4 v = *(const uint4*)(x + r * cols + c);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t base = (uint32_t)(r * cols + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
-      if (dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+      for (int i = 0; i < 4; ++i) {
+        if (dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
+        if (dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) atomicAdd(out + c + i, s[i] * scale);
+  for (int i = 0; i < 8; ++i) part[wave][i * 64 + lane] = s[i];     // [i][lane]: conflict-free
+  __syncthreads();
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int i = e >> 6, l = e & 63;
+    const long long cc = ((long long)blockIdx.x * 64 + l) * 8 + i;
+    if (cc < cols) atomicAdd(out + cc, (part[0][e] + part[1][e] + part[2][e] + part[3][e]) * scale);
+  }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
@@ -715,8 +725,8 @@ extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const 
   const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DMT_BF16 && cols % 8 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 256) {
-    const int rpb8 = 16;
-    dim3 g8((unsigned)cdiv64(cols / 8, 256), (unsigned)cdiv64(rows, rpb8));
+    const int rpb8 = 64;
+    dim3 g8((unsigned)cdiv64(cols / 8, 64), (unsigned)cdiv64(rows, rpb8));
     DMT_CHECK_ARG(g8.y <= 65535, "dmt_colsum_drop: too many rows");
     hipLaunchKernelGGL(colsum_drop_v8_kernel, g8, dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)x, scale / keep_prob, out, rpb8, seed, thr);
     DMT_CHECK_LAUNCH("dmt_colsum_drop");

@@ -206,6 +206,7 @@ class GatherFn(torch.autograd.Function):
             L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
         ctx.engine, ctx.batch, ctx.inv, ctx.seq_T = engine, batch, inv, seq_T
         ctx.pos_shapes = [tuple(pl.shape) for pl in pos_leaves]
+        ctx.pos_leaves = pos_leaves
         return (*X, tar, zbuf)
 
     @staticmethod
@@ -225,14 +226,17 @@ class GatherFn(torch.autograd.Function):
         # learned positions: dP[t] = sum_b dX[b, t]   (lookup by range(T), TransformerModel_util.py:296-306)
         dpos = []
         for s in range(n_seq):
-            g = torch.zeros(ctx.pos_shapes[s], dtype=F32, device=dev)
+            # accumulate straight into the position table's gradient arena when it is reachable (no zero-fill, no autograd add)
+            gv = ops._grad_view(ctx.pos_leaves[s])
+            direct = gv is not None and gv.is_contiguous() and tuple(gv.shape) == ctx.pos_shapes[s]
+            g = gv if direct else torch.zeros(ctx.pos_shapes[s], dtype=F32, device=dev)
             seeds, keep = ctx.drop
             if 0.0 < keep < 1.0:
                 L.call("dmt_colsum_drop", ops.dt_code(dX[s].dtype), B, ctx.seq_T[s] * d, ops.p(dX[s]), 1.0, ops.p(g), int(seeds[s]), float(keep),
                        ops.stream_ptr())
             else:
                 ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
-            dpos.append(g)
+            dpos.append(None if direct else g)
         engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz, ctx.drop)
         return (None, None, *dpos)
 

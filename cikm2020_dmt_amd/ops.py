@@ -518,6 +518,7 @@ class LNFn(torch.autograd.Function):
                p(stats), stream_ptr())
         ctx.save_for_backward(x2, gamma, stats)
         ctx.xshape = x.shape
+        ctx.gb = (gamma, beta)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -528,14 +529,19 @@ class LNFn(torch.autograd.Function):
         if dy2.stride(-1) != 1:
             dy2 = dy2.contiguous()
         dx = torch.empty((rows, d), dtype=x2.dtype, device=x2.device)
-        dg = torch.zeros((d,), dtype=F32, device=x2.device)
-        db = torch.zeros((d,), dtype=F32, device=x2.device)
+        # dgamma / dbeta are accumulated by the finish kernel: straight into the gradient arena when the parameters expose it
+        gg, gb = _grad_view(ctx.gb[0]), _grad_view(ctx.gb[1])
+        direct = gg is not None and gb is not None and gg.dim() == 1 and gb.dim() == 1
+        dg = gg if direct else torch.zeros((d,), dtype=F32, device=x2.device)
+        db = gb if direct else torch.zeros((d,), dtype=F32, device=x2.device)
         npart = L.load().dmt_ln_bwd_partials(rows)
         partials = torch.empty((npart, 2 * d), dtype=F32, device=x2.device)
         if dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype)
         L.call("dmt_ln_bwd", dt_code(x2.dtype), rows, d, p(x2), _row_major2d(x2, "x"), p(gamma), p(stats), p(dy2),
                _row_major2d(dy2, "dy"), p(dx), d, p(dg), p(db), p(partials), stream_ptr())
+        if direct:
+            return dx.reshape(ctx.xshape), None, None, None
         return dx.reshape(ctx.xshape), dg, db, None
 
 
