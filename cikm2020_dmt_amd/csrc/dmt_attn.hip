@@ -426,6 +426,230 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Coalesced variant of the forward kernel (dh % 8 == 0, 16-byte aligned rows).  The kernel above reads every operand row by
+// row PER LANE (64 lanes x 8/16 bytes from 64 different cache lines per instruction): rocprofv3 --pmc showed the vector memory
+// pipe saturated (TCP busy 96 %, TD busy 89 %, 16x more L1 line accesses than the bytes need) while HBM, VALU and MFMA idled.
+// Here every global access is a 16-byte chunk with consecutive lanes on consecutive chunks of a row (a head's row = dh*2
+// contiguous bytes), tiles go through ONE wave-private LDS region that is reused for Q, K, V and the output:
+//   Q, K : [64 rows][dh + 8]   16-byte fragment reads, rows 44 banks apart -> conflict free
+//   V    : [64 keys][RSV]      untransposed; the A operand V^T comes from ds_read_b64_tr_b16 (4 keys x 16 dims per 16 lanes)
+//   O    : [32 q][36] fp32 per (32 dims, query half) in a small second tile, read back as rows: residual add, one rounding,
+//          16-byte stores (64-byte runs per row)
+template <int DH> struct CoTile {
+  static constexpr int CH = DH / 8;                 // 16-byte chunks per row
+  static constexpr int RS = DH + 8;                 // Q / K row stride (elements)
+  static constexpr int rsv() { int r = (DH + 7) / 8 * 8; while (r % 128 != 32 && r % 128 != 96) r += 8; return r; }
+  static constexpr int RSV = rsv();                 // V row stride: 4 consecutive key rows x 64 B land in disjoint banks
+  static constexpr int RO = 36;                     // fp32 staging row stride of one [32 q][32 dims] output sub-tile
+  static constexpr int QKV_BYTES = ((64 * RS * 2 > 64 * RSV * 2 + 256 ? 64 * RS * 2 : 64 * RSV * 2 + 256) + 255) / 256 * 256;
+  static constexpr int BYTES = QKV_BYTES + 32 * RO * 4;   // + the output staging tile
+};
+
+template <int DH>
+__device__ __forceinline__ void co_load(uint4 (&buf)[DH / 8], const bf16_t* __restrict__ Xg, long long rs, int n_rows, int lane) {
+  constexpr int CH = DH / 8;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int item = lane + 64 * i, r = item / CH, c = item - r * CH;
+    buf[i] = (r < n_rows) ? *reinterpret_cast<const uint4*>(Xg + (long long)r * rs + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void co_store(const uint4 (&buf)[DH / 8], bf16_t* __restrict__ Xt, int row_stride, int lane) {
+  constexpr int CH = DH / 8;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int item = lane + 64 * i, r = item / CH, c = item - r * CH;
+    *reinterpret_cast<uint4*>(Xt + r * row_stride + c * 8) = buf[i];
+  }
+}
+// 16-byte MFMA fragment of row `row`, k = j0 .. j0+7 (zero past dh)
+template <int DH>
+__device__ __forceinline__ bf16x8_t co_frag(const bf16_t* __restrict__ Xt, int row, int j0) {
+  union { bf16x8_t v; uint4 q; } u;
+  u.q = make_uint4(0u, 0u, 0u, 0u);
+  if (j0 + 8 <= DH) u.v = *reinterpret_cast<const bf16x8_t*>(Xt + row * CoTile<DH>::RS + j0);
+  return u.v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_co_kernel(const AttnArgs a) {
+  typedef CoTile<DH> CT;
+  constexpr int NK = (DH + 15) / 16;
+  constexpr int NDT = (DH + 31) / 32;
+  constexpr int CH = CT::CH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const long long wid = (long long)blockIdx.x * nw + wave;
+  if (wid >= (long long)a.B * a.H) return;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int half = lane >> 5, l31 = lane & 31;
+  bf16_t* R = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(smem) + (size_t)wave * CT::BYTES);
+
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
+
+  uint4 gq[CH], gk[CH];
+  co_load<DH>(gq, Qg, a.q_rs, Tq, lane);
+  co_load<DH>(gk, Kg, a.k_rs, Tk, lane);
+
+  // ---- S^T = K Q^T
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  {
+    bf16x8_t bQ[2][NK];
+    co_store<DH>(gq, R, CT::RS, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) bQ[t][s2] = co_frag<DH>(R, t * 32 + l31, s2 * 16 + 8 * half);
+    __builtin_amdgcn_wave_barrier();
+    co_load<DH>(gq, Vg, a.v_rs, Tk, lane);          // V rides in Q's registers while K is consumed
+    co_store<DH>(gk, R, CT::RS, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2) {
+      const bf16x8_t k0 = co_frag<DH>(R, l31, s2 * 16 + 8 * half), k1 = co_frag<DH>(R, 32 + l31, s2 * 16 + 8 * half);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, bQ[0][s2], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, bQ[1][s2], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, bQ[0][s2], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, bQ[1][s2], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  co_store<DH>(gq, R, CT::RSV, lane);               // V tile (keys >= Tk zero filled: 0 * garbage must not make NaN)
+  // the residual pieces this lane adds in the epilogue (row = 32 qt + (item >> 2), dims dt*32 + 8 (item & 3)), requested now so
+  // that their latency hides behind the softmax
+  const bf16_t* Rg = a.resid ? reinterpret_cast<const bf16_t*>(a.resid) + (long long)b * a.r_bs + h * DH : nullptr;
+  uint4 rres[NDT][2][2];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int item = lane + 64 * i, q = qt * 32 + (item >> 2), j = dt * 32 + 8 * (item & 3);
+        rres[dt][qt][i] = (Rg && q < Tq && j + 8 <= DH) ? *reinterpret_cast<const uint4*>(Rg + (long long)q * a.r_rs + j) : make_uint4(0u, 0u, 0u, 0u);
+      }
+
+  // ---- masked softmax over keys, per query column (same arithmetic as attn_fwd_mfma_kernel)
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : Tq;
+  const float kscale = LOG2E / sqrtf((float)DH);
+  const int kl = klen - 4 * half, tk = Tk - 4 * half;
+  bf16x8_t pB[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + l31;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float x = acc[kt][qt][r] * kscale;
+        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+        x = (c >= tk) ? -3.0e38f : x;
+        acc[kt][qt][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);
+        acc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv_sum = __builtin_amdgcn_rcpf(sum);
+    const bool qpad = (q >= qlen);
+    const unsigned keep = drop_bits(a, b, h, q, half);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      union { bf16x8_t v; unsigned w[4]; } f;
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const int r0 = 8 * (u & 1) + i;
+        float p0 = acc[u >> 1][qt][r0] * inv_sum, p1 = acc[u >> 1][qt][r0 + 1] * inv_sum;
+        const int c0 = (u >> 1) * 32 + (r0 & 3) + 8 * (r0 >> 2);
+        if (qpad) {
+          p0 = (c0 < tk) ? PADDING_NUM : 0.f;
+          p1 = (c0 + 1 < tk) ? PADDING_NUM : 0.f;
+        }
+        if (a.drop_on) {
+          const int e0 = (u >> 1) * 16 + r0;
+          p0 = ((keep >> e0) & 1u) ? p0 * a.drop_inv : 0.f;
+          p1 = ((keep >> (e0 + 1)) & 1u) ? p1 * a.drop_inv : 0.f;
+        }
+        f.w[i >> 1] = pack_bf16(p0, p1);
+      }
+      pB[qt][u] = f.v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- O^T = V^T P^T per 32 output dims: A = V^T through transposing LDS reads (slot i of lane-half h <-> key
+  //      16u + (i&3) + 8(i>>2) + 4h); epilogue per query half: registers -> fp32 rows in LDS -> (+ residual) -> bf16 rows
+  bf16_t* Og = reinterpret_cast<bf16_t*>(a.out) + (long long)b * a.o_bs + h * DH;
+  float* Of = reinterpret_cast<float*>(reinterpret_cast<char*>(R) + CT::QKV_BYTES);
+  typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+  typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
+  const int i16 = lane & 15, jgrp = (lane >> 4) & 1;
+  const bf16_t* vbase = R + (4 * half + (i16 >> 2)) * CT::RSV + 16 * jgrp + 4 * (i16 & 3);
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16_t* vp = vbase + 16 * u * CT::RSV + dt * 32;
+      const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp));
+      const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp + 8 * CT::RSV));
+      const bf16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[0][u], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[1][u], o[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(Of + l31 * CT::RO + 8 * g + 4 * half) = make_float4(o[qt][4 * g], o[qt][4 * g + 1], o[qt][4 * g + 2], o[qt][4 * g + 3]);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int item = lane + 64 * i, qr = item >> 2, q = qt * 32 + qr, j = dt * 32 + 8 * (item & 3);
+        if (q >= Tq || j + 8 > DH) continue;
+        const float4 x0 = *reinterpret_cast<const float4*>(Of + qr * CT::RO + 8 * (item & 3));
+        const float4 x1 = *reinterpret_cast<const float4*>(Of + qr * CT::RO + 8 * (item & 3) + 4);
+        float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const unsigned w[4] = {rres[dt][qt][i].x, rres[dt][qt][i].y, rres[dt][qt][i].z, rres[dt][qt][i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] += __uint_as_float(w[e] << 16); f[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        uint4 ov;
+        ov.x = pack_bf16(f[0], f[1]); ov.y = pack_bf16(f[2], f[3]); ov.z = pack_bf16(f[4], f[5]); ov.w = pack_bf16(f[6], f[7]);
+        *reinterpret_cast<uint4*>(Og + (long long)q * a.o_rs + j) = ov;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // Store an O^T-style accumulator pair (rows = head-dim in registers, column = lane's row of the output matrix).
 template <int DH>
 __device__ __forceinline__ void store_rows_T(const f32x16_t (&o)[2], bf16_t* __restrict__ base, long long rs, int dt, int l31,
@@ -1079,8 +1303,19 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   if (mfma_ok) {
     a.vec16 = (d->dh % 8 == 0 && q1v_aligned(d->Q, d->q_bs, d->q_rs) && q1v_aligned(d->K, d->k_bs, d->k_rs) && q1v_aligned(d->V, d->v_bs, d->v_rs)) ? 1 : 0;
     const int nwm = 4;
-    const size_t ldsm = (size_t)nwm * d->dh * 72 * 2;
     const unsigned nb = (unsigned)cdiv64((long long)d->B * d->H, nwm);
+    // all-coalesced variant: 16-byte aligned rows everywhere (incl. residual and output)
+    if (a.vec16 && d->dh % 16 == 0 && q1v_aligned(d->out, d->o_bs, d->o_rs) && (d->resid == nullptr || q1v_aligned(d->resid, d->r_bs, d->r_rs))) {
+      switch (d->dh) {
+        case 16: hipLaunchKernelGGL((attn_fwd_co_kernel<16>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<16>::BYTES, st, a); break;
+        case 32: hipLaunchKernelGGL((attn_fwd_co_kernel<32>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<32>::BYTES, st, a); break;
+        case 64: hipLaunchKernelGGL((attn_fwd_co_kernel<64>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<64>::BYTES, st, a); break;
+        default: hipLaunchKernelGGL((attn_fwd_co_kernel<80>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<80>::BYTES, st, a); break;
+      }
+      DMT_CHECK_LAUNCH("dmt_attn_fwd(mfma, coalesced)");
+      return DMT_OK;
+    }
+    const size_t ldsm = (size_t)nwm * d->dh * 72 * 2;
     switch (d->dh) {
       case 16: hipLaunchKernelGGL((attn_fwd_mfma_kernel<16>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
       case 20: hipLaunchKernelGGL((attn_fwd_mfma_kernel<20>), dim3(nb), dim3(nwm * 64), ldsm, st, a); break;
