@@ -896,6 +896,301 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Coalesced variant of the backward kernel (dh % 16 == 0, 16-byte aligned rows): same math and register layouts as
+// attn_bwd_mfma_kernel, but every global access is a 16-byte chunk of a row with consecutive lanes on consecutive chunks
+// (see attn_fwd_co_kernel for the measurement behind this).  Wave-private LDS:
+//   X  [64][dh+8] bf16   one raw row tile at a time: K, V (fragments -> registers), Q (phase A), then K again (K^T for dQ), dO
+//                        (dO^T for dV), Q (Q^T for dK) -- transposed operands come from ds_read_b64_tr_b16, no register transposes
+//   Y  = PD [64][72] + ST: holds the raw dO tile during phase A, afterwards P / dS as [key][q] (PD) and the 32-row bf16 output
+//                        staging tile (ST) from which dQ / dV / dK leave as coalesced 16-byte stores
+template <int DH> struct CoBwd {
+  static constexpr int RS = DH + 8;
+  static constexpr int PLD = 72;
+  static constexpr int SLD = 40;                       // staging row stride (elements): [32 rows][32 dims]
+  static constexpr int X_BYTES = 64 * RS * 2;
+  static constexpr int PD_BYTES = 64 * PLD * 2;
+  static constexpr int ST_BYTES = (X_BYTES - PD_BYTES > 32 * SLD * 2) ? X_BYTES - PD_BYTES : 32 * SLD * 2;
+  static constexpr int BYTES = (X_BYTES + PD_BYTES + ST_BYTES + 64 + 255) / 256 * 256;
+};
+
+// one [32 rows][32 dims] accumulator half (rows = lane's output row, registers = dims) -> bf16 -> LDS rows -> 16-byte stores
+template <int DH>
+__device__ __forceinline__ void co_store_half(const f32x16_t& o, bf16_t* __restrict__ ST, bf16_t* __restrict__ base, long long rs, int dt,
+                                              int t, int lane, int n_rows) {
+  constexpr int SLD = CoBwd<DH>::SLD;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    uint2 ov;
+    ov.x = pack_bf16(o[4 * g + 0], o[4 * g + 1]);
+    ov.y = pack_bf16(o[4 * g + 2], o[4 * g + 3]);
+    *reinterpret_cast<uint2*>(ST + l31 * SLD + 8 * g + 4 * half) = ov;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int item = lane + 64 * i, rr = item >> 2, row = t * 32 + rr, j = dt * 32 + 8 * (item & 3);
+    if (row < n_rows && j + 8 <= DH)
+      *reinterpret_cast<uint4*>(base + (long long)row * rs + j) = *reinterpret_cast<const uint4*>(ST + rr * SLD + 8 * (item & 3));
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int DH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_co_kernel(const AttnArgs a) {
+  typedef CoBwd<DH> CB;
+  constexpr int NK = (DH + 15) / 16;
+  constexpr int NDT = (DH + 31) / 32;
+  constexpr int CH = DH / 8;
+  constexpr int RS = CB::RS, PLD = CB::PLD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const long long wid = blockIdx.x;
+  const int b = (int)(wid / a.H), h = (int)(wid % a.H);
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int half = lane >> 5, l31 = lane & 31;
+  bf16_t* X = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Y = X + CB::X_BYTES / 2;                 // raw dO tile during phase A
+  bf16_t* PD = Y;                                  // afterwards: P, then dS, as [key][q]
+  bf16_t* ST = Y + CB::PD_BYTES / 2;               // output staging
+
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
+  const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
+
+  // all four operand tiles are requested up front: ONE exposed global round trip instead of four
+  uint4 g0[CH], g1[CH];
+  {
+    uint4 g2[CH], g3[CH];
+    co_load<DH>(g0, Kg, a.k_rs, Tk, lane);
+    co_load<DH>(g1, Vg, a.v_rs, Tk, lane);
+    co_load<DH>(g2, Qg, a.q_rs, Tq, lane);
+    co_load<DH>(g3, dOg, a.do_rs, Tq, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    co_store<DH>(g0, X, RS, lane);                 // K rows
+    co_store<DH>(g3, Y, RS, lane);                 // dO rows (stay for the whole of phase A)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) g0[i] = g2[i];    // Q rows wait in registers until K and V have passed through X
+  }
+
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : Tq;
+  const float kscale = LOG2E / sqrtf((float)DH), inv_sc = 1.0f / sqrtf((float)DH);
+  const int kl = klen - 4 * half, tk = Tk - 4 * half;   // slot constant c: key = c + 4 half
+  bf16x8_t dsB[2][4];     // dS  (B operand of dQ^T, later copied to LDS as [key][q])
+  unsigned pP[2][16];     // P as it feeds dV (query mask and dropout applied), packed pairs of accumulator slots
+  {
+    bf16x8_t aK[2][NK], aV[2][NK];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) aK[t][s2] = co_frag<DH>(X, t * 32 + l31, s2 * 16 + 8 * half);
+    __builtin_amdgcn_wave_barrier();
+    co_store<DH>(g1, X, RS, lane);                 // V rows
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) aV[t][s2] = co_frag<DH>(X, t * 32 + l31, s2 * 16 + 8 * half);
+    __builtin_amdgcn_wave_barrier();
+    co_store<DH>(g0, X, RS, lane);                 // Q rows
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase A, one query tile (32 queries x 64 keys) at a time
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qt * 32 + l31;
+      f32x16_t acc[2], dp[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[kt][r] = 0.f; dp[kt][r] = 0.f; }
+#pragma unroll
+      for (int s2 = 0; s2 < NK; ++s2) {
+        const bf16x8_t bQ = co_frag<DH>(X, q, s2 * 16 + 8 * half), bD = co_frag<DH>(Y, q, s2 * 16 + 8 * half);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ, acc[kt], 0, 0, 0);   // S^T = K Q^T
+          dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD, dp[kt], 0, 0, 0);     // dP^T = V dO^T
+        }
+      }
+      if (qt == 1) {       // K / V fragments are dead: their registers take the K and dO rows that phases B and C transpose
+        co_load<DH>(g0, Kg, a.k_rs, Tk, lane);
+        co_load<DH>(g1, dOg, a.do_rs, Tq, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float m = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          float x = acc[kt][r] * kscale;
+          x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+          x = (c >= tk) ? -3.0e38f : x;
+          acc[kt][r] = x;
+          m = fmaxf(m, x);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
+          acc[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv_sum = __builtin_amdgcn_rcpf(sum);
+      const unsigned keep = drop_bits(a, b, h, q, half);
+      float dot = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = acc[kt][r] * inv_sum;
+          acc[kt][r] = pv;
+          float gq = dp[kt][r];
+          if (a.drop_on) gq = ((keep >> (kt * 16 + r)) & 1u) ? gq * a.drop_inv : 0.f;   // gradient w.r.t. the pre-dropout weights
+          dp[kt][r] = gq;
+          dot += pv * gq;
+        }
+      dot += __shfl_xor(dot, 32, 64);
+      const bool qpad = (q >= qlen);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          float pv = acc[kt][r];
+          float ds = (c < kl) ? pv * (dp[kt][r] - dot) * inv_sc : 0.f;      // no gradient into masked keys
+          if (qpad) { ds = 0.f; pv = (c < tk) ? PADDING_NUM : 0.f; }        // constant rows: gradient reaches V only
+          if (a.drop_on) pv = ((keep >> (kt * 16 + r)) & 1u) ? pv * a.drop_inv : 0.f;   // dropped weights feed dV
+          dp[kt][r] = ds;
+          acc[kt][r] = pv;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        union { bf16x8_t v; unsigned w[4]; } f;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          const int r0 = 8 * (u & 1) + i;
+          f.w[i >> 1] = pack_bf16(dp[u >> 1][r0], dp[u >> 1][r0 + 1]);
+        }
+        dsB[qt][u] = f.v;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) pP[qt][kt * 8 + (r >> 1)] = pack_bf16(acc[kt][r], acc[kt][r + 1]);
+      __builtin_amdgcn_sched_barrier(0);           // one query tile at a time: interleaving both doubles the live accumulators
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+  typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
+  const int i16 = lane & 15, jgrp = (lane >> 4) & 1;
+  // A = X^T fragments through transposing reads.  slot order: k-slot i of lane-half h <-> row 16u + (i&3) + 8(i>>2) + 4h;
+  // natural order: k-slot i <-> row 16u + 8h + i
+  const bf16_t* xs = X + (4 * half + (i16 >> 2)) * RS + 16 * jgrp + 4 * (i16 & 3);
+  const bf16_t* xn = X + (8 * half + (i16 >> 2)) * RS + 16 * jgrp + 4 * (i16 & 3);
+  auto fragT = [&](const bf16_t* base, int u, int dt, int hi_rows) -> bf16x8_t {
+    const bf16_t* vp = base + 16 * u * RS + dt * 32;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp + hi_rows * RS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  // ---- dQ^T = K^T dS^T
+  bf16_t* dQg = reinterpret_cast<bf16_t*>(a.dQ) + (long long)b * a.dq_bs + h * DH;
+  bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
+  bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
+  co_store<DH>(g0, X, RS, lane);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t av = fragT(xs, u, dt, 8);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[0][u], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[1][u], o[1], 0, 0, 0);
+    }
+    co_store_half<DH>(o[0], ST, dQg, a.dq_rs, dt, 0, lane, Tq);
+    co_store_half<DH>(o[1], ST, dQg, a.dq_rs, dt, 1, lane, Tq);
+  }
+
+  // ---- dV^T = dO^T P   (reduction over queries, natural k slots).  dO replaces the dead K tile; P goes to LDS as [key][q].
+  __builtin_amdgcn_wave_barrier();
+  co_load<DH>(g0, Qg, a.q_rs, Tq, lane);
+  co_store<DH>(g1, X, RS, lane);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        PD[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(pP[qt][kt * 8 + (r >> 1)] >> (16 * (r & 1)));
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t ov[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ov[0][r] = 0.f; ov[1][r] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t ad = fragT(xn, u, dt, 4);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8_t bp = *reinterpret_cast<const bf16x8_t*>(PD + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
+        ov[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bp, ov[kt], 0, 0, 0);
+      }
+    }
+    co_store_half<DH>(ov[0], ST, dVg, a.dv_rs, dt, 0, lane, Tk);
+    co_store_half<DH>(ov[1], ST, dVg, a.dv_rs, dt, 1, lane, Tk);
+  }
+
+  // ---- dK^T = Q^T dS.  Q replaces the dead dO tile; dS replaces P.
+  __builtin_amdgcn_wave_barrier();
+  co_store<DH>(g0, X, RS, lane);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        union { bf16x8_t v; unsigned w[4]; } f;
+        f.v = dsB[qt][2 * kt + (r >> 3)];
+        PD[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(f.w[(r & 7) >> 1] >> (16 * (r & 1)));
+      }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    f32x16_t ok[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ok[0][r] = 0.f; ok[1][r] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x8_t aq = fragT(xn, u, dt, 4);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8_t bd = *reinterpret_cast<const bf16x8_t*>(PD + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
+        ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
+      }
+    }
+    co_store_half<DH>(ok[0], ST, dKg, a.dk_rs, dt, 0, lane, Tk);
+    co_store_half<DH>(ok[1], ST, dKg, a.dk_rs, dt, 1, lane, Tk);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Single-query attention (the decoder: the target item attends over the encoded sequence, Tq == 1).  Memory bound:
 // one wavefront per (example, head), lane k owns key k and streams its K / V rows straight from global in 4-element
@@ -1376,6 +1671,17 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
                  q1v_aligned(d->dout, d->do_bs, d->do_rs)) ? 1 : 0;
       const size_t ldsm = ((size_t)(f.dh > 64 ? f.dh : 64) * 72 + 64 * 72) * 2;   // one transposed tile + one [key][q] tile
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
+      if (a.vec16 && f.dh % 16 == 0 && q1v_aligned(d->dQ, d->dq_bs, d->dq_rs) && q1v_aligned(d->dK, d->dk_bs, d->dk_rs) &&
+          q1v_aligned(d->dV, d->dv_bs, d->dv_rs)) {
+        switch (f.dh) {
+          case 16: hipLaunchKernelGGL((attn_bwd_co_kernel<16>), dim3(nbm), dim3(64), (size_t)CoBwd<16>::BYTES, st, a); break;
+          case 32: hipLaunchKernelGGL((attn_bwd_co_kernel<32>), dim3(nbm), dim3(64), (size_t)CoBwd<32>::BYTES, st, a); break;
+          case 64: hipLaunchKernelGGL((attn_bwd_co_kernel<64>), dim3(nbm), dim3(64), (size_t)CoBwd<64>::BYTES, st, a); break;
+          default: hipLaunchKernelGGL((attn_bwd_co_kernel<80>), dim3(nbm), dim3(64), (size_t)CoBwd<80>::BYTES, st, a); break;
+        }
+        DMT_CHECK_LAUNCH("dmt_attn_bwd(mfma, coalesced)");
+        return DMT_OK;
+      }
       switch (f.dh) {
         case 16: hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), dim3(nbm), dim3(64), ldsm, st, a); break;
         case 20: hipLaunchKernelGGL((attn_bwd_mfma_kernel<20>), dim3(nbm), dim3(64), ldsm, st, a); break;
