@@ -446,22 +446,34 @@ template <int DH> struct CoTile {
   static constexpr int BYTES = QKV_BYTES + 32 * RO * 4;   // + the output staging tile
 };
 
+// Row-chunk mapping of a [64 rows][dh] tile onto the wave: RPI whole rows per pass (lane -> row lane / CH, chunk lane % CH),
+// so the per-pass address is lane_offset + pass * constant (one VGPR per tensor instead of one 64-bit address per pass).
+template <int DH> struct CoMap {
+  static constexpr int CH = DH / 8;
+  static constexpr int RPI = 64 / CH;                 // rows per pass
+  static constexpr int NI = (64 + RPI - 1) / RPI;     // passes
+};
 template <int DH>
-__device__ __forceinline__ void co_load(uint4 (&buf)[DH / 8], const bf16_t* __restrict__ Xg, long long rs, int n_rows, int lane) {
-  constexpr int CH = DH / 8;
+__device__ __forceinline__ void co_load(uint4 (&buf)[CoMap<DH>::NI], const bf16_t* __restrict__ Xg, long long rs, int n_rows, int lane) {
+  typedef CoMap<DH> M;
+  const int lr = lane / M::CH, lc = lane - lr * M::CH;
+  const bool act = lr < M::RPI;
+  const char* lp = reinterpret_cast<const char*>(Xg) + ((unsigned)lr * (unsigned)rs + (unsigned)lc * 8u) * 2u;
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int item = lane + 64 * i, r = item / CH, c = item - r * CH;
-    buf[i] = (r < n_rows) ? *reinterpret_cast<const uint4*>(Xg + (long long)r * rs + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+  for (int i = 0; i < M::NI; ++i) {
+    const int r = i * M::RPI + lr;
+    buf[i] = (act && r < n_rows && r < 64) ? *reinterpret_cast<const uint4*>(lp + (size_t)i * M::RPI * (size_t)rs * 2) : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 template <int DH>
-__device__ __forceinline__ void co_store(const uint4 (&buf)[DH / 8], bf16_t* __restrict__ Xt, int row_stride, int lane) {
-  constexpr int CH = DH / 8;
+__device__ __forceinline__ void co_store(const uint4 (&buf)[CoMap<DH>::NI], bf16_t* __restrict__ Xt, int row_stride, int lane) {
+  typedef CoMap<DH> M;
+  const int lr = lane / M::CH, lc = lane - lr * M::CH;
+  if (lr >= M::RPI) return;
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int item = lane + 64 * i, r = item / CH, c = item - r * CH;
-    *reinterpret_cast<uint4*>(Xt + r * row_stride + c * 8) = buf[i];
+  for (int i = 0; i < M::NI; ++i) {
+    const int r = i * M::RPI + lr;
+    if (r < 64) *reinterpret_cast<uint4*>(Xt + r * row_stride + lc * 8) = buf[i];
   }
 }
 // 16-byte MFMA fragment of row `row`, k = j0 .. j0+7 (zero past dh)
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
   const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
 
-  uint4 gq[CH], gk[CH];
+  uint4 gq[CoMap<DH>::NI], gk[CoMap<DH>::NI];
   co_load<DH>(gq, Qg, a.q_rs, Tq, lane);
   co_load<DH>(gk, Kg, a.k_rs, Tk, lane);
 
@@ -910,8 +922,12 @@ template <int DH> struct CoBwd {
   static constexpr int SLD = 40;                       // staging row stride (elements): [32 rows][32 dims]
   static constexpr int X_BYTES = 64 * RS * 2;
   static constexpr int PD_BYTES = 64 * PLD * 2;
-  static constexpr int ST_BYTES = (X_BYTES - PD_BYTES > 32 * SLD * 2) ? X_BYTES - PD_BYTES : 32 * SLD * 2;
-  static constexpr int BYTES = (X_BYTES + PD_BYTES + ST_BYTES + 64 + 255) / 256 * 256;
+  static constexpr int ST_BYTES = 32 * SLD * 2;
+  // The raw dO tile of phase A aliases PD + ST when P's first 32 rows (written while dO rows 32.. are still needed) end below
+  // dO row 32, i.e. PLD <= RS; otherwise (small head dims, LDS is not tight there) it gets its own region.
+  static constexpr bool Y_ALIASES = (PLD <= RS) && (PD_BYTES + ST_BYTES >= X_BYTES);
+  static constexpr int Y_OFFSET = Y_ALIASES ? X_BYTES : X_BYTES + PD_BYTES + ST_BYTES;
+  static constexpr int BYTES = ((Y_ALIASES ? X_BYTES + PD_BYTES + ST_BYTES : Y_OFFSET + X_BYTES) + 64 + 255) / 256 * 256;
 };
 
 // one [32 rows][32 dims] accumulator half (rows = lane's output row, registers = dims) -> bf16 -> LDS rows -> 16-byte stores
@@ -951,9 +967,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
   bf16_t* X = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Y = X + CB::X_BYTES / 2;                 // raw dO tile during phase A
-  bf16_t* PD = Y;                                  // afterwards: P, then dS, as [key][q]
-  bf16_t* ST = Y + CB::PD_BYTES / 2;               // output staging
+  bf16_t* PD = X + CB::X_BYTES / 2;                // P, then dS, as [q][key]
+  bf16_t* ST = PD + CB::PD_BYTES / 2;              // output staging
+  bf16_t* Y = X + CB::Y_OFFSET / 2;                // raw dO tile during phase A
 
   const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
   const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
@@ -961,9 +977,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
 
   // all four operand tiles are requested up front: ONE exposed global round trip instead of four
-  uint4 g0[CH], g1[CH];
+  uint4 g0[CoMap<DH>::NI], g1[CoMap<DH>::NI];
   {
-    uint4 g2[CH], g3[CH];
+    uint4 g2[CoMap<DH>::NI], g3[CoMap<DH>::NI];
     co_load<DH>(g0, Kg, a.k_rs, Tk, lane);
     co_load<DH>(g1, Vg, a.v_rs, Tk, lane);
     co_load<DH>(g2, Qg, a.q_rs, Tq, lane);
@@ -972,7 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     co_store<DH>(g0, X, RS, lane);                 // K rows
     co_store<DH>(g3, Y, RS, lane);                 // dO rows (stay for the whole of phase A)
 #pragma unroll
-    for (int i = 0; i < CH; ++i) g0[i] = g2[i];    // Q rows wait in registers until K and V have passed through X
+    for (int i = 0; i < CoMap<DH>::NI; ++i) g0[i] = g2[i];    // Q rows wait in registers until K and V have passed through X
   }
 
   int klen = a.k_lens ? a.k_lens[b] : Tk;
@@ -981,7 +997,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const float kscale = LOG2E / sqrtf((float)DH), inv_sc = 1.0f / sqrtf((float)DH);
   const int kl = klen - 4 * half, tk = Tk - 4 * half;   // slot constant c: key = c + 4 half
   bf16x8_t dsB[2][4];     // dS  (B operand of dQ^T, later copied to LDS as [key][q])
-  unsigned pP[2][16];     // P as it feeds dV (query mask and dropout applied), packed pairs of accumulator slots
   {
     bf16x8_t aK[2][NK], aV[2][NK];
     __builtin_amdgcn_wave_barrier();
@@ -1018,9 +1033,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD, dp[kt], 0, 0, 0);     // dP^T = V dO^T
         }
       }
-      if (qt == 1) {       // K / V fragments are dead: their registers take the K and dO rows that phases B and C transpose
+      if (qt == 1) {       // K / V fragments are dead: their registers take the K rows that phase B transposes
         co_load<DH>(g0, Kg, a.k_rs, Tk, lane);
-        co_load<DH>(g1, dOg, a.do_rs, Tq, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
       float m = -3.0e38f;
@@ -1084,10 +1098,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         dsB[qt][u] = f.v;
       }
+      // P as it feeds dV (query mask and dropout applied) goes straight to PD row q: 4 consecutive keys per 8-byte store
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) pP[qt][kt * 8 + (r >> 1)] = pack_bf16(acc[kt][r], acc[kt][r + 1]);
+        for (int g = 0; g < 4; ++g) {
+          uint2 pv;
+          pv.x = pack_bf16(acc[kt][4 * g + 0], acc[kt][4 * g + 1]);
+          pv.y = pack_bf16(acc[kt][4 * g + 2], acc[kt][4 * g + 3]);
+          *reinterpret_cast<uint2*>(PD + q * PLD + kt * 32 + 8 * g + 4 * half) = pv;
+        }
       __builtin_amdgcn_sched_barrier(0);           // one query tile at a time: interleaving both doubles the live accumulators
     }
   }
@@ -1106,12 +1126,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp + hi_rows * RS));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
+  // B fragment of PD^T: lane n = key kt*32 + l31, k-slot i <-> query 16u + 8h + i
+  const bf16_t* pn = PD + (8 * half + (i16 >> 2)) * PLD + 16 * jgrp + 4 * (i16 & 3);
+  auto fragPD = [&](int u, int kt) -> bf16x8_t {
+    const bf16_t* vp = pn + 16 * u * PLD + kt * 32;
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp + 4 * PLD));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
 
   // ---- dQ^T = K^T dS^T
   bf16_t* dQg = reinterpret_cast<bf16_t*>(a.dQ) + (long long)b * a.dq_bs + h * DH;
   bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
   bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
   co_store<DH>(g0, X, RS, lane);
+  co_load<DH>(g1, dOg, a.do_rs, Tq, lane);         // for phase C, in flight during phase B
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
@@ -1132,13 +1161,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_wave_barrier();
   co_load<DH>(g0, Qg, a.q_rs, Tq, lane);
   co_store<DH>(g1, X, RS, lane);
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        PD[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(pP[qt][kt * 8 + (r >> 1)] >> (16 * (r & 1)));
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
@@ -1150,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const bf16x8_t ad = fragT(xn, u, dt, 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const bf16x8_t bp = *reinterpret_cast<const bf16x8_t*>(PD + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
+        const bf16x8_t bp = fragPD(u, kt);
         ov[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bp, ov[kt], 0, 0, 0);
       }
     }
@@ -1164,13 +1186,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        union { bf16x8_t v; unsigned w[4]; } f;
-        f.v = dsB[qt][2 * kt + (r >> 3)];
-        PD[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * PLD + qt * 32 + l31] = (bf16_t)(f.w[(r & 7) >> 1] >> (16 * (r & 1)));
-      }
+    for (int u = 0; u < 4; ++u) {      // slots 0..3 of dsB[qt][u] <-> keys 16u + 4h + {0..3}, slots 4..7 <-> 8 keys further
+      union { bf16x8_t v; uint2 h2[2]; } f;
+      f.v = dsB[qt][u];
+      *reinterpret_cast<uint2*>(PD + (qt * 32 + l31) * PLD + 16 * u + 4 * half) = f.h2[0];
+      *reinterpret_cast<uint2*>(PD + (qt * 32 + l31) * PLD + 16 * u + 8 + 4 * half) = f.h2[1];
+    }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
@@ -1182,7 +1203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const bf16x8_t aq = fragT(xn, u, dt, 4);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const bf16x8_t bd = *reinterpret_cast<const bf16x8_t*>(PD + (kt * 32 + l31) * PLD + 16 * u + 8 * half);
+        const bf16x8_t bd = fragPD(u, kt);
         ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
       }
     }
