@@ -16,7 +16,9 @@ def _rand(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("B,T,H,dh", [(5, 50, 4, 20), (3, 10, 4, 20), (2, 64, 4, 80), (4, 7, 2, 16), (3, 1, 4, 20)])
+@pytest.mark.parametrize("B,T,H,dh", [(5, 50, 4, 20), (3, 10, 4, 20), (2, 64, 4, 80), (4, 7, 2, 16), (3, 1, 4, 20),
+                                      # head dims of the coalesced MFMA kernels (dh % 16 == 0), ragged and full tiles
+                                      (5, 50, 4, 80), (6, 10, 4, 16), (3, 33, 2, 32), (2, 50, 2, 64), (2, 64, 2, 16)])
 def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
     d = H * dh
     q = torch.tensor(_rand((B, T, d), 1), dtype=dtype)
