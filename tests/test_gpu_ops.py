@@ -229,3 +229,30 @@ def test_batched_cast_transpose_equals_per_weight_casts(cuda):
             assert torch.equal(dp, w)
         if dt is not None:
             assert torch.equal(dt, w.t())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H,dh", [(7, 50, 4, 80), (9, 10, 4, 80), (3, 64, 2, 16), (4, 33, 2, 64)])
+def test_mfma_attention_dropout_matches_fp32_kernel(cuda, B, T, H, dh):
+    """Attention-weight dropout (TransformerModel_util.py:51 tf.layers.dropout on the softmax) in the coalesced bf16 MFMA kernels
+    against the scalar fp32 kernel of the same library (independent code, same counter mask): a different mask would show up as
+    O(1) errors.  Ragged lengths, forward and all three input gradients."""
+    d = H * dh
+    g = torch.Generator(device="cpu").manual_seed(11)
+    qkv32 = (torch.randn((B, T, 3 * d), generator=g) * 0.7)
+    x32 = torch.randn((B, T, d), generator=g)
+    lens = torch.tensor(np.random.default_rng(3).integers(1, T + 1, size=B), dtype=torch.int32, device=cuda)
+    w = torch.randn((B, T, d), generator=g).to(cuda) * (torch.arange(T, device=cuda)[None, :, None] < lens[:, None, None])
+    outs, grads = [], []
+    for dt in (torch.float32, torch.bfloat16):
+        qkv = qkv32.to(torch.bfloat16).to(dt).to(cuda).requires_grad_(True)      # same (bf16-representable) inputs on both paths
+        x = x32.to(torch.bfloat16).to(dt).to(cuda).requires_grad_(True)
+        out = ops.AttnFn.apply(qkv, None, x, lens, lens, H, d, True, 0x5EED1234, 0.9)
+        (out.float() * w).sum().backward()
+        outs.append(out.detach().float())
+        grads.append(qkv.grad.detach().float())
+    valid = (torch.arange(T, device=cuda)[None, :, None] < lens[:, None, None])
+    eo = ((outs[0] - outs[1]).abs() * valid).max().item() / outs[0].abs().mul(valid).max().item()
+    eg = (grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item()
+    assert eo < 2e-2, eo
+    assert eg < 4e-2, eg
