@@ -121,7 +121,7 @@ def main():
     n_g, t_g, fl_g = agg(gkey)
     n_ga, t_ga, by_ga = agg("gather_fwd")
     peak = 2500.0 if args.dtype == "bf16" else 157.3
-    roofline = {"kernel": "gemm_glds_kernel (fwd / input-grad) + gemm_kernel<%s> (weight-grad): all QKV/FFN/MMoE/tower GEMMs, %d launches/step" % (args.dtype, n_g // max(args.steps, 1)),
+    roofline = {"kernel": "gemm_glds_kernel (fwd / input-grad) + gemm_dw_glds_kernel (weight-grad) [+ gemm_kernel<%s> for small / ragged shapes]: all QKV/FFN/MMoE/tower GEMMs, %d launches/step" % (args.dtype, n_g // max(args.steps, 1)),
                 "bound": "mfma", "achieved": round(fl_g / t_g / 1e12, 2) if t_g > 0 else None, "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl_g / t_g / 1e12 / peak, 4) if t_g > 0 else None, "traffic": None,
                 "avg_launch_us": round(t_g / max(n_g, 1) * 1e6, 2), "time_share": round(t_g / dt, 3)}
