@@ -338,6 +338,39 @@ class DMTEngine:
         L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
         return X, tar
 
+    def gather_pooled(self, batch: DeviceBatch):
+        """Inference-only gather WITHOUT the sequence rows: target embedding tar [B, d] and the MMoE input buffer zbuf (dense
+        features, pooled id embeddings, bias-tower embeddings).  Used by the serving path, where the behaviour sequences of the
+        one user are encoded once (serving.CandidateScorer) and only these per-candidate pieces are needed for every row."""
+        spec, plan, store = self.spec, self.plan, self.store
+        dev, cdt = store.device, store.compute_dtype
+        B, d = batch.B, spec["d_model"]
+        tar = torch.empty((B, d), dtype=cdt, device=dev)
+        zbuf = torch.zeros((B, plan.ldz), dtype=cdt, device=dev)
+        inv = torch.empty((len(plan.items), B), dtype=F32, device=dev)
+        desc = L.GatherDesc()
+        desc.B, desc.n_features = B, len(plan.items)
+        for i, it in enumerate(plan.items):
+            col = batch.feats[it["feature"]]
+            f = desc.feat[i]
+            f.table = store.table[it["table"]].data_ptr()
+            f.rows, f.dim = it["rows"], it["dim"]
+            f.idx = col.idx.data_ptr()
+            f.wts = col.wts.data_ptr() if col.wts is not None else None
+            f.lens, f.T = col.lens.data_ptr(), col.T
+            is_target = it["seq_id"] == L.DMT_SEQ_TARGET
+            f.pooled_off, f.group = it["pooled_off"], it["group"]
+            f.seq_id, f.seq_off = (it["seq_id"], it["seq_off"]) if is_target else (-1, 0)
+            f.inv_wsum = inv[i].data_ptr()
+        desc.n_seq = 0
+        desc.tar_out, desc.d_model, desc.seq_scale = tar.data_ptr(), d, float(d) ** 0.5
+        desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
+        desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
+        desc.out_dtype = ops.dt_code(cdt)
+        desc.seq_drop_keep = 1.0
+        L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
+        return tar, zbuf
+
     def _attn_drop(self, stream):
         rate = self.spec.get("dropout_rate", 0.0)
         if self.dropout_step_seed is None or not rate:
@@ -382,6 +415,20 @@ class DMTEngine:
         y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3)
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(y, blk + ffs)
+
+    def decode_shared(self, y, mem1, k_lens, i):
+        """decode_prepared for B queries against ONE shared memory mem1 [1, T, d] (serving: every candidate row of a request has
+        the same user): K | V are projected once and broadcast through a zero batch stride.  Inference only (no dropout)."""
+        blk = trans_prefix(i) + "num_blocks_0/"
+        d, H = self.spec["d_model"], self.spec["num_heads"]
+        a = blk + "vanilla_attention/"
+        wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
+        q = ops.linear(y, wl[:, :d], bl[:d], self._wslice(w, 0, d))
+        kv = ops.linear(mem1, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d)).expand(y.shape[0], -1, -1)
+        s = ops.AttnFn.apply(q, kv, y, None, k_lens, H, d, False, 0, 1.0)
+        s = ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
+        ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
+        return self.ff(s, blk + ffs)
 
     def embedding_trans(self, batch: DeviceBatch):
         X, tar, zbuf = self.gather(batch)

@@ -476,6 +476,27 @@ def inference(inputs, P, spec, is_predict=False, step_seed=None):
 
 
 # --------------------------------------------------------------------------------------------- loss
+def serving_normalise(raw, mean, std):
+    """Online normalisation of the raw dense features in the exported graph, float32 as the TF constants are
+    (saved_model/export_model.py:86-96; constants from saved_model/preprocess.py:17-40, computed there in float64)."""
+    m, s = np.asarray(mean, dtype=np.float64), np.asarray(std, dtype=np.float64)
+    eps64 = np.full_like(s, 1e-7)
+    div1 = (m * s) / (np.square(s + eps64) * 3)                 # preprocess.py:30-31
+    div2 = (m * s) / (s + eps64)                                # :32
+    const_vec = ((div1 + div2) - m).astype(np.float32)          # :33-34, fed to tf.constant(float32) at export_model.py:87
+    std32 = np.asarray(std, dtype=np.float32)
+    eps32 = np.full(std32.shape, 0.0000001, dtype=np.float32)
+    x = np.clip(np.asarray(raw, dtype=np.float32), 0.0, np.finfo(np.float32).max)            # :91
+    y = (x * std32) / (np.square(std32 + eps32) * np.float32(3.0)) - const_vec                 # :92-93
+    return np.clip(y, np.float32(-0.99), np.float32(0.99))                                     # :95
+
+
+def serving_scores(click_logit, order_logit, export_weight):
+    """Scores = (w0 * sigmoid(click) + w1 * sigmoid(order)) / sum(w)  (saved_model/export_model.py:106-114)."""
+    pc, po = sigmoid(np.reshape(click_logit, -1)), sigmoid(np.reshape(order_logit, -1))
+    return (export_weight[0] * pc + export_weight[1] * po) / float(sum(export_weight))
+
+
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
