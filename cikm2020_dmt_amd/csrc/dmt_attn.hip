@@ -486,8 +486,9 @@ __device__ __forceinline__ bf16x8_t co_frag(const bf16_t* __restrict__ Xt, int r
   return u.v;
 }
 
-// NT = number of 32-row tiles per side (1 when Tq, Tk <= 32: a quarter of the score tile, e.g. the 10-step cart sequence)
-template <int DH, int NT>
+// NTQ / NTK = number of 32-row query / key tiles (1 when Tq resp. Tk <= 32: the 10-step cart sequence runs 1 x 1, the
+// single-query decoder attention 1 x 2)
+template <int DH, int NTQ, int NTK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_co_kernel(const AttnArgs a) {
   typedef CoTile<DH> CT;
   constexpr int NK = (DH + 15) / 16;
@@ -513,19 +514,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   co_load<DH>(gk, Kg, a.k_rs, Tk, lane);
 
   // ---- S^T = K Q^T
-  f32x16_t acc[NT][NT];
+  f32x16_t acc[NTK][NTQ];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < NTK; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTQ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   {
-    bf16x8_t bQ[NT][NK];
+    bf16x8_t bQ[NTQ][NK];
     co_store<DH>(gq, R, CT::RS, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTQ; ++t)
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) bQ[t][s2] = co_frag<DH>(R, t * 32 + l31, s2 * 16 + 8 * half);
     __builtin_amdgcn_wave_barrier();
@@ -535,10 +536,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s2 = 0; s2 < NK; ++s2)
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
+      for (int kt = 0; kt < NTK; ++kt) {
         const bf16x8_t kf = co_frag<DH>(R, kt * 32 + l31, s2 * 16 + 8 * half);
 #pragma unroll
-        for (int qt = 0; qt < NT; ++qt) acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, bQ[qt][s2], acc[kt][qt], 0, 0, 0);
+        for (int qt = 0; qt < NTQ; ++qt) acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, bQ[qt][s2], acc[kt][qt], 0, 0, 0);
       }
     __builtin_amdgcn_wave_barrier();
   }
@@ -546,11 +547,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // the residual pieces this lane adds in the epilogue (row = 32 qt + (item >> 2), dims dt*32 + 8 (item & 3)), requested now so
   // that their latency hides behind the softmax
   const bf16_t* Rg = a.resid ? reinterpret_cast<const bf16_t*>(a.resid) + (long long)b * a.r_bs + h * DH : nullptr;
-  uint4 rres[NDT][NT][2];
+  uint4 rres[NDT][NTQ][2];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
+    for (int qt = 0; qt < NTQ; ++qt)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int item = lane + 64 * i, q = qt * 32 + (item >> 2), j = dt * 32 + 8 * (item & 3);
@@ -563,13 +564,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
   const float kscale = LOG2E / sqrtf((float)DH);
   const int kl = klen - 4 * half, tk = Tk - 4 * half;
-  bf16x8_t pB[NT][2 * NT];
+  bf16x8_t pB[NTQ][2 * NTK];
 #pragma unroll
-  for (int qt = 0; qt < NT; ++qt) {
+  for (int qt = 0; qt < NTQ; ++qt) {
     const int q = qt * 32 + l31;
     float m = -3.0e38f;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float e = __builtin_amdgcn_exp2f(acc[kt][qt][r] - m);
@@ -592,9 +593,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sum += __shfl_xor(sum, 32, 64);
     const float inv_sum = __builtin_amdgcn_rcpf(sum);
     const bool qpad = (q >= qlen);
-    const unsigned keep = drop_bits<NT>(a, b, h, q, half);
+    const unsigned keep = drop_bits<NTK>(a, b, h, q, half);
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {
+    for (int u = 0; u < 2 * NTK; ++u) {
       union { bf16x8_t v; unsigned w[4]; } f;
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {
@@ -627,22 +628,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bf16_t* vbase = R + (4 * half + (i16 >> 2)) * CT::RSV + 16 * jgrp + 4 * (i16 & 3);
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
-    f32x16_t o[NT];
+    f32x16_t o[NTQ];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
+    for (int qt = 0; qt < NTQ; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qt][r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {
+    for (int u = 0; u < 2 * NTK; ++u) {
       const bf16_t* vp = vbase + 16 * u * CT::RSV + dt * 32;
       const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp));
       const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p4)(vp + 8 * CT::RSV));
       const bf16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-      for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[qt][u], o[qt], 0, 0, 0);
+      for (int qt = 0; qt < NTQ; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pB[qt][u], o[qt], 0, 0, 0);
     }
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NTQ; ++qt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(Of + l31 * CT::RO + 8 * g + 4 * half) = make_float4(o[qt][4 * g], o[qt][4 * g + 1], o[qt][4 * g + 2], o[qt][4 * g + 3]);
@@ -957,7 +958,7 @@ __device__ __forceinline__ void co_store_half(const f32x16_t& o, bf16_t* __restr
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int DH, int NT>
+template <int DH, int NTQ, int NTK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_co_kernel(const AttnArgs a) {
   typedef CoBwd<DH> CB;
   constexpr int NK = (DH + 15) / 16;
@@ -1000,19 +1001,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
   const float kscale = LOG2E / sqrtf((float)DH), inv_sc = 1.0f / sqrtf((float)DH);
   const int kl = klen - 4 * half, tk = Tk - 4 * half;   // slot constant c: key = c + 4 half
-  bf16x8_t dsB[NT][2 * NT];     // dS  (B operand of dQ^T, later copied to LDS as [key][q])
+  bf16x8_t dsB[NTQ][2 * NTK];     // dS  (B operand of dQ^T, later copied to LDS as [key][q])
   {
-    bf16x8_t aK[NT][NK], aV[NT][NK];
+    bf16x8_t aK[NTK][NK], aV[NTK][NK];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTK; ++t)
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) aK[t][s2] = co_frag<DH>(X, t * 32 + l31, s2 * 16 + 8 * half);
     __builtin_amdgcn_wave_barrier();
     co_store<DH>(g1, X, RS, lane);                 // V rows
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTK; ++t)
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) aV[t][s2] = co_frag<DH>(X, t * 32 + l31, s2 * 16 + 8 * half);
     __builtin_amdgcn_wave_barrier();
@@ -1021,29 +1022,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     // ---- phase A, one query tile (32 queries x 64 keys) at a time
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NTQ; ++qt) {
       const int q = qt * 32 + l31;
-      f32x16_t acc[NT], dp[NT];
+      f32x16_t acc[NTK], dp[NTK];
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[kt][r] = 0.f; dp[kt][r] = 0.f; }
 #pragma unroll
       for (int s2 = 0; s2 < NK; ++s2) {
         const bf16x8_t bQ = co_frag<DH>(X, q, s2 * 16 + 8 * half), bD = co_frag<DH>(Y, q, s2 * 16 + 8 * half);
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NTK; ++kt) {
           acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aK[kt][s2], bQ, acc[kt], 0, 0, 0);   // S^T = K Q^T
           dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aV[kt][s2], bD, dp[kt], 0, 0, 0);     // dP^T = V dO^T
         }
       }
-      if (qt == NT - 1) {       // K / V fragments are dead: their registers take the K rows that phase B transposes
+      if (qt == NTQ - 1) {       // K / V fragments are dead: their registers take the K rows that phase B transposes
         co_load<DH>(g0, Kg, a.k_rs, Tk, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
       float m = -3.0e38f;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       m = fmaxf(m, __shfl_xor(m, 32, 64));
       float sum = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
@@ -1065,10 +1066,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       sum += __shfl_xor(sum, 32, 64);
       const float inv_sum = __builtin_amdgcn_rcpf(sum);
-      const unsigned keep = drop_bits<NT>(a, b, h, q, half);
+      const unsigned keep = drop_bits<NTK>(a, b, h, q, half);
       float dot = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = acc[kt][r] * inv_sum;
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       dot += __shfl_xor(dot, 32, 64);
       const bool qpad = (q >= qlen);
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           acc[kt][r] = pv;
         }
 #pragma unroll
-      for (int u = 0; u < 2 * NT; ++u) {
+      for (int u = 0; u < 2 * NTK; ++u) {
         union { bf16x8_t v; unsigned w[4]; } f;
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
       // P as it feeds dV (query mask and dropout applied) goes straight to PD row q: 4 consecutive keys per 8-byte store
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2 pv;
@@ -1148,19 +1149,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
-    f32x16_t o[NT];
+    f32x16_t o[NTQ];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt)
+    for (int qt = 0; qt < NTQ; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[qt][r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {
+    for (int u = 0; u < 2 * NTK; ++u) {
       const bf16x8_t av = fragT(xs, u, dt, 8);
 #pragma unroll
-      for (int qt = 0; qt < NT; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[qt][u], o[qt], 0, 0, 0);
+      for (int qt = 0; qt < NTQ; ++qt) o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dsB[qt][u], o[qt], 0, 0, 0);
     }
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) co_store_half<DH>(o[qt], ST, dQg, a.dq_rs, dt, qt, lane, Tq);
+    for (int qt = 0; qt < NTQ; ++qt) co_store_half<DH>(o[qt], ST, dQg, a.dq_rs, dt, qt, lane, Tq);
   }
 
   // ---- dV^T = dO^T P   (reduction over queries, natural k slots).  dO replaces the dead K tile; P goes to LDS as [key][q].
@@ -1170,31 +1171,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
-    f32x16_t ov[NT];
+    f32x16_t ov[NTK];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ov[kt][r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {
+    for (int u = 0; u < 2 * NTQ; ++u) {
       const bf16x8_t ad = fragT(xn, u, dt, 4);
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
+      for (int kt = 0; kt < NTK; ++kt) {
         const bf16x8_t bp = fragPD(u, kt);
         ov[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bp, ov[kt], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) co_store_half<DH>(ov[kt], ST, dVg, a.dv_rs, dt, kt, lane, Tk);
+    for (int kt = 0; kt < NTK; ++kt) co_store_half<DH>(ov[kt], ST, dVg, a.dv_rs, dt, kt, lane, Tk);
   }
 
   // ---- dK^T = Q^T dS.  Q replaces the dead dO tile; dS replaces P.
   __builtin_amdgcn_wave_barrier();
   co_store<DH>(g0, X, RS, lane);
 #pragma unroll
-  for (int qt = 0; qt < NT; ++qt)
+  for (int qt = 0; qt < NTQ; ++qt)
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {      // slots 0..3 of dsB[qt][u] <-> keys 16u + 4h + {0..3}, slots 4..7 <-> 8 keys further
+    for (int u = 0; u < 2 * NTK; ++u) {      // slots 0..3 of dsB[qt][u] <-> keys 16u + 4h + {0..3}, slots 4..7 <-> 8 keys further
       union { bf16x8_t v; uint2 h2[2]; } f;
       f.v = dsB[qt][u];
       *reinterpret_cast<uint2*>(PD + (qt * 32 + l31) * PLD + 16 * u + 4 * half) = f.h2[0];
@@ -1203,22 +1204,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) {
-    f32x16_t ok[NT];
+    f32x16_t ok[NTK];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ok[kt][r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < 2 * NT; ++u) {
+    for (int u = 0; u < 2 * NTQ; ++u) {
       const bf16x8_t aq = fragT(xn, u, dt, 4);
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt) {
+      for (int kt = 0; kt < NTK; ++kt) {
         const bf16x8_t bd = fragPD(u, kt);
         ok[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bd, ok[kt], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) co_store_half<DH>(ok[kt], ST, dKg, a.dk_rs, dt, kt, lane, Tk);
+    for (int kt = 0; kt < NTK; ++kt) co_store_half<DH>(ok[kt], ST, dKg, a.dk_rs, dt, kt, lane, Tk);
   }
 }
 
@@ -1617,7 +1618,9 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   if (d->Tq == 1 && q1_aligned(d->dtype, d->Q, d->q_bs, d->q_rs, d->dh) && q1_aligned(d->dtype, d->K, d->k_bs, d->k_rs, d->dh) &&
       q1_aligned(d->dtype, d->V, d->v_bs, d->v_rs, d->dh)) {
     // (the lanes-along-dh kernel attn_q1v_kernel<.., false> measured 2x SLOWER than this one for the forward: 128 vs 65 us,
-    //  65 us = K and V read once at 4 TB/s; it pays only in the backward, which also writes dK / dV rows)
+    //  65 us = K and V read once at 4 TB/s; it pays only in the backward, which also writes dK / dV rows.  Routing Tq = 1
+    //  through the coalesced MFMA kernels (NTQ = 1, NTK = 2) measured the same step time as these two kernels, forward and
+    //  backward, so the simpler kernels stay.)
     const int r1 = (d->dtype == DMT_F32) ? launch_q1<float, false>(a, st) : launch_q1<bf16_t, false>(a, st);
     if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_fwd(q1)"); return DMT_OK; }
   }
@@ -1632,9 +1635,11 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
     const unsigned nb = (unsigned)cdiv64((long long)d->B * d->H, nwm);
     // all-coalesced variant: 16-byte aligned rows everywhere (incl. residual and output)
     if (a.vec16 && d->dh % 16 == 0 && q1v_aligned(d->out, d->o_bs, d->o_rs) && (d->resid == nullptr || q1v_aligned(d->resid, d->r_bs, d->r_rs))) {
-      const bool small = d->Tq <= 32 && d->Tk <= 32;       // one 32x32 score tile instead of four
-#define DMT_FWD_CO(DHV) do { if (small) hipLaunchKernelGGL((attn_fwd_co_kernel<DHV, 1>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<DHV>::BYTES, st, a); \
-                             else hipLaunchKernelGGL((attn_fwd_co_kernel<DHV, 2>), dim3(nb), dim3(nwm * 64), (size_t)nwm * CoTile<DHV>::BYTES, st, a); } while (0)
+      const int ntq = d->Tq <= 32 ? 1 : 2, ntk = d->Tk <= 32 ? 1 : 2;       // 32-row tiles actually needed
+#define DMT_FWD_CO(DHV) do { const size_t lb = (size_t)nwm * CoTile<DHV>::BYTES; \
+    if (ntq == 1 && ntk == 1) hipLaunchKernelGGL((attn_fwd_co_kernel<DHV, 1, 1>), dim3(nb), dim3(nwm * 64), lb, st, a); \
+    else if (ntq == 1) hipLaunchKernelGGL((attn_fwd_co_kernel<DHV, 1, 2>), dim3(nb), dim3(nwm * 64), lb, st, a); \
+    else hipLaunchKernelGGL((attn_fwd_co_kernel<DHV, 2, 2>), dim3(nb), dim3(nwm * 64), lb, st, a); } while (0)
       switch (d->dh) {
         case 16: DMT_FWD_CO(16); break;
         case 32: DMT_FWD_CO(32); break;
@@ -1708,9 +1713,11 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
       if (a.vec16 && f.dh % 16 == 0 && q1v_aligned(d->dQ, d->dq_bs, d->dq_rs) && q1v_aligned(d->dK, d->dk_bs, d->dk_rs) &&
           q1v_aligned(d->dV, d->dv_bs, d->dv_rs)) {
-        const bool small = f.Tq <= 32 && f.Tk <= 32;
-#define DMT_BWD_CO(DHV) do { if (small) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1>), dim3(nbm), dim3(64), (size_t)CoBwd<DHV>::BYTES, st, a); \
-                             else hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 2>), dim3(nbm), dim3(64), (size_t)CoBwd<DHV>::BYTES, st, a); } while (0)
+        const int ntq = f.Tq <= 32 ? 1 : 2, ntk = f.Tk <= 32 ? 1 : 2;
+#define DMT_BWD_CO(DHV) do { const size_t lb = (size_t)CoBwd<DHV>::BYTES; \
+    if (ntq == 1 && ntk == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 1>), dim3(nbm), dim3(64), lb, st, a); \
+    else if (ntq == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 2>), dim3(nbm), dim3(64), lb, st, a); \
+    else hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 2, 2>), dim3(nbm), dim3(64), lb, st, a); } while (0)
         switch (f.dh) {
           case 16: DMT_BWD_CO(16); break;
           case 32: DMT_BWD_CO(32); break;

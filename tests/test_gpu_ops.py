@@ -256,3 +256,31 @@ def test_mfma_attention_dropout_matches_fp32_kernel(cuda, B, T, H, dh):
     eg = (grads[0] - grads[1]).abs().max().item() / grads[0].abs().max().item()
     assert eo < 2e-2, eo
     assert eg < 4e-2, eg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Tq,Tk,H,dh", [(5, 12, 50, 4, 80), (4, 40, 20, 2, 64), (3, 9, 9, 2, 16)])
+def test_mfma_cross_attention_matches_fp32_kernel(cuda, B, Tq, Tk, H, dh):
+    """Cross attention with different query / key tile counts (coalesced kernels <NTQ, NTK> = <1,2>, <2,1>, <1,1>), separate
+    query and key lengths, packed K|V: bf16 MFMA path against the scalar fp32 kernel, forward and gradients."""
+    d = H * dh
+    g = torch.Generator(device="cpu").manual_seed(17)
+    q32, kv32, x32 = torch.randn((B, Tq, d), generator=g) * 0.7, torch.randn((B, Tk, 2 * d), generator=g) * 0.7, torch.randn((B, Tq, d), generator=g)
+    rng = np.random.default_rng(4)
+    ql = torch.tensor(rng.integers(1, Tq + 1, size=B), dtype=torch.int32, device=cuda)
+    kl = torch.tensor(rng.integers(1, Tk + 1, size=B), dtype=torch.int32, device=cuda)
+    valid = (torch.arange(Tq, device=cuda)[None, :, None] < ql[:, None, None])
+    w = torch.randn((B, Tq, d), generator=g).to(cuda) * valid
+    outs, gq, gkv = [], [], []
+    for dt in (torch.float32, torch.bfloat16):
+        q = q32.to(torch.bfloat16).to(dt).to(cuda).requires_grad_(True)
+        kv = kv32.to(torch.bfloat16).to(dt).to(cuda).requires_grad_(True)
+        x = x32.to(torch.bfloat16).to(dt).to(cuda)
+        out = ops.AttnFn.apply(q, kv, x, ql, kl, H, d, False, 0xABCDEF, 0.9)
+        (out.float() * w).sum().backward()
+        outs.append(out.detach().float()); gq.append(q.grad.detach().float()); gkv.append(kv.grad.detach().float())
+    eo = ((outs[0] - outs[1]).abs() * valid).max().item() / outs[0].abs().mul(valid).max().item()
+    assert eo < 2e-2, eo
+    for a, b2 in ((gq[0], gq[1]), (gkv[0], gkv[1])):
+        e = (a - b2).abs().max().item() / a.abs().max().item()
+        assert e < 4e-2, e
