@@ -78,6 +78,13 @@ class Trainer:
         eng, st = self.engine, self.store
         wire = torch.bfloat16 if st.compute_dtype == torch.bfloat16 else None    # bf16 mode: gradient rows travel as bf16
         all_k, all_r, cap = parallel.allgather_sparse(uniq, grad_rows, n, st.total_rows, transport_dtype=wire)
+        return self.merge_gathered(all_k, all_r)
+
+    def merge_gathered(self, all_k, all_r):
+        """Second-level reduce of the rank-major (row id, gradient row) pairs: same stable sort + segment reduce as the
+        per-rank embedding gradient (also driven directly by scripts/dp_merge_bench.py with a synthetic 8-rank gather)."""
+        eng, st = self.engine, self.store
+        grad_rows = all_r
         N = all_k.numel()
         vals = torch.arange(N, dtype=torch.int32, device=all_k.device)
         keys_s = eng._buf("m_keys_s", (N,), torch.int32)
