@@ -100,6 +100,7 @@ _SIGS = {
     "dmt_adam_dense": [c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp],
     "dmt_adam_sparse_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp,
                              c_vp, c_f32, c_f32, c_f32, c_vp],
+    "dmt_adam_sparse_rows_bf16": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_catchup_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],

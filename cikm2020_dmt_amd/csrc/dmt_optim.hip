@@ -67,10 +67,20 @@ constexpr int SPARSE_GRID = 256 * 8;
 __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ void st4(float* q, const float4& x) { *reinterpret_cast<float4*>(q) = x; }
 
+// gradient rows as fp32 or (data-parallel wire format) bf16
+__device__ __forceinline__ float4 ldg4(const float* q) { return ld4(q); }
+__device__ __forceinline__ float4 ldg4(const bf16_t* q) {
+  const uint2 u = *reinterpret_cast<const uint2*>(q);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ float ldg1(const float* q) { return *q; }
+__device__ __forceinline__ float ldg1(const bf16_t* q) { return bf2f(*q); }
+
+template <typename GT>
 __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
                                                           float* __restrict__ v, int* __restrict__ last_step,
                                                           const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
-                                                          const float* __restrict__ grad_rows, int max_dim, float gscale,
+                                                          const GT* __restrict__ grad_rows, int max_dim, float gscale,
                                                           const float* __restrict__ state, const float* __restrict__ lr_hist,
                                                           float b1, float b2, float eps) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
@@ -81,15 +91,16 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
   const long long groups = (long long)gridDim.x * 16;   // 16-lane groups in the grid
   for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
     const int row = (int)uniq[u];
+    if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables]) continue;   // padding slot of a gathered (rank-major) row list
     const int t = find_table(tm, row);
     const int dim = tm.dim[t];
     const int last = last_step[row];
     const long long base = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim;
-    const float* gr = grad_rows + u * max_dim;
+    const GT* gr = grad_rows + u * max_dim;
     if ((dim & 3) == 0 && (max_dim & 3) == 0) {
       for (int j = c * 4; j < dim; j += 64) {
         float4 pv = ld4(p + base + j), mv = ld4(m + base + j), vv = ld4(v + base + j);
-        const float4 gv = ld4(gr + j);
+        const float4 gv = ldg4(gr + j);
         if (last + 1 <= step - 1) {
           catch_up(pv.x, mv.x, vv.x, last + 1, step - 1, lr_hist, c1, c2, eps);
           catch_up(pv.y, mv.y, vv.y, last + 1, step - 1, lr_hist, c1, c2, eps);
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
       for (int j = c; j < dim; j += 16) {
         float pv = p[base + j], mv = m[base + j], vv = v[base + j];
         catch_up(pv, mv, vv, last + 1, step - 1, lr_hist, c1, c2, eps);
-        adam_update(pv, mv, vv, gr[j] * gscale, a, c1, c2, eps);
+        adam_update(pv, mv, vv, ldg1(gr + j) * gscale, a, c1, c2, eps);
         p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
       }
     }
@@ -217,9 +228,24 @@ extern "C" int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m,
   DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_sparse_rows: bad table map / max_uniq");
   const long long need = cdiv64(max_uniq, 16);
   const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
-  hipLaunchKernelGGL(adam_sparse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
+  hipLaunchKernelGGL(adam_sparse_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
                      grad_rows, max_dim, grad_scale, state, lr_hist, beta1, beta2, eps);
   DMT_CHECK_LAUNCH("dmt_adam_sparse_rows");
+  return DMT_OK;
+}
+
+extern "C" int dmt_adam_sparse_rows_bf16(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                                         const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const void* grad_rows_bf16,
+                                         int32_t max_dim, float grad_scale, const float* state, const float* lr_hist, float beta1,
+                                         float beta2, float eps, void* stream) {
+  DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && grad_rows_bf16 && state && lr_hist, "dmt_adam_sparse_rows_bf16: null argument");
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_sparse_rows_bf16: bad table map / max_uniq");
+  DMT_CHECK_ARG(max_dim % 4 == 0 && ((uintptr_t)grad_rows_bf16 & 7) == 0, "dmt_adam_sparse_rows_bf16: rows must be 8-byte aligned, max_dim % 4 == 0");
+  const long long need = cdiv64(max_uniq, 16);
+  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
+  hipLaunchKernelGGL(adam_sparse_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
+                     reinterpret_cast<const bf16_t*>(grad_rows_bf16), max_dim, grad_scale, state, lr_hist, beta1, beta2, eps);
+  DMT_CHECK_LAUNCH("dmt_adam_sparse_rows_bf16");
   return DMT_OK;
 }
 

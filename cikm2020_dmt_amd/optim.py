@@ -64,6 +64,11 @@ class TFAdam:
     def apply_sparse(self, sparse, grad_scale: float = 1.0):
         s = self.store
         uniq, n_uniq, grad_rows, cap = sparse
+        if grad_rows.dtype == torch.bfloat16:      # reduced rows straight off the data-parallel wire
+            L.call("dmt_adam_sparse_rows_bf16", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+                   ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.shape[1]), float(grad_scale),
+                   ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, ops.stream_ptr())
+            return
         L.call("dmt_adam_sparse_rows", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
                ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.shape[1]), float(grad_scale),
                ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, ops.stream_ptr())

@@ -4,9 +4,11 @@ Reference semantics (run_dnn.py:45-87,148-207): every tower computes the loss me
 averaged over towers (mean of means) and one Adam step is applied.  Here:
   * dense parameters: ONE all-reduce(sum) of the flat fp32 gradient arena (13.7 MB at reference dims), scaled by
     1/world inside the Adam kernel;
-  * embedding tables: never densified.  Each rank's (row id, fp32 grad row) pairs -- already reduced per row on the
-    GPU -- are all-gathered (padded to the largest rank), concatenated in RANK ORDER and reduced again per row by
-    the same stable-sort + segment-reduce kernels, so every rank applies the identical update.
+  * embedding tables: never densified.  Each rank's (row id, grad row) pairs -- already reduced per row on the GPU -- go to
+    the row's OWNER rank (row % world) by all_to_all_single, are concatenated there in RANK ORDER and reduced again per row by
+    the same stable-sort + segment-reduce kernels; the reduced shards are all-gathered, so every rank applies the identical
+    update to its replica (exchange_to_owners / allgather_shards).  The older one-step form (all-gather everything, every
+    rank reduces everything: allgather_sparse) is kept behind Trainer(dp_exchange="allgather").
 The functions below only move data; they work on CPU tensors with the gloo backend (tests) and on device tensors
 with RCCL.
 """
@@ -73,6 +75,76 @@ def allgather_sparse(keys: torch.Tensor, rows: torch.Tensor, n: int, invalid_key
         return k_loc, r_loc, cap
     all_k = torch.empty((W * cap,), dtype=keys.dtype, device=dev)
     all_r = torch.empty((W * cap, D), dtype=r_loc.dtype, device=dev)
+    _all_gather_cat(all_k, k_loc, W, cap)
+    _all_gather_cat(all_r, r_loc.contiguous(), W, cap)
+    return all_k, all_r, cap
+
+
+def _a2a(dst: torch.Tensor, src: torch.Tensor, recv_splits, send_splits):
+    """all_to_all_single along dim 0 with uneven splits.  RCCL moves device tensors directly (one send/recv per peer: on the
+    xGMI full mesh every pair has its own link); gloo (tests) only implements the CPU form, so device tensors are staged."""
+    if dist.get_backend() != "nccl" and src.is_cuda:
+        d_cpu = torch.empty(dst.shape, dtype=dst.dtype)
+        dist.all_to_all_single(d_cpu, src.cpu(), recv_splits, send_splits)
+        dst.copy_(d_cpu)
+        return
+    dist.all_to_all_single(dst, src, recv_splits, send_splits)
+
+
+def owner_of(keys: torch.Tensor, W: int) -> torch.Tensor:
+    """Owner rank of a global row id in the owner-reduce exchange: interleaved (row % W), so the hot low ids of a Zipf law
+    spread evenly over the ranks."""
+    return torch.remainder(keys, W)
+
+
+def exchange_to_owners(keys: torch.Tensor, rows: torch.Tensor, n: int, transport_dtype=None):
+    """First half of the owner-reduce exchange.  keys [>= n] int32 distinct row ids of this rank, rows [>= n, D] their
+    gradient rows.  Every (key, row) pair travels to rank key % W -- ONE all_to_all_single for the keys and one for the rows
+    (bf16 on the wire when transport_dtype says so) -- and arrives concatenated in RANK ORDER, which keeps the order of
+    summation of the reference's tower loop (run_dnn.py:45-80).  Returns (recv_keys [R], recv_rows [R, D])."""
+    rank, W = world()
+    dev = keys.device
+    k = keys[:n]
+    owner = owner_of(k, W)
+    _so, perm = torch.sort(owner, stable=True)           # per-owner slices, each still ascending in key
+    counts = torch.bincount(owner.long(), minlength=W)
+    rows_mat = [torch.zeros_like(counts) for _ in range(W)]
+    dist.all_gather(rows_mat, counts)
+    M = torch.stack(rows_mat).cpu()                      # M[s, d] = pairs rank s sends to rank d  (the one host sync)
+    send_splits, recv_splits = M[rank].tolist(), M[:, rank].tolist()
+    send_k = k.index_select(0, perm)
+    send_r = rows[:n].index_select(0, perm)
+    if transport_dtype is not None and transport_dtype != send_r.dtype:
+        send_r = send_r.to(transport_dtype)
+    R = int(sum(recv_splits))
+    recv_k = torch.empty((R,), dtype=keys.dtype, device=dev)
+    recv_r = torch.empty((R, rows.shape[1]), dtype=send_r.dtype, device=dev)
+    _a2a(recv_k, send_k.contiguous(), recv_splits, send_splits)
+    _a2a(recv_r, send_r.contiguous(), recv_splits, send_splits)
+    return recv_k, recv_r
+
+
+def allgather_shards(keys: torch.Tensor, rows: torch.Tensor, m: int, invalid_key: int, transport_dtype=None):
+    """Second half: every owner's reduced shard (m distinct keys, rows [>= m, D]) goes to every rank.  Shards are padded to the
+    largest one (interleaved ownership keeps them within a few per cent of each other); padding slots carry `invalid_key`,
+    which the optimizer kernels skip.  Returns (all_keys [W*cap], all_rows [W*cap, D], cap)."""
+    rank, W = world()
+    dev = keys.device
+    cnt = torch.tensor([m], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(W)]
+    dist.all_gather(cnts, cnt)
+    cap = max(1, int(torch.stack(cnts).max().item()))
+    k_loc = torch.full((cap,), invalid_key, dtype=keys.dtype, device=dev)
+    k_loc[:m] = keys[:m]
+    if rows.shape[0] >= cap:
+        r_loc = rows[:cap]
+    else:
+        r_loc = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=dev)
+        r_loc[:m] = rows[:m]
+    if transport_dtype is not None and transport_dtype != r_loc.dtype:
+        r_loc = r_loc.to(transport_dtype)
+    all_k = torch.empty((W * cap,), dtype=keys.dtype, device=dev)
+    all_r = torch.empty((W * cap, rows.shape[1]), dtype=r_loc.dtype, device=dev)
     _all_gather_cat(all_k, k_loc, W, cap)
     _all_gather_cat(all_r, r_loc.contiguous(), W, cap)
     return all_k, all_r, cap

@@ -301,6 +301,12 @@ int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m, float* v, 
                          const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* grad_rows,
                          int32_t max_dim, float grad_scale, const float* state, const float* lr_hist, float beta1,
                          float beta2, float eps, void* stream);
+/* The same with bf16 gradient rows (the data-parallel wire format of the reduced rows).  Both variants skip keys
+ * >= the total row count: padding slots of a rank-major gathered list.                                          */
+int dmt_adam_sparse_rows_bf16(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                              const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq,
+                              const void* grad_rows_bf16, int32_t max_dim, float grad_scale, const float* state,
+                              const float* lr_hist, float beta1, float beta2, float eps, void* stream);
 /* Replay the pending zero-gradient steps of the listed rows up to the last COMPLETED step (state.step): must run
  * before the forward pass gathers those rows, so the values read are the ones the dense sweep would have produced. */
 int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,

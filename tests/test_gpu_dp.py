@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, steps, bf16=False):
+def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
     import torch.distributed as dist
     from cikm2020_dmt_amd.train import Trainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, steps, bf16=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
-    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dp_exchange=dp_exchange)
     tr.store.load_state(P)
     losses = []
     for s in range(steps):
@@ -112,3 +112,67 @@ def test_two_rank_bf16_mode_replicas_identical_and_close_to_oracle(cuda):
     # one Adam step moves every touched parameter by ~lr regardless of the gradient's magnitude: after 2 steps |dp| <= ~2e-3
     worst = max(float(np.abs(got[k] - P[k]).max()) for k in P)
     assert worst < 5e-3, worst
+
+
+def _run(world, steps, bf16, dp_exchange):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps, bf16, dp_exchange)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    return res
+
+
+def test_owner_reduce_exchange_equals_allgather_exchange(cuda):
+    """The two transports of the embedding-gradient rows (owner-reduce: all_to_all + all-gather of reduced shards; and the
+    one-step all-gather with a full second-level reduce on every rank) sum the same pairs in the same rank order: in fp32
+    mode the replicas after two steps are bit-identical, on both ranks."""
+    a = _run(2, 2, False, "owner")
+    b = _run(2, 2, False, "allgather")
+    for k in a[0][2]:
+        assert np.array_equal(a[0][2][k], a[1][2][k]), k
+        assert np.array_equal(a[0][2][k], b[0][2][k]), k
+    assert a[0][1] == b[0][1]
+
+
+def _nccl_world1(q):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    keys = torch.sort(torch.randperm(5000, generator=g)[:700]).values.to(torch.int32).to(dev)
+    rows = torch.randn((700, 64), generator=g).to(dev)
+    rk, rr = parallel.exchange_to_owners(keys, rows, 700, transport_dtype=torch.bfloat16)
+    ok1 = torch.equal(rk, keys) and torch.equal(rr, rows.to(torch.bfloat16))
+    ak, ar, cap = parallel.allgather_shards(rk, rr.float(), 700, 5000, transport_dtype=torch.bfloat16)
+    ok2 = cap == 700 and torch.equal(ak, keys) and torch.equal(ar, rows.to(torch.bfloat16))
+    flat = torch.ones(1000, device=dev)
+    w = parallel.allreduce_dense_(flat, async_op=True)
+    if w is not None:
+        w.wait()
+    torch.cuda.synchronize()
+    q.put((bool(ok1), bool(ok2), float(flat.sum())))
+    dist.destroy_process_group()
+
+
+def test_rccl_accepts_the_exchange_calls_single_rank(cuda):
+    """A one-GPU box cannot run two RCCL ranks; a ONE-rank RCCL communicator still runs the exact collectives of the N-rank
+    step (all_to_all_single with uneven-split lists on int32 / bf16 device tensors, all_gather_into_tensor, all_reduce), so
+    argument / dtype problems surface here rather than in the 8-GPU run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_nccl_world1, args=(q,))
+    p_.start()
+    ok1, ok2, s = q.get(timeout=300)
+    p_.join(60)
+    assert p_.exitcode == 0
+    assert ok1 and ok2 and s == 1000.0

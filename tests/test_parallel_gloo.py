@@ -111,3 +111,62 @@ def test_single_process_paths_are_noops():
     k, r, cap = parallel.allgather_sparse(torch.tensor([3, 9, 0], dtype=torch.int32), torch.ones((3, 2)), 2, 100)
     assert cap == 2 and k.tolist() == [3, 9] and r.shape == (2, 2)
     assert float(parallel.mean_scalar(torch.tensor(2.5))) == 2.5
+
+
+# ------------------------------------------------------------------------------------------------ owner-reduce exchange
+def _rank_rows(rank, total, D):
+    rng = np.random.default_rng(900 + rank)
+    n = int(rng.integers(40, 80))
+    hot = np.arange(12)                                                       # rows every rank touches (the Zipf head)
+    keys = np.unique(np.concatenate([hot, rng.choice(total, size=n, replace=False)])).astype(np.int32)
+    rows = rng.standard_normal((len(keys), D)).astype(np.float32)
+    return keys, rows
+
+
+def _owner_worker(rank, world, port, q, total, D):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    keys, rows = _rank_rows(rank, total, D)
+    n = len(keys)
+    k_t = torch.tensor(np.concatenate([keys, np.zeros(5, np.int32)]))         # buffers may be larger than n
+    r_t = torch.tensor(np.concatenate([rows, np.zeros((5, D), np.float32)]))
+    rk, rr = parallel.exchange_to_owners(k_t, r_t, n)
+    assert bool((torch.remainder(rk, world) == rank).all())                   # only rows this rank owns arrive
+    # second-level reduce in arrival (= rank) order: what merge_gathered's stable sort + segment reduce does on the GPU
+    order = np.argsort(rk.numpy(), kind="stable")
+    ks, rs = rk.numpy()[order], rr.numpy()[order]
+    uk, start = np.unique(ks, return_index=True)
+    red = np.add.reduceat(rs.astype(np.float64), start, axis=0).astype(np.float32) if len(ks) else np.zeros((0, D), np.float32)
+    all_k, all_r, cap = parallel.allgather_shards(torch.tensor(uk.astype(np.int32)), torch.tensor(red), len(uk), total)
+    assert all_k.numel() == world * cap and bool((all_k[rank * cap + len(uk): (rank + 1) * cap] == total).all())
+    valid = all_k < total
+    q.put((rank, all_k[valid].numpy(), all_r[valid].numpy(), int(rk.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_owner_reduce_exchange_sums_every_row_once():
+    world, total, D = 3, 1000, 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q, total, D)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    want = {}
+    for r in range(world):
+        keys, rows = _rank_rows(r, total, D)
+        for k, row in zip(keys, rows):
+            want[int(k)] = want.get(int(k), 0) + row.astype(np.float64)
+    for rank, ks, rs, received in res:
+        assert sorted(ks.tolist()) == sorted(want)                             # the union, every row exactly once
+        for k, row in zip(ks, rs):
+            assert np.abs(row - want[int(k)]).max() < 1e-5
+        assert np.array_equal(ks, res[0][1]) and np.array_equal(rs, res[0][2])  # identical on every rank (same order too)
+    assert sum(t[3] for t in res) == sum(len(_rank_rows(r, total, D)[0]) for r in range(world))   # each pair travelled once
