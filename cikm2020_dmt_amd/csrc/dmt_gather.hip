@@ -339,14 +339,25 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   // invalid keys sort last: the number of valid entries of this chunk
   const unsigned long long vmask = __ballot(my_seg >= 0);
   const int cnt = __popcll(vmask);
-  // ---- phase B
+  // ---- phase B.  Only the first and the last run of this chunk can continue in a neighbouring chunk: those two are added
+  //      atomically onto the pre-zeroed rows, every run in between is complete here and is stored.
+  const int first_seg = __shfl(my_seg, 0, 64);
+  int last_seg = my_seg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_xor(last_seg, o, 64); last_seg = t2 > last_seg ? t2 : last_seg; }   // run ids ascend
   float acc = 0.f;
   int cur_seg = -1, cur_dim = 0;
-  for (int i0 = 0; i0 < cnt; i0 += 4) {
-    float v[4], sc[4];
-    int sg[4], dm[4];
+  auto flush = [&]() {
+    if (cur_seg < 0 || lane >= cur_dim) return;
+    float* dst = &grad_rows[(long long)cur_seg * max_dim + lane];
+    if (cur_seg == first_seg || cur_seg == last_seg) atomicAdd(dst, acc); else *dst = acc;
+  };
+  constexpr int NBATCH = 4;   // gathers in flight per wave (8 measured the same)
+  for (int i0 = 0; i0 < cnt; i0 += NBATCH) {
+    float v[NBATCH], sc[NBATCH];
+    int sg[NBATCH], dm[NBATCH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NBATCH; ++k) {
       const int i = (i0 + k < cnt) ? i0 + k : cnt - 1;
       const unsigned lo = __shfl(my_lo, i, 64), hi = __shfl(my_hi, i, 64);
       sc[k] = __shfl(my_scale, i, 64);
@@ -354,17 +365,19 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
       const int dmf = __shfl(my_dim, i, 64);
       dm[k] = dmf & 0xFFFF;
       const GT_* src = reinterpret_cast<const GT_*>(((unsigned long long)hi << 32) | lo);
-      v[k] = (lane < dm[k]) ? ldf<GT_>(src + lane) : 0.f;
-      if (drop_on && (dmf >> 16)) {   // wave-uniform
-        const uint32_t sd = __shfl(my_dseed, i, 64), fl = __shfl(my_flat, i, 64);
-        if (!dmt_drop_keep(sd, fl + lane, drop_thr)) v[k] = 0.f;
-      }
+      // branch-free on purpose: a predicated load (or a mask applied right behind it) makes the compiler wait for this row
+      // before it requests the next one, and the four gathers of a batch then pay four memory latencies instead of one
+      const int ln = lane < dm[k] ? lane : dm[k] - 1;
+      v[k] = ldf<GT_>(src + ln);
+      const uint32_t sd = __shfl(my_dseed, i, 64), fl = __shfl(my_flat, i, 64);
+      const bool dropped = drop_on && (dmf >> 16) && !dmt_drop_keep(sd, fl + lane, drop_thr);
+      sc[k] = (lane < dm[k] && !dropped) ? sc[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NBATCH; ++k) {
       if (i0 + k >= cnt) break;
       if (sg[k] != cur_seg) {
-        if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
+        flush();
         acc = 0.f;
         cur_seg = sg[k];
         cur_dim = dm[k];
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
       acc += sc[k] * v[k];
     }
   }
-  if (cur_seg >= 0 && lane < cur_dim) atomicAdd(&grad_rows[(long long)cur_seg * max_dim + lane], acc);
+  flush();
 }
 
 template <typename RT>
@@ -406,6 +419,8 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
       if (cur_seg == first_seg || cur_seg == last_seg) atomicAdd(dst, acc); else *dst = acc;
     };
     // eight row loads in flight per wave (the entries are known up front; summing stays in sorted order)
+    if (first_seg < 0) break;                                       // sorted: no valid entry in this chunk at all
+    const uint32_t ev0 = __shfl(my_val, 0, 64);
     for (int i0 = 0; i0 < cnt; i0 += 8) {
       float x[8];
       int sg[8];
@@ -414,7 +429,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
         const int i = (i0 + u < cnt) ? i0 + u : cnt - 1;
         const uint32_t ev = __shfl(my_val, i, 64);
         sg[u] = (i0 + u < cnt) ? __shfl(my_seg, i, 64) : -1;      // -1: past the end or an invalid (padding) key
-        x[u] = (sg[u] >= 0 && j < max_dim) ? ldf<RT>(in_rows + (long long)ev * max_dim + j) : 0.f;
+        // branch-free (a predicated load would be waited for before the next one is requested): padding entries re-read
+        // the row of entry 0, which is valid whenever the chunk has any valid entry, and are dropped below by sg < 0
+        const uint32_t evs = sg[u] >= 0 ? ev : ev0;
+        x[u] = ldf<RT>(in_rows + (long long)evs * max_dim + (j < max_dim ? j : max_dim - 1));
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
