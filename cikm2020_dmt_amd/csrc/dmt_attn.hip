@@ -1359,10 +1359,9 @@ __device__ __forceinline__ float group16_sum(float v) {
 __device__ __forceinline__ float cross_group_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 __device__ __forceinline__ float cross_group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
-template <int DH, bool BWD>
+template <int DH, bool BWD, int NIT>      // NIT: 4-row passes, Tk <= 4 * NIT (the row registers are sized by it)
 __global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
   constexpr int CPR = DH / 8;      // 16-byte chunks per row
-  constexpr int NIT = 16;          // 4 rows per iteration, Tk <= 64
   const int lane = threadIdx.x & 63;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (long long)a.B * a.H) return;
@@ -1375,17 +1374,19 @@ __global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
   const int qlen = a.q_lens ? a.q_lens[b] : 1;
   const float sc = sqrtf((float)DH);
   const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH + c * 8;
-  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH + c * 8;
-  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH + c * 8;
   const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-
+  // All K / V row requests go out back to back and BRANCH-FREE: a predicated load is waited for before the next one is
+  // issued (the first version paid 16 serial round trips per wave).  Lanes past the row (c >= CPR) and rows past Tk re-read a
+  // valid chunk / the last row instead; what they load is kept out of every sum below.
+  const int cc = cact ? c : CPR - 1;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH + cc * 8;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH + cc * 8;
   uint4 Kr[NIT], Vr[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int k = it * 4 + g;
-    const bool ok = cact && (k < Tk);
-    Kr[it] = (it * 4 < Tk && ok) ? *reinterpret_cast<const uint4*>(Kg + (long long)k * a.k_rs) : z4;
-    Vr[it] = (it * 4 < Tk && ok) ? *reinterpret_cast<const uint4*>(Vg + (long long)k * a.v_rs) : z4;
+    const int k = it * 4 + g, kc = k < Tk ? k : Tk - 1;
+    Kr[it] = *reinterpret_cast<const uint4*>(Kg + (long long)kc * a.k_rs);
+    Vr[it] = *reinterpret_cast<const uint4*>(Vg + (long long)kc * a.v_rs);
   }
   float q[8], dO[8];
   {
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
       float d0 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) d0 = fmaf(q[e], kf[e], d0);
-      d0 = group16_sum(d0);
+      d0 = group16_sum(cact ? d0 : 0.f);
       const int k = it * 4 + g;
       float x = d0 / sc;
       if (k >= klen) x = PADDING_NUM;
@@ -1421,7 +1422,7 @@ __global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
         float d1 = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d1 = fmaf(dO[e], vf[e], d1);
-        dP[it] = group16_sum(d1);
+        dP[it] = group16_sum(cact ? d1 : 0.f);
       }
     }
   }
@@ -1513,13 +1514,20 @@ __global__ __launch_bounds__(256) void attn_q1v_kernel(const AttnArgs a) {
 template <bool BWD>
 int launch_q1v(const AttnArgs& a, hipStream_t st) {
   const unsigned nb = (unsigned)cdiv64((long long)a.B * a.H, 4);
+  if (a.Tk < 1 || a.Tk > 64) return -1;
+#define DMT_Q1V(DHV) do { \
+    if (a.Tk <= 12) hipLaunchKernelGGL((attn_q1v_kernel<DHV, BWD, 3>), dim3(nb), dim3(256), 0, st, a); \
+    else if (a.Tk <= 32) hipLaunchKernelGGL((attn_q1v_kernel<DHV, BWD, 8>), dim3(nb), dim3(256), 0, st, a); \
+    else if (a.Tk <= 52) hipLaunchKernelGGL((attn_q1v_kernel<DHV, BWD, 13>), dim3(nb), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((attn_q1v_kernel<DHV, BWD, 16>), dim3(nb), dim3(256), 0, st, a); } while (0)
   switch (a.dh) {
-    case 16: hipLaunchKernelGGL((attn_q1v_kernel<16, BWD>), dim3(nb), dim3(256), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((attn_q1v_kernel<32, BWD>), dim3(nb), dim3(256), 0, st, a); break;
-    case 64: hipLaunchKernelGGL((attn_q1v_kernel<64, BWD>), dim3(nb), dim3(256), 0, st, a); break;
-    case 80: hipLaunchKernelGGL((attn_q1v_kernel<80, BWD>), dim3(nb), dim3(256), 0, st, a); break;
+    case 16: DMT_Q1V(16); break;
+    case 32: DMT_Q1V(32); break;
+    case 64: DMT_Q1V(64); break;
+    case 80: DMT_Q1V(80); break;
     default: return -1;
   }
+#undef DMT_Q1V
   return 0;
 }
 
@@ -1617,10 +1625,15 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (d->Tq == 1 && q1_aligned(d->dtype, d->Q, d->q_bs, d->q_rs, d->dh) && q1_aligned(d->dtype, d->K, d->k_bs, d->k_rs, d->dh) &&
       q1_aligned(d->dtype, d->V, d->v_bs, d->v_rs, d->dh)) {
-    // (the lanes-along-dh kernel attn_q1v_kernel<.., false> measured 2x SLOWER than this one for the forward: 128 vs 65 us,
-    //  65 us = K and V read once at 4 TB/s; it pays only in the backward, which also writes dK / dV rows.  Routing Tq = 1
-    //  through the coalesced MFMA kernels (NTQ = 1, NTK = 2) measured the same step time as these two kernels, forward and
-    //  backward, so the simpler kernels stay.)
+    // bf16 with 16-byte aligned rows: the lanes-along-dh kernel (coalesced row chunks, all K / V requests in flight at once:
+    // 73 us forward / 116 us backward at B=4096, T=50 against 65-85 / 240 us before its loads were made branch-free).  Routing
+    // Tq = 1 through the coalesced MFMA kernels (NTQ = 1, NTK = 2) measured no better, so the simple kernels stay.
+    if (d->dtype == DMT_BF16 && d->Tk <= 64 && q1v_aligned(d->Q, d->q_bs, d->q_rs) && q1v_aligned(d->K, d->k_bs, d->k_rs) &&
+        q1v_aligned(d->V, d->v_bs, d->v_rs) && q1v_aligned(d->out, d->o_bs, d->o_rs) && q1v_aligned(d->resid, d->r_bs, d->r_rs) &&
+        launch_q1v<false>(a, st) == 0) {
+      DMT_CHECK_LAUNCH("dmt_attn_fwd(q1v)");
+      return DMT_OK;
+    }
     const int r1 = (d->dtype == DMT_F32) ? launch_q1<float, false>(a, st) : launch_q1<bf16_t, false>(a, st);
     if (r1 == 0) { DMT_CHECK_LAUNCH("dmt_attn_fwd(q1)"); return DMT_OK; }
   }
