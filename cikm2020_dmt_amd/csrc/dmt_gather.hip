@@ -128,28 +128,42 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
     OutT* out = reinterpret_cast<OutT*>(g.seq_out) + (long long)b * g.seq_T * g.d_model;
     const int nch = g.d_model / VEC;
     const int items = g.seq_T * nch;
-    for (int it = tid; it < items; it += GT) {
-      const int t = it / nch, c = it - t * nch;
-      const int f = s_colfeat[c];
-      const GFeat& F = g.f[f];
-      const int col = c * VEC;
-      const int id = (t < Tmax) ? s_idx[f * Tmax + t] : 0;
-      float v[VEC];
+    // U items per thread and pass, all table / position requests issued BRANCH-FREE before the first use (a predicated load
+    // is waited for before the next one goes out: one memory latency per item instead of one per pass).  Padding ids (0 ->
+    // the all-zero row of [0;E]) and items past the end read a valid row and are masked afterwards.
+    constexpr int U = 4;
+    const float* posp = g.pos ? g.pos : g.f[0].table;
+    const float pos_on = g.pos ? 1.f : 0.f;
+    for (int it0 = tid; it0 < items; it0 += GT * U) {
+      float v[U][VEC], p[U][VEC];
+      int tt[U], cl[U];
+      float keep[U];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) v[k] = 0.f;
-      if (id > 0) ld_row<VEC>(F.table + (long long)(id - 1) * F.dim + (col - F.seq_off), v);
-      float p[VEC];
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) p[k] = 0.f;
-      if (g.pos) ld_row<VEC>(g.pos + (long long)t * g.d_model + col, p);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) v[k] = g.scale * v[k] + p[k];
-      if (g.drop_inv != 0.f) {
-        const uint32_t flat = (uint32_t)(((long long)b * g.seq_T + t) * g.d_model + col);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) v[k] = dmt_drop_keep(g.drop_seed, flat + k, g.drop_thr) ? v[k] * g.drop_inv : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * GT;
+        const int itc = it < items ? it : items - 1;
+        const int t = itc / nch, c = itc - t * nch;
+        const int f = s_colfeat[c];
+        const GFeat& F = g.f[f];
+        const int col = c * VEC;
+        const int id = (t < Tmax) ? s_idx[f * Tmax + t] : 0;
+        tt[u] = t; cl[u] = col;
+        keep[u] = (id > 0) ? g.scale : 0.f;
+        ld_row<VEC>(F.table + (long long)(id > 0 ? id - 1 : 0) * F.dim + (col - F.seq_off), v[u]);
+        ld_row<VEC>(posp + (g.pos ? (long long)t * g.d_model + col : 0ll), p[u]);   // (no positions: a dummy in-bounds read)
       }
-      st_vec<OutT, VEC>(out + (long long)t * g.d_model + col, v);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (it0 + u * GT >= items) break;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[u][k] = keep[u] * v[u][k] + pos_on * p[u][k];
+        if (g.drop_inv != 0.f) {
+          const uint32_t flat = (uint32_t)(((long long)b * g.seq_T + tt[u]) * g.d_model + cl[u]);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) v[u][k] = dmt_drop_keep(g.drop_seed, flat + k, g.drop_thr) ? v[u][k] * g.drop_inv : 0.f;
+        }
+        st_vec<OutT, VEC>(out + (long long)tt[u] * g.d_model + cl[u], v[u]);
+      }
     }
   }
 
@@ -170,14 +184,20 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
         const GFeat& F = g.f[f];
         const int cc = s_chunkcol[c];
         const int Tf = F.T < Tmax ? F.T : Tmax;
-        for (int t = r; t < Tf; t += R) {
-          const float w = s_w[f * Tmax + t];
-          if (w != 0.f) {
-            float v[VEC];
-            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + t] * F.dim + cc, v);
+        // four rows in flight, branch-free (w == 0 for padding / past-the-end steps; their ids are valid rows)
+        for (int t0 = r; t0 < Tf; t0 += 4 * R) {
+          float v[4][VEC], w[4];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] += w * v[k];
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * R;
+            const int tc = t < Tf ? t : Tf - 1;
+            w[u] = t < Tf ? s_w[f * Tmax + tc] : 0.f;
+            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + tc] * F.dim + cc, v[u]);
           }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] += w[u] * v[u][k];
         }
       }
       __syncthreads();
