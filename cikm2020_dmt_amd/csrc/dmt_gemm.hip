@@ -903,9 +903,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //   * the all-ones row that yields the bias gradient is a COLUMN of this image: in the one M tile that holds it, 64 threads
 //     rewrite that column after the DMA has landed (one extra barrier per k-step, that tile only).
 //   * same 2-stage DMA pipeline / persistent tile loop as gemm_glds_kernel; epilogue = fp32 atomics (split-K / accumulate).
+//   * BKS k rows per DMA stage, NS stages (two workgroups per CU either way: NS * BKS * 512 B = 64 KB).  The kernel is bound by
+//     the latency of its operand stream, i.e. by the bytes in flight per CU: <64, 2> keeps one 32 KB stage in flight per
+//     workgroup, <32, 4> three 16 KB stages.
+template <int BKS, int NS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dw_glds_kernel(const GemmArgs g) {
-  constexpr int STAGE = 32768;   // A image 16 KB | B image 16 KB
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int OPB = BKS * 256;     // bytes of one operand image: [BKS k][128 rows] bf16
+  constexpr int STAGE = 2 * OPB;     // A image | B image
+  constexpr int RND = BKS / 16;      // DMA rounds per operand and stage (a round = 16 k rows = 4 per wave)
+  constexpr int LPS = 2 * RND;       // DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   typedef __attribute__((address_space(3))) void* lds_vp;
   typedef __attribute__((address_space(3))) bf16x4_t* lds_p4;
   typedef bf16_t T;
@@ -929,11 +936,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0) {
     unsigned char* sb = smem + stage * STAGE + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < RND; ++p)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(sb + p * 4096), 16, a_voff, (int)((k0 + p * 16) * a_kb), 0, 0);
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, b_voff, (int)((k0 + p * 16) * b_kb), 0, 0);
+    for (int p = 0; p < RND; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + OPB + p * 4096), 16, b_voff, (int)((k0 + p * 16) * b_kb), 0, 0);
   };
   f32x16_t acc[2][2];
   // The fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) for an LDS-DMA in
@@ -942,7 +949,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // means slice s has arrived.  The waits name the registers they release ("+v") so no MFMA is scheduled above them.
   const unsigned lds0 = (unsigned)(unsigned long long)((lds_vp)smem);
   const unsigned aA0 = lds0 + fr_chunk(wm * 2 + 0), aA1 = lds0 + fr_chunk(wm * 2 + 1);
-  const unsigned aB0 = lds0 + 16384 + fr_chunk(wn * 2 + 0), aB1 = lds0 + 16384 + fr_chunk(wn * 2 + 1);
+  const unsigned aB0 = lds0 + OPB + fr_chunk(wn * 2 + 0), aB1 = lds0 + OPB + fr_chunk(wn * 2 + 1);
 #define DMT_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define DMT_TR_SLICE(R, so, kk)                                                                             \
   DMT_TR_READ(R[0], aA0 + so, (kk) * 256); DMT_TR_READ(R[1], aA0 + so, (kk) * 256 + 1024);                    \
@@ -966,12 +973,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     DMT_TR_SLICE(r1, so, 16)
     DMT_TR_WAIT(r0, 8);
     DMT_TR_MFMA(r0)
-    DMT_TR_SLICE(r0, so, 32)
-    DMT_TR_WAIT(r1, 8);
-    DMT_TR_MFMA(r1)
-    DMT_TR_SLICE(r1, so, 48)
-    DMT_TR_WAIT(r0, 8);
-    DMT_TR_MFMA(r0)
+    if constexpr (BKS == 64) {
+      DMT_TR_SLICE(r0, so, 32)
+      DMT_TR_WAIT(r1, 8);
+      DMT_TR_MFMA(r1)
+      DMT_TR_SLICE(r1, so, 48)
+      DMT_TR_WAIT(r0, 8);
+      DMT_TR_MFMA(r0)
+    }
     DMT_TR_WAIT(r1, 0);
     DMT_TR_MFMA(r1)
   };
@@ -985,14 +994,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const T* Ag = reinterpret_cast<const T*>(g.A);
   const T* Bg = reinterpret_cast<const T*>(g.B);
   const int G = (int)gridDim.x;
+  // issue cursor: runs NS-1 k-steps ahead of the compute cursor through the same (tile, k-step) sequence, across tile ends
+  int iL = (int)blockIdx.x, ik = 0, ik_end = 0, istage = 0, inflight = 0;
+  bool ivalid = false;
+  __amdgpu_buffer_rsrc_t ira = rsrc_of(Ag, g.a_cs, 0, M_real), irb = rsrc_of(Bg, g.b_rs, 0, g.N);
+  auto itile = [&]() {
+    ivalid = false;
+    for (; iL < g.total_blocks; iL += G) {
+      const TileCoord ti = decode_tile(g, iL);
+      if (!ti.valid) continue;
+      ira = rsrc_of(Ag, g.a_cs, ti.m0, M_real); irb = rsrc_of(Bg, g.b_rs, ti.n0, g.N);
+      ik = ti.k_begin; ik_end = ti.k_end; ivalid = true;
+      return;
+    }
+  };
+  auto issue_next = [&]() {
+    if (!ivalid) return;
+    issue(istage, ira, irb, ik);
+    istage = (istage + 1 == NS) ? 0 : istage + 1;
+    ++inflight;
+    ik += BKS;
+    if (ik >= ik_end) { iL += G; itile(); }
+  };
+  itile();
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0) issue_next();
   int cur = 0;
-  bool pre = false;
   for (int L = (int)blockIdx.x; L < g.total_blocks; L += G) {
     const TileCoord t = decode_tile(g, L);
     if (!t.valid) continue;
     const int m0 = t.m0, n0 = t.n0, ks = t.ks;
-    const __amdgpu_buffer_rsrc_t ra = rsrc_of(Ag, g.a_cs, m0, M_real);
-    const __amdgpu_buffer_rsrc_t rb = rsrc_of(Bg, g.b_rs, n0, g.N);
     const bool ones_here = (ones_row >= m0 && ones_row < m0 + BM);
     const int ones_ml = ones_row - m0;
 #pragma unroll
@@ -1001,30 +1032,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (!pre) issue(cur, ra, rb, t.k_begin);
-    pre = false;
-    for (int k0 = t.k_begin; k0 < t.k_end; k0 += 64) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // stage `cur` landed for every wave; every wave has left stage cur^1
-      if (ones_here) {                       // the bias-gradient row: column `ones_ml` of the A image := 1.0 (no DMA is in flight here)
-        if (tid < 64) {
-          unsigned char* q = smem + cur * STAGE + tid * 256 + (((ones_ml >> 5) ^ (tid & 3)) * 64) + (ones_ml & 31) * 2;
-          *reinterpret_cast<bf16_t*>(q) = (bf16_t)0x3F80;
+    for (int k0 = t.k_begin; k0 < t.k_end; k0 += BKS) {
+      // stage `cur` must have landed: at most (inflight - 1) younger stages (LPS DMA instructions each) may still be out.  The
+      // first k-step of a tile follows an epilogue whose atomics also count in vmcnt and may retire out of order with the
+      // loads, so it drains everything.
+      if (k0 == t.k_begin || inflight <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      __builtin_amdgcn_s_barrier();          // stage `cur` landed for every wave; every wave has left the stage before it
+      if (ones_here) {                       // the bias-gradient row: column `ones_ml` of the A image := 1.0
+        if (tid < BKS) {
+          const unsigned q = lds0 + (unsigned)(cur * STAGE + tid * 256 + (((ones_ml >> 5) ^ (tid & 3)) * 64) + (ones_ml & 31) * 2);
+          const unsigned one = 0x3F80u;
+          asm volatile("ds_write_b16 %0, %1" ::"v"(q), "v"(one) : "memory");   // (asm: a visible LDS store would wait for all DMA)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
-      if (k0 + 64 < t.k_end) {
-        issue(cur ^ 1, ra, rb, k0 + 64);
-      } else if (L + G < g.total_blocks) {   // last k-step: request the first stage of this workgroup's next tile
-        const TileCoord tn = decode_tile(g, L + G);
-        if (tn.valid) {
-          issue(cur ^ 1, rsrc_of(Ag, g.a_cs, tn.m0, M_real), rsrc_of(Bg, g.b_rs, tn.n0, g.N), tn.k_begin);
-          pre = true;
-        }
-      }
+      issue_next();                          // refills the stage consumed in the previous k-step
       compute(cur);
-      cur ^= 1;
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      --inflight;
     }
     // (the next k-step's barrier orders these reads of the stage against its next DMA: that DMA is only issued after it)
 
@@ -1128,7 +1156,11 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok && batch == 1 &&
                        (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
   if (dw_glds) {
-    hipLaunchKernelGGL(gemm_dw_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
+    const dim3 gd((unsigned)(nblk < GL_GRID ? nblk : GL_GRID));
+    // long reductions (the 204800-row weight gradients) run three 16 KB stages ahead, short ones one 32 KB stage:
+    // measured +3..7 % resp. -8 % for the other choice
+    if ((long long)d->K / split > 4096) hipLaunchKernelGGL((gemm_dw_glds_kernel<32, 4>), gd, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_dw_glds_kernel<64, 2>), gd, dim3(NT), 0, st, g);
   } else if (glds) {
     hipLaunchKernelGGL(gemm_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
   } else if (d->in_dtype == DMT_F32) {
