@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--law", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
+    ap.add_argument("--long-seq", type=int, default=0, help="BASELINE long-seq variant: click / order histories of this length (e.g. 200) instead of 50")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -71,12 +72,16 @@ def main():
     from cikm2020_dmt_amd.train import Trainer
 
     sp = S.e64_spec() if args.dims == "e64" else S.default_spec()
+    seq_lens = None
+    if args.long_seq:
+        sp = dict(sp, maxlen_k=max(sp["maxlen_k"], args.long_seq))
+        seq_lens = {grp[0][0]: args.long_seq for grp in sp["attention_embed_pairs"][:2]}
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout)
     nb = 4
     batches = []
     for i in range(nb):
-        inputs, mask, label = make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law)
+        inputs, mask, label = make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law, seq_lens=seq_lens)
         batches.append(tr.make_batch(inputs, mask, label))
     del inputs
 
@@ -130,7 +135,7 @@ def main():
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process; the committed measurement of
     # the same command (profiles/*_gemm_traffic.json, made by scripts/pmc_traffic.py from two rocprofv3 --pmc passes) is quoted
     tfile = os.path.join(ROOT, "profiles", "r01e_gemm_traffic.json")
-    if args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and os.path.exists(tfile):
+    if args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             roofline["traffic"] = int(tj["hbm_bytes_per_launch"])
@@ -147,8 +152,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=50/50/10 full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
-                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, args.law, "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
+                               "per-GPU batch %d, L=%s full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law, "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world},
         "roofline": roofline, "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }

@@ -528,6 +528,92 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(int n_jobs,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row softmax of the UNFUSED attention used for sequences longer than 64 keys (BASELINE "long-seq variant", L = 200): the
+// scores S = Q K^T and the products P V, dO V^T, dS K, dS^T Q, P^T dO run as batched dmt_gemm launches, these two kernels do
+// what lies between them (TransformerModel_util.py:11-56, 80-108): scale, key mask (padding value -2^32+1), softmax over
+// keys, query mask applied AFTER the softmax, attention-weight dropout with the library's counter mask (same flat index
+// ((b*H + h)*Tq + q)*Tk + k as the fused kernels).  One wavefront per (example, head, query) row; rows are a few hundred
+// bytes, the three passes over them stay in cache.
+constexpr float SM_PADDING_NUM = -4294967295.0f;   // -2**32 + 1
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int Tq, int Tk, T* __restrict__ S, long long ld,
+                                                          const int* __restrict__ q_lens, const int* __restrict__ k_lens, float scale,
+                                                          int drop_on, uint32_t seed, uint32_t thr24, float inv_keep, T* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * H * Tq) return;
+  const int q = (int)(row % Tq);
+  const int b = (int)(row / ((long long)H * Tq));
+  int klen = k_lens ? k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = q_lens ? q_lens[b] : Tq;
+  T* s = S + row * ld;
+  T* p = P + row * ld;
+  float m = -3.0e38f;
+  for (int k = lane; k < Tk; k += 64) {
+    const float x = (k < klen) ? ldf<T>(s + k) * scale : SM_PADDING_NUM;
+    m = fmaxf(m, x);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int k = lane; k < Tk; k += 64) {
+    const float x = (k < klen) ? ldf<T>(s + k) * scale : SM_PADDING_NUM;
+    sum += expf(x - m);
+  }
+  sum = wave_sum(sum);
+  const bool qpad = q >= qlen;
+  const uint32_t base = (uint32_t)(row * Tk);
+  for (int k = lane; k < Tk; k += 64) {
+    const float x = (k < klen) ? ldf<T>(s + k) * scale : SM_PADDING_NUM;
+    float pv = expf(x - m) / sum;
+    if (qpad) pv = SM_PADDING_NUM;                                      // query mask after the softmax (reference behaviour)
+    stf<T>(p + k, pv);
+    if (drop_on) pv = dmt_drop_keep(seed, base + k, thr24) ? pv * inv_keep : 0.f;
+    stf<T>(s + k, pv);                                                  // the A operand of P.V
+  }
+  for (int k = Tk + lane; k < ld; k += 64) { stf<T>(s + k, 0.f); stf<T>(p + k, 0.f); }   // row padding up to the leading dimension
+}
+
+// dP (gradient w.r.t. the dropped weights, in place -> dS), P (saved) -> Pd (dropped weights, the A^T operand of dV)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int Tq, int Tk, const T* __restrict__ P, T* __restrict__ dPS,
+                                                          T* __restrict__ Pd, long long ld, const int* __restrict__ q_lens,
+                                                          const int* __restrict__ k_lens, float scale, int drop_on, uint32_t seed,
+                                                          uint32_t thr24, float inv_keep) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * H * Tq) return;
+  const int q = (int)(row % Tq);
+  const int b = (int)(row / ((long long)H * Tq));
+  int klen = k_lens ? k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = q_lens ? q_lens[b] : Tq;
+  const bool qpad = q >= qlen;
+  const T* p = P + row * ld;
+  T* g = dPS + row * ld;
+  T* pd = Pd + row * ld;
+  const uint32_t base = (uint32_t)(row * Tk);
+  float dot = 0.f;
+  for (int k = lane; k < Tk; k += 64) {
+    float gq = ldf<T>(g + k);
+    if (drop_on) gq = dmt_drop_keep(seed, base + k, thr24) ? gq * inv_keep : 0.f;     // gradient w.r.t. the pre-dropout weights
+    dot += ldf<T>(p + k) * gq;
+  }
+  dot = wave_sum(dot);
+  for (int k = lane; k < Tk; k += 64) {
+    const float pv = ldf<T>(p + k);
+    float gq = ldf<T>(g + k);
+    bool keep = true;
+    if (drop_on) { keep = dmt_drop_keep(seed, base + k, thr24); gq = keep ? gq * inv_keep : 0.f; }
+    float ds = (k < klen && !qpad) ? pv * (gq - dot) * scale : 0.f;     // no gradient into masked keys / through constant rows
+    stf<T>(g + k, ds);
+    stf<T>(pd + k, drop_on ? (keep ? pv * inv_keep : 0.f) : pv);
+  }
+  for (int k = Tk + lane; k < ld; k += 64) { stf<T>(g + k, 0.f); stf<T>(pd + k, 0.f); }
+}
+
 __global__ __launch_bounds__(256) void auc_hist_kernel(int B, const float* __restrict__ pred, const float* __restrict__ label, int n_thr,
                                                        unsigned long long* __restrict__ hist) {
   const int b = blockIdx.x * 256 + threadIdx.x;
@@ -776,6 +862,41 @@ extern "C" int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_jo
   DMT_CHECK_ARG(n_jobs > 0 && jobs_dev && total_tiles > 0, "dmt_cast_transpose_bf16_batched: bad argument");
   hipLaunchKernelGGL(cast_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, n_jobs, jobs_dev);
   DMT_CHECK_LAUNCH("dmt_cast_transpose_bf16_batched");
+  return DMT_OK;
+}
+
+extern "C" int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* S, int64_t ld, const int32_t* q_lens,
+                               const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, void* stream) {
+  DMT_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0 && S && P && ld >= Tk, "dmt_softmax_fwd: bad argument");
+  DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_softmax_fwd: bad dtype");
+  DMT_CHECK_ARG((long long)B * H * Tq * Tk < 0xFFFFFFFFll, "dmt_softmax_fwd: B*H*Tq*Tk exceeds the 32-bit dropout counter");
+  const int drop_on = (drop_keep > 0.f && drop_keep < 1.f) ? 1 : 0;
+  const uint32_t thr = (uint32_t)(drop_keep * 16777216.0f);
+  const float inv = drop_on ? 1.f / drop_keep : 1.f;
+  const unsigned nb = (unsigned)cdiv64((long long)B * H * Tq, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (float*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (float*)P);
+  else
+    hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (bf16_t*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (bf16_t*)P);
+  DMT_CHECK_LAUNCH("dmt_softmax_fwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, const void* P, void* dP_dS, void* Pd, int64_t ld,
+                               const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* stream) {
+  DMT_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0 && P && dP_dS && Pd && ld >= Tk, "dmt_softmax_bwd: bad argument");
+  DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_softmax_bwd: bad dtype");
+  const int drop_on = (drop_keep > 0.f && drop_keep < 1.f) ? 1 : 0;
+  const uint32_t thr = (uint32_t)(drop_keep * 16777216.0f);
+  const float inv = drop_on ? 1.f / drop_keep : 1.f;
+  const unsigned nb = (unsigned)cdiv64((long long)B * H * Tq, 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DMT_F32)
+    hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const float*)P, (float*)dP_dS, (float*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv);
+  else
+    hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const bf16_t*)P, (bf16_t*)dP_dS, (bf16_t*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv);
+  DMT_CHECK_LAUNCH("dmt_softmax_bwd");
   return DMT_OK;
 }
 

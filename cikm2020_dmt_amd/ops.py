@@ -407,6 +407,85 @@ def dropout(x, rate, step_seed, stream):
     return DropoutFn.apply(x, site_seed(step_seed, stream), 1.0 - rate)
 
 
+# ---- attention core: fused kernels for T <= 64, the unfused batched-GEMM form for longer sequences
+ATTN_FUSED_MAX_T = 64
+
+
+def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
+    """T > 64 (BASELINE "long-seq variant", L = 200): S = Q K^T, P = softmax(mask(S / sqrt(dh))), out = dropout(P) V + resid as
+    batched dmt_gemm launches (one per head, batch = B) around dmt_softmax_fwd.  Returns P (before dropout) for the backward."""
+    B, Tq, d = q.shape
+    Tk, dh = k.shape[1], d // H
+    ldp = (Tk + 7) // 8 * 8
+    S = torch.empty((B, H, Tq, ldp), dtype=q.dtype, device=q.device)
+    P = torch.empty_like(S)
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        gemm(q[..., sl], q.stride(1), 1, k[..., sl], 1, k.stride(1), Tq, Tk, dh, S[:, h], ldp, batch=B, a_bs=q.stride(0), b_bs=k.stride(0),
+             c_bs=H * Tq * ldp)
+    L.call("dmt_softmax_fwd", dt_code(q.dtype), B, H, Tq, Tk, p(S), ldp, p(q_lens), p(k_lens), 1.0 / float(dh) ** 0.5, int(drop_seed),
+           float(drop_keep), p(P), stream_ptr())
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        kw = {}
+        if resid is not None:
+            kw = dict(resid=resid[..., sl], ldr=resid.stride(1), resid_bs=resid.stride(0))
+        gemm(S[:, h], ldp, 1, v[..., sl], v.stride(1), 1, Tq, dh, Tk, out[..., sl], out.stride(1), batch=B, a_bs=H * Tq * ldp, b_bs=v.stride(0),
+             c_bs=out.stride(0), **kw)
+    return P
+
+
+def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep):
+    """dP = dO V^T; dS = softmax'(P, dP); dQ = dS K; dK = dS^T Q; dV = dropout(P)^T dO -- batched GEMMs around dmt_softmax_bwd."""
+    B, Tq, d = q.shape
+    Tk, dh = k.shape[1], d // H
+    ldp = P.shape[-1]
+    dS = torch.empty_like(P)
+    Pd = torch.empty_like(P)
+    cb = H * Tq * ldp
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        gemm(dout[..., sl], dout.stride(1), 1, v[..., sl], 1, v.stride(1), Tq, Tk, dh, dS[:, h], ldp, batch=B, a_bs=dout.stride(0),
+             b_bs=v.stride(0), c_bs=cb)
+    L.call("dmt_softmax_bwd", dt_code(q.dtype), B, H, Tq, Tk, p(P), p(dS), p(Pd), ldp, p(q_lens), p(k_lens), 1.0 / float(dh) ** 0.5,
+           int(drop_seed), float(drop_keep), stream_ptr())
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        gemm(dS[:, h], ldp, 1, k[..., sl], k.stride(1), 1, Tq, dh, Tk, dq[..., sl], dq.stride(1), batch=B, a_bs=cb, b_bs=k.stride(0),
+             c_bs=dq.stride(0))
+        gemm(dS[:, h], 1, ldp, q[..., sl], q.stride(1), 1, Tk, dh, Tq, dk[..., sl], dk.stride(1), batch=B, a_bs=cb, b_bs=q.stride(0),
+             c_bs=dk.stride(0))
+        gemm(Pd[:, h], 1, ldp, dout[..., sl], dout.stride(1), 1, Tk, dh, Tq, dv[..., sl], dv.stride(1), batch=B, a_bs=cb, b_bs=dout.stride(0),
+             c_bs=dv.stride(0))
+
+
+def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
+    """Returns what the backward needs beyond its inputs: None (fused kernels recompute P) or the saved P of the long form."""
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    if max(Tq, Tk) > ATTN_FUSED_MAX_T:
+        return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
+    desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
+    desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
+    L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+    return None
+
+
+def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep):
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    if P is not None:
+        return _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep)
+    bd = L.AttnBwdDesc()
+    bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
+    bd.f.drop_seed, bd.f.drop_keep = int(drop_seed), float(drop_keep)
+    bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
+    bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
+    bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
+    bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
+    L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+
+
 class AttnFn(torch.autograd.Function):
     """out = concat_h softmax(mask(QK^T/sqrt(dh))) V + resid.  q,k,v may be column slices of packed projections;
     their gradients are written straight into one packed buffer per distinct base tensor (`pack`)."""
@@ -423,9 +502,7 @@ class AttnFn(torch.autograd.Function):
             q, k, v = packed_q, packed_kv[..., :d], packed_kv[..., d:]
         B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
         out = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
-        desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
-        desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
-        L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+        ctx.P = attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
         ctx.save_for_backward(packed_q, packed_kv, q_lens, k_lens)
         ctx.H, ctx.d, ctx.self_attn = H, d, self_attn
         ctx.drop = (int(drop_seed), float(drop_keep))
@@ -448,15 +525,8 @@ class AttnFn(torch.autograd.Function):
             dpq = torch.empty_like(packed_q)
             dpkv = torch.empty_like(packed_kv)
             dq, dk, dv = dpq, dpkv[..., :d], dpkv[..., d:]
-        B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
-        bd = L.AttnBwdDesc()
-        bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
-        bd.f.drop_seed, bd.f.drop_keep = ctx.drop
-        bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
-        bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
-        bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
-        bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
-        L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+        attn_core_bwd(q, k, v, q_lens, k_lens, ctx.P, dout, dq, dk, dv, H, *ctx.drop)
+        ctx.P = None
         return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None
 
 
@@ -473,9 +543,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
         qkv = linear_forward(x2, w, b_leaf).reshape(B, T, 3 * d)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         out = torch.empty((B, T, d), dtype=x.dtype, device=x.device)
-        desc = _attn_desc(x.dtype, B, H, d // H, T, T, q, k, v, lens, lens, x, out)
-        desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
-        L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+        ctx.P = attn_core_fwd(q, k, v, lens, lens, x, out, H, drop_seed, drop_keep)
         ctx.save_for_backward(x2, qkv, lens)
         ctx.w, ctx.leaves, ctx.H, ctx.drop = w, (w_leaf, b_leaf), H, (int(drop_seed), float(drop_keep))
         return out
@@ -490,14 +558,8 @@ class SelfAttnBlockFn(torch.autograd.Function):
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
-        bd = L.AttnBwdDesc()
-        bd.f = _attn_desc(q.dtype, B, ctx.H, d // ctx.H, T, T, q, k, v, lens, lens, None, None)
-        bd.f.drop_seed, bd.f.drop_keep = ctx.drop
-        bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), dout.stride(0), dout.stride(1)
-        bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
-        bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
-        bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
-        L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+        attn_core_bwd(q, k, v, lens, lens, ctx.P, dout, dq, dk, dv, ctx.H, *ctx.drop)
+        ctx.P = None
         dz = dqkv.reshape(-1, d3)
         dx = linear_backward_input(dz, ctx.w, resid=dout.reshape(-1, d)).reshape(B, T, d) if ctx.needs_input_grad[0] else None
         dW, db = linear_backward_weight(x2, dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])

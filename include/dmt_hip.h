@@ -332,6 +332,19 @@ typedef struct dmt_cast_job {
 } dmt_cast_job;
 int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_job* jobs_dev, int32_t total_tiles, void* stream);
 
+/* Row softmax of the UNFUSED attention used for sequences longer than 64 keys (dmt_attn_fwd/bwd take T <= 64): the scores
+ * S = Q K^T and the products around it run as batched dmt_gemm launches; these do what lies between them
+ * (model/net/TransformerModel_util.py:11-56 scaled_dot_product_attention, :80-108 mask).  S [B, H, Tq, ld] holds the raw
+ * scores on entry and the dropped weights (A operand of P.V) on return; P receives the weights before dropout (saved for
+ * the backward).  Same masking rules, padding value and dropout counter as dmt_attn_fwd.                               */
+int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* S, int64_t ld, const int32_t* q_lens,
+                    const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, void* stream);
+/* dP_dS: gradient w.r.t. the dropped weights on entry, dS (gradient of the scaled scores' pre-image Q K^T) on return;
+ * Pd receives the dropped weights again (the operand of dV = Pd^T dO).                                                */
+int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, const void* P, void* dP_dS, void* Pd,
+                    int64_t ld, const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed,
+                    float drop_keep, void* stream);
+
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
 int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,

@@ -131,3 +131,34 @@ def test_padded_batch_equals_tight_batch(cuda):
     b2 = tr.make_batch(inputs, mask, pad_to=pad)
     (c1, o1), y1 = tr.engine.inference(b2)
     assert (c0 - c1).abs().max().item() < 1e-5 and (o0 - o1).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_long_sequence_variant_L200_matches_oracle(cuda):
+    """BASELINE "long-seq variant": click / order histories of up to 200 steps (maxlen_k = 200).  Self-attention over T > 64
+    runs as batched GEMMs around dmt_softmax_fwd/bwd, the decoder attends over the 200-step memory the same way; everything
+    else is the ordinary path.  fp32 forward + gradients against the oracle."""
+    so, sp = small_specs()
+    so, sp = dict(so, maxlen_k=200), dict(sp, maxlen_k=200)
+    P = O.init_params(so, seed=12)
+    long_feats = {grp[0][0]: 200 for grp in sp["attention_embed_pairs"][:2]}     # clk and ord sequences; the cart sequence stays at 10
+    inputs, mask, label = make_batch(sp, 5, seed=31, lengths="ragged", weights="random", seq_lens=long_feats)
+    assert max(inputs[f].dense_shape[1] for f in long_feats) > 64
+    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False)
+    tr.store.load_state(P)
+    loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
+    loss = tr.forward_backward(tr.make_batch(inputs, mask, label))
+    (c, o), yb = tr.last["out"]
+    assert np.abs(c.detach().cpu().numpy() - c_ref).max() < 3e-4
+    assert np.abs(o.detach().cpu().numpy() - o_ref).max() < 3e-4
+    assert abs(float(loss) - loss_ref) / abs(loss_ref) < 1e-4
+    got = dict(tr.store.grad_dict())
+    got.update(sparse_to_dense_tables(tr.store, tr.engine.sparse))
+    gscale = max(np.abs(G[n]).max() for n in got)
+    bad = []
+    for name, g in got.items():
+        ref = G[name]
+        e = np.linalg.norm(g - ref) / max(np.linalg.norm(ref), 1e-6 * gscale * np.sqrt(ref.size))
+        if not e < 3e-3:
+            bad.append((name, float(e)))
+    assert not bad, bad

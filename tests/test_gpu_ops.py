@@ -18,7 +18,9 @@ def _rand(shape, seed, scale=1.0):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("B,T,H,dh", [(5, 50, 4, 20), (3, 10, 4, 20), (2, 64, 4, 80), (4, 7, 2, 16), (3, 1, 4, 20),
                                       # head dims of the coalesced MFMA kernels (dh % 16 == 0), ragged and full tiles
-                                      (5, 50, 4, 80), (6, 10, 4, 16), (3, 33, 2, 32), (2, 50, 2, 64), (2, 64, 2, 16)])
+                                      (5, 50, 4, 80), (6, 10, 4, 16), (3, 33, 2, 32), (2, 50, 2, 64), (2, 64, 2, 16),
+                                      # longer than the fused kernels' 64 keys: batched GEMMs + dmt_softmax_* (BASELINE long-seq variant)
+                                      (3, 200, 4, 20), (2, 200, 4, 80), (2, 65, 2, 16), (2, 130, 2, 32)])
 def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
     d = H * dh
     q = torch.tensor(_rand((B, T, d), 1), dtype=dtype)
@@ -40,7 +42,8 @@ def test_attention_core_matches_oracle(cuda, dtype, tol, B, T, H, dh):
     valid = m[:, :, None]
     # rows of padded queries hold c * sum(V) with c = -2**32+1 (reference behaviour): compare relatively
     err = np.abs(got - ref) / (np.abs(ref) + 1.0)
-    assert err.max() < tol, err.max()
+    # (padded query rows sum T terms of magnitude 4e9 * |V| with cancellation: their fp32 rounding error grows with T)
+    assert err.max() < (tol if T <= 64 or dtype != torch.float32 else 4 * tol), err.max()
     # gradients (only through valid query rows, as in the model) vs torch autograd of the second oracle
     w = torch.tensor(_rand((B, T, d), 6) * m[:, :, None], dtype=torch.float64)
     (out.double() * w.to(cuda)).sum().backward()
@@ -232,7 +235,7 @@ def test_batched_cast_transpose_equals_per_weight_casts(cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,H,dh", [(7, 50, 4, 80), (9, 10, 4, 80), (3, 64, 2, 16), (4, 33, 2, 64)])
+@pytest.mark.parametrize("B,T,H,dh", [(7, 50, 4, 80), (9, 10, 4, 80), (3, 64, 2, 16), (4, 33, 2, 64), (3, 200, 4, 80), (2, 96, 2, 16)])
 def test_mfma_attention_dropout_matches_fp32_kernel(cuda, B, T, H, dh):
     """Attention-weight dropout (TransformerModel_util.py:51 tf.layers.dropout on the softmax) in the coalesced bf16 MFMA kernels
     against the scalar fp32 kernel of the same library (independent code, same counter mask): a different mask would show up as
@@ -259,7 +262,7 @@ def test_mfma_attention_dropout_matches_fp32_kernel(cuda, B, T, H, dh):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Tq,Tk,H,dh", [(5, 12, 50, 4, 80), (4, 40, 20, 2, 64), (3, 9, 9, 2, 16)])
+@pytest.mark.parametrize("B,Tq,Tk,H,dh", [(5, 12, 50, 4, 80), (4, 40, 20, 2, 64), (3, 9, 9, 2, 16), (4, 1, 200, 4, 80), (3, 30, 100, 2, 16)])
 def test_mfma_cross_attention_matches_fp32_kernel(cuda, B, Tq, Tk, H, dh):
     """Cross attention with different query / key tile counts (coalesced kernels <NTQ, NTK> = <1,2>, <2,1>, <1,1>), separate
     query and key lengths, packed K|V: bf16 MFMA path against the scalar fp32 kernel, forward and gradients."""
