@@ -447,17 +447,18 @@ class DMTEngine:
         sp = self.spec
         E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
         K = self.plan.K
-        g1 = ops.linear(z[:, :K], self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
+        zin = z if z.shape[1] == K else z[:, :K]      # inference() hands over the already split [B, K] view
+        g1 = ops.linear(zin, self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
                         self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0])
-        expert = g1[:, : E * units[0]]          # [B, E * u0]: the four experts' layer-0 outputs side by side
+        # [B, E * u0]: the four experts' layer-0 outputs side by side | both gates' logits
+        expert, glogit = ops.split_cols(g1, 0, E * units[0], E * units[0], E * units[0] + T * E)
         for li in range(1, len(units)):
             nms = ["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)]
             expert = ops.expert_layer(expert, [self._w(n + "weights") for n in nms], [self._lf(n + "weights") for n in nms],
                                       [self._lf(n + "biases") for n in nms])
-        glogit = g1[:, E * units[0]: E * units[0] + T * E]
         mix, gates = ops.MixFn.apply(expert, glogit, E, units[-1], T)
         self.intermediates["gates"] = gates
-        return [mix[t] for t in range(T)]
+        return list(ops.Unbind0Fn.apply(mix))
 
     def build_tower(self, x, name):
         sp = self.spec
@@ -470,7 +471,7 @@ class DMTEngine:
 
     def embedding_mlp_bias(self, z):
         sp = self.spec
-        h = z[:, self.plan.bias_off: self.plan.bias_off + self.plan.bias_width]
+        h = z if z.shape[1] == self.plan.bias_width else z[:, self.plan.bias_off: self.plan.bias_off + self.plan.bias_width]
         n = len(sp["hidden_units_bias"])
         for li in range(n):
             nm = "layer_bias%d/" % li
@@ -481,11 +482,18 @@ class DMTEngine:
 
     def inference(self, batch: DeviceBatch, is_predict=False):
         z = self.embedding_trans(batch)
-        tasks = self.expert_gate(z)
-        logits = tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         if is_predict:
-            return logits
-        return logits, self.embedding_mlp_bias(z)
+            tasks = self.expert_gate(z)
+            return tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
+        # MMoE input | bias-tower input: one autograd node for both column slices of z
+        plan = self.plan
+        if plan.bias_width == plan.K:      # (degenerate layout: keep the two views distinguishable by the plain path)
+            z_main, z_bias = z[:, :plan.K], z[:, plan.bias_off: plan.bias_off + plan.bias_width]
+        else:
+            z_main, z_bias = ops.split_cols(z, 0, plan.K, plan.bias_off, plan.bias_off + plan.bias_width)
+        tasks = self.expert_gate(z_main)
+        logits = tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
+        return logits, self.embedding_mlp_bias(z_bias)
 
     def loss_unbias(self, out, mask, method=None, ctr_rel=None):
         (c, o), yb = out

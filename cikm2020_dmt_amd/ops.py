@@ -407,6 +407,62 @@ def dropout(x, rate, step_seed, stream):
     return DropoutFn.apply(x, site_seed(step_seed, stream), 1.0 - rate)
 
 
+# ---- slicing without autograd's zero-fill + add per slice
+class SplitColsFn(torch.autograd.Function):
+    """x[:, a:b] column slices of one 2-D activation as ONE autograd node.  Plain slicing gives every slice its own SliceBackward
+    (a zero-filled full-size buffer + a copy) and then adds the buffers; here the slices' gradients are copied side by side
+    into one buffer and only the columns no slice covers are zeroed."""
+
+    @staticmethod
+    def forward(ctx, x, *bounds):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device, bounds)
+        return tuple(x[:, bounds[2 * i]: bounds[2 * i + 1]] for i in range(len(bounds) // 2))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dt, dev, bounds = ctx.meta
+        g = torch.empty(shape, dtype=dt, device=dev)
+        spans = sorted((bounds[2 * i], bounds[2 * i + 1], i) for i in range(len(bounds) // 2))
+        pos = 0
+        for a, b, i in spans:
+            if a < pos:
+                raise RuntimeError("SplitColsFn: overlapping slices")
+            if a > pos:
+                g[:, pos:a].zero_()
+            if grads[i] is None:
+                g[:, a:b].zero_()
+            else:
+                g[:, a:b].copy_(grads[i])
+            pos = b
+        if pos < shape[1]:
+            g[:, pos:].zero_()
+        return (g,) + (None,) * len(bounds)
+
+
+def split_cols(x, *bounds):
+    return SplitColsFn.apply(x, *bounds)
+
+
+class Unbind0Fn(torch.autograd.Function):
+    """x[t] for every t of the leading dim as one node (backward: one stacked buffer instead of zero-fill + copy + add per t)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = (tuple(x.shape), x.dtype, x.device)
+        return tuple(x[t] for t in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dt, dev = ctx.meta
+        g = torch.empty(shape, dtype=dt, device=dev)
+        for t, gt in enumerate(grads):
+            if gt is None:
+                g[t].zero_()
+            else:
+                g[t].copy_(gt)
+        return g
+
+
 # ---- attention core: fused kernels for T <= 64, the unfused batched-GEMM form for longer sequences
 ATTN_FUSED_MAX_T = 64
 
