@@ -190,7 +190,9 @@ struct FastLoad {
           voff[p] = (int)(((long long)(v % BK) * cs + (v / BK) * EPV) * (long long)sizeof(T));
       }
     }
-    long long bytes = valid_elems * (long long)sizeof(T);
+    // rounded up to whole dwords: the range check is per dword, and an odd bf16 element count would blank the last valid
+    // element together with its (in-allocation: the leading dimension is a multiple of 8) pad neighbour
+    long long bytes = (valid_elems * (long long)sizeof(T) + 3) & ~3ll;
     bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(unsigned)bytes, 0x00020000);
   }
@@ -986,7 +988,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   };
 #undef DMT_TR_READ
   auto rsrc_of = [&](const T* base, long long k_stride, int row0, int rows_real) {
-    long long bytes = ((long long)(g.K - 1) * k_stride + (rows_real - row0)) * 2;
+    // (the range check works on whole dwords: with an odd number of valid elements in the last k row the dword that holds the
+    //  last one would read as zero, so the bound is rounded up to the next dword -- that element is a pad column of the same
+    //  row, inside the allocation because the leading dimension is a multiple of 8, and only feeds discarded / patched rows)
+    long long bytes = (((long long)(g.K - 1) * k_stride + (rows_real - row0)) * 2 + 3) & ~3ll;
     bytes = bytes < 0 ? 0 : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base + row0), 0, (int)(unsigned)bytes, 0x00020000);
   };

@@ -101,3 +101,23 @@ def test_gemm_rejects_bad_args(cuda):
         ops.gemm(x, 4, 1, x, 4, 1, 0, 4, 4, x, 4)
     with pytest.raises(DmtError):
         ops.gemm(x, 4, 1, x, 4, 1, 4, 4, 4, x.to(torch.bfloat16), 4, split_k=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Kin,N,rows", [(513, 32, 64), (3047, 320, 4096), (511, 1280, 8192), (129, 32, 128), (321, 960, 40960)])
+def test_weight_grad_last_row_of_odd_width_inputs(cuda, Kin, N, rows):
+    """Regression: with an odd input width the last valid bf16 element of the last reduction row shares a dword with a pad
+    column; the buffer descriptor's dword-granular range check blanked it, so dW's last row missed one term (found by
+    scripts/gemm_fuzz.py).  Every row is checked on its own here -- a whole-matrix norm hides one bad row in thousands."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ldx = (Kin + 7) // 8 * 8
+    buf = (torch.randn((rows, ldx), generator=g) * 0.5).to(torch.bfloat16).to(cuda)      # pad columns hold data, not zeros
+    x = buf[:, :Kin]
+    dy = (torch.randn((rows, N), generator=g) * 0.5).to(torch.bfloat16).to(cuda)
+    for wb in (True, False):
+        dW, db = ops.linear_backward_weight(x, dy, want_bias=wb)
+        ref = x.float().t() @ dy.float()
+        per_row = (dW - ref).abs().max(1).values / ref.abs().max()
+        assert per_row.max().item() < 2e-5, (wb, int(per_row.argmax()), per_row.max().item())
+        if wb:
+            assert (db - dy.float().sum(0)).abs().max().item() < 1e-3
