@@ -76,6 +76,11 @@ def test_gradients_match_oracle(cuda, dtype):
         e = np.linalg.norm(g - ref) / denom
         if not e < t["grad"]:
             bad.append((name, float(e), float(np.abs(ref).max())))
+        # ... and element by element (a norm over a whole tensor hides a single wrong row among thousands)
+        if dtype == torch.float32:
+            worst = float(np.abs(g - ref).max())
+            if not worst < 5e-4 * max(float(np.abs(ref).max()), 1e-3 * gscale):
+                bad.append((name, "max element error", worst, float(np.abs(ref).max())))
     assert not bad, "gradient mismatches: %s" % bad
 
 
