@@ -16,10 +16,20 @@ for it in range(N_):
         bias = torch.randn(N, device=dev) if rng.random() < 0.5 else None
         relu = bool(rng.integers(0, 2)) and bias is not None
         C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-        ops.gemm(A, K, 1, Bm, 1, K, M, N, K, C, N, bias=bias, act_ncols=N if relu else 0)
+        kw = {}
+        gate = resid = None
+        if not relu and rng.random() < 0.4:
+            gate = torch.randn(M, N, device=dev).to(torch.bfloat16); kw.update(gate=gate, ldg=N)
+        if rng.random() < 0.4:
+            resid = torch.randn(M, N, device=dev).to(torch.bfloat16); kw.update(resid=resid, ldr=N)
+        ops.gemm(A, K, 1, Bm, 1, K, M, N, K, C, N, bias=bias, act_ncols=N if relu else 0, **kw)
         ref = A.float() @ Bm.float().t() + (bias if bias is not None else 0)
         if relu:
             ref = torch.relu(ref)
+        if gate is not None:
+            ref = torch.where(gate.float() > 0, ref, torch.zeros_like(ref))
+        if resid is not None:
+            ref = ref + resid.float()
         got = C.float()
         tol = 2e-2
     else:

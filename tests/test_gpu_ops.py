@@ -287,3 +287,34 @@ def test_mfma_cross_attention_matches_fp32_kernel(cuda, B, Tq, Tk, H, dh):
     for a, b2 in ((gq[0], gq[1]), (gkv[0], gkv[1])):
         e = (a - b2).abs().max().item() / a.abs().max().item()
         assert e < 4e-2, e
+
+
+@pytest.mark.gpu
+def test_sparse_adam_bf16_rows_and_padding_keys(cuda):
+    """dmt_adam_sparse_rows_bf16 (reduced rows straight off the data-parallel wire) == dmt_adam_sparse_rows on the same rows
+    widened to fp32, bit for bit; keys >= the total row count (padding slots of a rank-major gathered list) are skipped by
+    both."""
+    from cikm2020_dmt_amd.variables import VariableStore
+    from cikm2020_dmt_amd.optim import TFAdam
+    from tests.util import small_specs
+    _so, sp = small_specs()
+    a = VariableStore(sp, cuda, torch.float32, seed=2)
+    b = VariableStore(sp, cuda, torch.float32, seed=2)
+    oa, ob = TFAdam(a), TFAdam(b)
+    rng = np.random.default_rng(1)
+    D = max(t.shape[1] for t in a.table.values())
+    D = (D + 3) // 4 * 4
+    for step in range(5):
+        rows = np.unique(rng.integers(0, a.total_rows, size=300)).astype(np.int32)
+        pad = np.full(17, a.total_rows, dtype=np.int32)                      # padding slots, scattered through the list
+        keys = np.concatenate([rows[:100], pad[:9], rows[100:], pad[9:]])
+        g = (rng.standard_normal((len(keys), D)) * 0.01).astype(np.float32)
+        gb = torch.tensor(g, device=cuda).to(torch.bfloat16)
+        uniq = torch.tensor(keys, device=cuda)
+        nu = torch.tensor([len(keys)], dtype=torch.int32, device=cuda)
+        oa.begin(); oa.apply_sparse((uniq, nu, gb, len(keys)), grad_scale=0.5); oa.end()
+        ob.begin(); ob.apply_sparse((uniq, nu, gb.float(), len(keys)), grad_scale=0.5); ob.end()
+    for x, y in ((a.tab_p, b.tab_p), (a.tab_m, b.tab_m), (a.tab_v, b.tab_v)):
+        assert torch.equal(x, y)
+    assert torch.equal(a.last_step, b.last_step)
+    assert int((a.tab_m != 0).sum()) > 0
