@@ -56,8 +56,16 @@ def main():
     if os.environ.get("DMT_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("DMT_DIST_BACKEND", "nccl")
+    # DMT_BENCH_FORCE_DP=1 (with --gpus 1): a ONE-rank RCCL group and the full N-rank exchange path (all-reduces, all_to_all
+    # to the owners, shard all-gather, bf16-row Adam) -- the floor of the data-parallel overhead, measurable on a one-GPU box
+    force_dp = os.environ.get("DMT_BENCH_FORCE_DP") == "1" and world == 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if force_dp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -77,7 +85,7 @@ def main():
         sp = dict(sp, maxlen_k=max(sp["maxlen_k"], args.long_seq))
         seq_lens = {grp[0][0]: args.long_seq for grp in sp["attention_embed_pairs"][:2]}
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout)
+    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp)
     nb = 4
     batches = []
     for i in range(nb):
@@ -154,13 +162,13 @@ def main():
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
                                "per-GPU batch %d, L=%s full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
                                % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law, "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                   "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
         "roofline": roofline, "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(sp, args)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -81,6 +81,7 @@ _SIGS = {
     "dmt_segment_heads": [c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_vp, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_embgrad_reduce": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
     "dmt_rows_reduce": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
+    "dmt_rows_permute": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "dmt_zero_rows": [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp],
     "dmt_rows_reduce_bf16": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
     "dmt_gemm": [C.POINTER(GemmDesc), c_vp],

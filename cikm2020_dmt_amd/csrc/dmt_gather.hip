@@ -469,9 +469,46 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
   }
 }
 
+// out[i, :] = in[perm[i], :] (fp32 rows), optionally rounded to bf16: the per-owner grouping of the data-parallel exchange.
+// 16 lanes x 16 bytes per 64-float row piece, four rows per wave.
+template <typename OT>
+__global__ __launch_bounds__(256) void rows_permute_kernel(const float* __restrict__ in, const long long* __restrict__ perm, long long n,
+                                                           int dim, OT* __restrict__ out) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+  const long long i = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp;
+  if (i >= n) return;
+  const float* src = in + perm[i] * dim;
+  OT* dst = out + i * dim;
+  for (int j = c * 4; j < dim; j += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(src + j);
+    if constexpr (sizeof(OT) == 4) {
+      *reinterpret_cast<float4*>(dst + j) = v;
+    } else {
+      uint2 o;
+      o.x = dmt_pack_bf16(v.x, v.y);
+      o.y = dmt_pack_bf16(v.z, v.w);
+      *reinterpret_cast<uint2*>(dst + j) = o;
+    }
+  }
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
+extern "C" int dmt_rows_permute(const float* in_rows, const int64_t* perm, int64_t n, int32_t dim, int32_t out_dtype, void* out_rows,
+                                void* stream) {
+  DMT_CHECK_ARG(in_rows && perm && out_rows && n >= 0 && dim > 0 && dim % 4 == 0, "dmt_rows_permute: bad argument (dim % 4 == 0)");
+  DMT_CHECK_ARG(out_dtype == DMT_F32 || out_dtype == DMT_BF16, "dmt_rows_permute: bad out_dtype");
+  if (n == 0) return DMT_OK;
+  const unsigned nb = (unsigned)cdiv64(n, 16);
+  if (out_dtype == DMT_F32)
+    hipLaunchKernelGGL((rows_permute_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, in_rows, (const long long*)perm, (long long)n, dim, (float*)out_rows);
+  else
+    hipLaunchKernelGGL((rows_permute_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, in_rows, (const long long*)perm, (long long)n, dim, (bf16_t*)out_rows);
+  DMT_CHECK_LAUNCH("dmt_rows_permute");
+  return DMT_OK;
+}
+
 extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
   DMT_CHECK_ARG(d != nullptr, "dmt_gather_fwd: null descriptor");
   DMT_CHECK_ARG(d->B > 0 && d->n_features > 0 && d->n_features <= DMT_MAX_FEATURES, "dmt_gather_fwd: bad B/n_features");

@@ -26,9 +26,10 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
-def allreduce_dense_(flat_grads: torch.Tensor, async_op: bool = False):
-    """Sum the flat gradient arena over ranks in place (the mean is applied by the optimizer's grad_scale)."""
-    if world()[1] == 1:
+def allreduce_dense_(flat_grads: torch.Tensor, async_op: bool = False, force: bool = False):
+    """Sum the flat gradient arena over ranks in place (the mean is applied by the optimizer's grad_scale).
+    `force`: issue the collective even in a one-rank group (exercises the real RCCL call on a one-GPU box)."""
+    if world()[1] == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return None
     return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -97,25 +98,31 @@ def owner_of(keys: torch.Tensor, W: int) -> torch.Tensor:
     return torch.remainder(keys, W)
 
 
-def exchange_to_owners(keys: torch.Tensor, rows: torch.Tensor, n: int, transport_dtype=None):
+def exchange_to_owners(keys: torch.Tensor, rows: torch.Tensor, n: int, transport_dtype=None, group_fn=None):
     """First half of the owner-reduce exchange.  keys [>= n] int32 distinct row ids of this rank, rows [>= n, D] their
     gradient rows.  Every (key, row) pair travels to rank key % W -- ONE all_to_all_single for the keys and one for the rows
     (bf16 on the wire when transport_dtype says so) -- and arrives concatenated in RANK ORDER, which keeps the order of
-    summation of the reference's tower loop (run_dnn.py:45-80).  Returns (recv_keys [R], recv_rows [R, D])."""
+    summation of the reference's tower loop (run_dnn.py:45-80).  Returns (recv_keys [R], recv_rows [R, D]).
+    group_fn(keys, owner, rows, transport_dtype) -> (keys grouped by owner, rows grouped and in wire format): optional device
+    implementation of the stable grouping (the default is torch.sort + index_select, used on CPU)."""
     rank, W = world()
     dev = keys.device
     k = keys[:n]
     owner = owner_of(k, W)
-    _so, perm = torch.sort(owner, stable=True)           # per-owner slices, each still ascending in key
     counts = torch.bincount(owner.long(), minlength=W)
     rows_mat = [torch.zeros_like(counts) for _ in range(W)]
     dist.all_gather(rows_mat, counts)
     M = torch.stack(rows_mat).cpu()                      # M[s, d] = pairs rank s sends to rank d  (the one host sync)
     send_splits, recv_splits = M[rank].tolist(), M[:, rank].tolist()
-    send_k = k.index_select(0, perm)
-    send_r = rows[:n].index_select(0, perm)
-    if transport_dtype is not None and transport_dtype != send_r.dtype:
-        send_r = send_r.to(transport_dtype)
+    if group_fn is not None:
+        # device path (Trainer): one radix pass over the owner ids + one gather-and-round kernel (dmt_rows_permute)
+        send_k, send_r = group_fn(k, owner, rows[:n], transport_dtype)
+    else:
+        _so, perm = torch.sort(owner, stable=True)       # per-owner slices, each still ascending in key
+        send_k = k.index_select(0, perm)
+        send_r = rows[:n].index_select(0, perm)
+        if transport_dtype is not None and transport_dtype != send_r.dtype:
+            send_r = send_r.to(transport_dtype)
     R = int(sum(recv_splits))
     recv_k = torch.empty((R,), dtype=keys.dtype, device=dev)
     recv_r = torch.empty((R, rows.shape[1]), dtype=send_r.dtype, device=dev)
@@ -130,10 +137,14 @@ def allgather_shards(keys: torch.Tensor, rows: torch.Tensor, m: int, invalid_key
     which the optimizer kernels skip.  Returns (all_keys [W*cap], all_rows [W*cap, D], cap)."""
     rank, W = world()
     dev = keys.device
-    cnt = torch.tensor([m], dtype=torch.int64, device=dev)
+    # m may be a device tensor (the shard's distinct-row count as the segment kernel left it): the shard sizes of all ranks and
+    # this rank's own m then cost ONE host sync together
+    cnt = m.reshape(1).to(torch.int64) if isinstance(m, torch.Tensor) else torch.tensor([m], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(W)]
     dist.all_gather(cnts, cnt)
-    cap = max(1, int(torch.stack(cnts).max().item()))
+    c_host = torch.stack(cnts).reshape(-1).cpu()
+    m = int(c_host[rank])
+    cap = max(1, int(c_host.max()))
     k_loc = torch.full((cap,), invalid_key, dtype=keys.dtype, device=dev)
     k_loc[:m] = keys[:m]
     if rows.shape[0] >= cap:

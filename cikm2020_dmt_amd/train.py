@@ -22,7 +22,7 @@ from .variables import VariableStore
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = False, dropout_seed: int = 1,
-                 dp_exchange: str = "owner"):
+                 dp_exchange: str = "owner", force_dp: bool = False):
         self.spec = spec
         self.device = torch.device(device)
         self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init)
@@ -35,6 +35,9 @@ class Trainer:
         if dp_exchange not in ("owner", "allgather"):
             raise ValueError("dp_exchange must be 'owner' or 'allgather'")
         self.dp_exchange = dp_exchange     # how the embedding-gradient rows cross ranks (parallel.py)
+        # run the data-parallel exchange even in a one-rank group (a one-GPU box can still push the real RCCL calls of the
+        # N-rank step through a 1-rank communicator: tests/test_gpu_dp.py)
+        self.force_dp = bool(force_dp)
 
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
@@ -54,7 +57,7 @@ class Trainer:
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
         self._early = None
-        if _W > 1:
+        if _W > 1 or (self.force_dp and parallel.dist.is_initialized()):
             # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
             # final the moment dL/dz exists (91 % of the dense parameters): its all-reduce runs on the collective's own stream
             # while the three Transformer backward passes are still computing (run_dnn.py:45-80 average_gradients).
@@ -63,7 +66,7 @@ class Trainer:
             if z is not None and z.requires_grad:
                 def _hook(g, off=off):
                     if self._early is None:
-                        self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True))
+                        self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True, force=self.force_dp))
                     return g
                 z.register_hook(_hook)
         loss.backward()
@@ -75,7 +78,7 @@ class Trainer:
         """average_gradients for the IndexedSlices: concatenate every rank's (row, grad) pairs in rank order and
         reduce rows again with the same stable sort + segment reduce."""
         rank, W = parallel.world()
-        if W == 1:
+        if W == 1 and not (self.force_dp and parallel.dist.is_initialized()):
             return sparse
         uniq, n_uniq, grad_rows, _cap = sparse
         n = int(n_uniq.item())
@@ -87,16 +90,41 @@ class Trainer:
         # owner-reduce: a row's contributions meet on rank row % W (1/W of the pairs per rank instead of all of them on every
         # rank), are reduced there in rank order, and only the REDUCED shards are all-gathered: at 8 ranks 456 MB instead of
         # 827 MB received per rank and a 1/8 second-level reduce
-        rk, rr = parallel.exchange_to_owners(uniq, grad_rows, n, transport_dtype=wire)
+        rk, rr = parallel.exchange_to_owners(uniq, grad_rows, n, transport_dtype=wire, group_fn=self._group_by_owner)
         if rk.numel() > 0:
-            uniq2, n_uniq2, shard_rows, _capm = self.merge_gathered(rk, rr)
-            m = int(n_uniq2.item())
+            uniq2, m, shard_rows, _capm = self.merge_gathered(rk, rr)       # m stays on the device: allgather_shards syncs once
         else:
             uniq2, shard_rows, m = uniq[:0], grad_rows[:0], 0
         all_k, all_r, cap = parallel.allgather_shards(uniq2, shard_rows, m, st.total_rows, transport_dtype=wire)
         N = all_k.numel()
         n_dev = torch.full((1,), N, dtype=torch.int32, device=all_k.device)
         return (all_k, n_dev, all_r, N)
+
+    def _group_by_owner(self, keys, owner, rows, wire):
+        """Stable grouping of this rank's (key, row) pairs by owner rank: ONE radix pass over the owner ids (they fit in a few
+        bits) and one gather kernel that also rounds the rows to the wire format."""
+        eng = self.engine
+        n = keys.numel()
+        _r, W = parallel.world()
+        end_bit = max(1, int(W - 1).bit_length())
+        iota = torch.arange(n, dtype=torch.int32, device=keys.device)
+        own_s = eng._buf("own_keys_s", (n,), torch.int32)
+        perm32 = eng._buf("own_perm", (n,), torch.int32)
+        own = owner.to(torch.int32) if owner.dtype != torch.int32 else owner
+        need = C.c_uint64(0)
+        L.call("dmt_sort_pairs", ops.p(own), ops.p(own_s), ops.p(iota), ops.p(perm32), n, end_bit, None, C.byref(need), ops.stream_ptr())
+        ws = eng._buf("own_sort_ws", (max(int(need.value), 16),), torch.uint8)
+        have = C.c_uint64(ws.numel())
+        L.call("dmt_sort_pairs", ops.p(own), ops.p(own_s), ops.p(iota), ops.p(perm32), n, end_bit, ops.p(ws), C.byref(have), ops.stream_ptr())
+        perm = perm32.long()
+        send_k = keys.index_select(0, perm)
+        out_dt = wire if wire is not None else rows.dtype
+        send_r = torch.empty((n, rows.shape[1]), dtype=out_dt, device=rows.device)
+        if rows.dtype == torch.float32 and rows.is_contiguous() and rows.shape[1] % 4 == 0 and out_dt in (torch.float32, torch.bfloat16):
+            L.call("dmt_rows_permute", ops.p(rows), ops.p(perm), n, int(rows.shape[1]), ops.dt_code(out_dt), ops.p(send_r), ops.stream_ptr())
+        else:
+            send_r.copy_(rows.index_select(0, perm))
+        return send_k, send_r
 
     def merge_gathered(self, all_k, all_r):
         """Second-level reduce of the rank-major (row id, gradient row) pairs: same stable sort + segment reduce as the
@@ -120,16 +148,17 @@ class Trainer:
         loss = self.forward_backward(batch)
         rank, W = parallel.world()
         sparse = self.engine.sparse
-        if W > 1:
+        if W > 1 or (self.force_dp and parallel.dist.is_initialized()):
             early, self._early = getattr(self, "_early", None), None
             self.early_allreduce_used = early is not None
             if early is not None:
-                works = [early[1], parallel.allreduce_dense_(self.store.grads[: early[0]], async_op=True)]
+                works = [early[1], parallel.allreduce_dense_(self.store.grads[: early[0]], async_op=True, force=self.force_dp)]
             else:
-                works = [parallel.allreduce_dense_(self.store.grads, async_op=True)]
+                works = [parallel.allreduce_dense_(self.store.grads, async_op=True, force=self.force_dp)]
             sparse = self.merge_sparse(sparse)
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
             loss = parallel.mean_scalar(loss)
         self.opt.step(sparse, grad_scale=1.0 / W)
         return loss

@@ -127,6 +127,11 @@ typedef struct {
 /* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e.            */
 int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, void* stream);
 
+/* out[i, :] = in[perm[i], :] for fp32 rows of `dim` floats (dim % 4 == 0), written as fp32 or rounded to bf16: groups a
+ * rank's gradient rows by owner rank and puts them into the wire format of the data-parallel exchange in one pass.     */
+int dmt_rows_permute(const float* in_rows, const int64_t* perm, int64_t n, int32_t dim, int32_t out_dtype, void* out_rows,
+                     void* stream);
+
 /* Stable LSD radix sort of (key, value) pairs on bits [0, end_bit).  ws_bytes: in/out workspace size;
  * call with ws == NULL to query.                                                                     */
 int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,

@@ -176,3 +176,49 @@ def test_rccl_accepts_the_exchange_calls_single_rank(cuda):
     p_.join(60)
     assert p_.exitcode == 0
     assert ok1 and ok2 and s == 1000.0
+
+
+def _nccl_world1_step(q, bf16):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    so, sp = small_specs()
+    P = O.init_params(so, seed=5)
+    states = []
+    for force in (False, True):
+        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, force_dp=force)
+        tr.store.load_state(P)
+        for s_ in range(3):
+            inputs, mask, _ = make_batch(sp, 9, seed=300 + s_, lengths="ragged", weights="random")
+            tr.train_step(tr.make_batch(inputs, mask))
+        if force:
+            assert tr.early_allreduce_used
+        tr.opt.flush_tables()
+        torch.cuda.synchronize()
+        states.append(tr.store.state_dict())
+    worst = max(float(np.abs(states[0][k] - states[1][k]).max()) for k in states[0])
+    same = all(np.array_equal(states[0][k], states[1][k]) for k in states[0])
+    q.put((same, worst))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_full_train_step_through_one_rank_rccl_group(cuda, bf16):
+    """The N-rank train step (early + late all-reduce, all_to_all to the owners, shard all-gather, bf16-row Adam with padding
+    keys) pushed through REAL RCCL calls in a one-rank group: in fp32 mode the result must be bit-identical to the plain
+    one-GPU step; in bf16 mode the only difference is the bf16 wire format of the (single-contribution) gradient rows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_nccl_world1_step, args=(q, bf16))
+    p_.start()
+    same, worst = q.get(timeout=300)
+    p_.join(60)
+    assert p_.exitcode == 0
+    if bf16:
+        assert worst < 4e-3, worst          # three Adam steps move a parameter by at most ~3e-3
+    else:
+        assert same, worst
