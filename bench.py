@@ -142,12 +142,12 @@ def main():
     roofline["algorithmic_bytes_per_launch"] = int(alg_bytes)
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process; the committed measurement of
     # the same command (profiles/*_gemm_traffic.json, made by scripts/pmc_traffic.py from two rocprofv3 --pmc passes) is quoted
-    tfile = os.path.join(ROOT, "profiles", "r01e_gemm_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01m_gemm_traffic.json")
     if args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
             roofline["traffic"] = int(tj["hbm_bytes_per_launch"])
-            roofline["traffic_source"] = "profiles/r01e_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command)"
+            roofline["traffic_source"] = "profiles/r01m_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command)"
         except Exception:
             pass
     gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",
