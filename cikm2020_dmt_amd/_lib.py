@@ -69,6 +69,15 @@ class CastJob(C.Structure):
                 ("rows", c_i32), ("cols", c_i32), ("tile_begin", c_i32), ("tiles_x", c_i32)]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [("mode", c_i32), ("kin", c_i32), ("nmid", c_i32), ("nout", c_i32), ("M", c_i64), ("in_", c_vp), ("ld_in", c_i64),
+                ("image", c_vp), ("bias2", c_vp), ("gamma", c_vp), ("beta", c_vp), ("eps", c_f32), ("s_out", c_vp), ("y_out", c_vp),
+                ("ld_out", c_i64), ("stats", c_vp), ("mid_out", c_vp), ("ld_mid", c_i64), ("mask", c_vp)]
+
+
+DMT_CHAIN_FFN_LN, DMT_CHAIN_FFN_BWD = 0, 1
+
+
 class TableMap(C.Structure):
     _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
                 ("elem_off", c_i64 * DMT_MAX_TABLES)]
@@ -112,9 +121,12 @@ _SIGS = {
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "dmt_chain_image_bytes": [c_i32, c_i32, c_i32, C.POINTER(c_i64)],
+    "dmt_chain_image_build": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "dmt_chain2": [C.POINTER(ChainDesc), c_vp],
 }
 
-EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size"])
+EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported"])
 
 _lib = None
 
@@ -139,6 +151,8 @@ def load():
     lib.dmt_version.restype = c_i32
     lib.dmt_ln_bwd_partials.restype = c_i32
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
+    lib.dmt_chain_supported.restype = c_i32
+    lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
     _lib = lib
     return lib
 

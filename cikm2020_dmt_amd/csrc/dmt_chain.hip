@@ -1,0 +1,517 @@
+// Two chained MFMA GEMMs whose intermediate never leaves the compute unit (bf16 operands, fp32 accumulation):
+//
+//     out[m, :] = epi( mid(  in[m, :] . A1^T  ) . A2^T )            in: [M, KIN]   mid: [M, NMID]   out: [M, NOUT]
+//
+//   mode DMT_CHAIN_FFN_LN    y = LN(relu(x W1 + b1) W2 + b2 + x)          ff() + ln() of TransformerModel_util.py:212-235, 58-78
+//   mode DMT_CHAIN_FFN_BWD   dx = ((ds W2^T) * [h > 0]) W1^T + ds         its input gradient (the relu gate is a bit mask the
+//                                                                          forward wrote: one bit per element of h)
+//
+// Shape of the computation (one workgroup = 4 wavefronts = 128 rows, one wavefront per SIMD, up to 512 registers):
+//   * a wavefront owns 32 rows.  Its input rows stay in REGISTERS as MFMA B fragments for the whole tile (KIN / 16 fragments), its
+//     output tile out^T [NOUT x 32] stays in the accumulators (NOUT / 32 tiles of 16 registers);
+//   * the weights stream HBM/L2 -> LDS by DMA (buffer_load ... lds) as a ring of three stages; stage jt holds the 32 mid columns
+//     jt*32 .. +32: the A1 rows that produce them (32 x KIN) and the A2 columns that consume them (NOUT x 32).  Both lie in a
+//     prebuilt bf16 IMAGE (dmt_chain_image_build) in exactly the byte order of the LDS stage, row strides padded to an odd number of
+//     16-byte slots (conflict-free ds_read_b128), so a stage is one linear 1 KB-per-instruction copy;
+//   * everything is computed TRANSPOSED: mid^T tile [32 j x 32 m] = A1[j, :] . in^T  (A operand = weights from LDS, B operand = the
+//     resident input fragments), so a lane holds ONE input row m = lane & 31 in every accumulator.  The mid tile feeds the second GEMM
+//     straight from the accumulator registers as its B operand: the MFMA k-slot (half h, element e) of a lane holds
+//     j = 4h + (e & 3) + 8 (e >> 2) of a 16-chunk, and the image stores A2 (and A1, for the residual) with the same permutation of k
+//     inside every 16-chunk -- a reduction does not care about the order of its terms as long as both operands agree;
+//   * with the same permutation applied to the input fragments, the residual x[m, n] that the epilogue adds to accumulator register
+//     (tile t, r) is element 4 ((r >> 2) & 1) + (r & 3) of input fragment 2 t + (r >> 3): no data movement;
+//   * LayerNorm row statistics: a row is spread over the two lanes m and m + 32 only, so mean / variance are in-lane sums plus one
+//     exchange with the partner lane.
+// Nothing but the input rows (once), the weight image (once per 128 rows, from L2) and the outputs touch memory; h is written
+// only when the caller needs it for the weight gradients (training).
+#include "dmt_common.h"
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) void* lds_vp;
+
+constexpr int CH_NT = 256;   // 4 wavefronts
+constexpr int CH_NS = 3;     // DMA ring depth
+
+template <int KIN_, int NMID_, int NOUT_>
+struct Geo {
+  static constexpr int KIN = KIN_, NMID = NMID_, NOUT = NOUT_;
+  static constexpr int KC = KIN / 16;              // input fragments (k chunks of 16)
+  static constexpr int NJT = NMID / 32;            // mid tiles = DMA stages per row tile
+  static constexpr int NOT = (NOUT + 31) / 32;     // output tiles
+  static constexpr int A1_STRIDE = KIN * 2 + 16;   // bytes; (KIN / 8 + 1) 16-byte slots: odd
+  static constexpr int A1_BYTES = 32 * A1_STRIDE;
+  static constexpr int A2_STRIDE = 80;             // 4 slots of data + 1 pad slot
+  static constexpr int A2_OFF = A1_BYTES;
+  static constexpr int A2_BYTES = NOT * 32 * A2_STRIDE;
+  static constexpr int BIAS_OFF = A2_OFF + A2_BYTES;
+  static constexpr int RAW = BIAS_OFF + 128;
+  static constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
+  static constexpr int PER_WAVE = STAGE / 4096;    // DMA instructions (1 KB each) per wavefront and stage
+  static constexpr long long IMAGE_BYTES = (long long)NJT * STAGE;
+  static_assert(KIN % 16 == 0 && NMID % 32 == 0, "chain geometry");
+  static_assert(CH_NS * STAGE <= 160 * 1024, "LDS ring exceeds 160 KB");
+};
+
+template <int... I, typename F>
+__device__ __forceinline__ void sfor_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// k position p (0..15) of an image chunk holds original index perm16(p): the order in which the 32x32 MFMA accumulator hands its rows
+// to a B operand (see the header).
+__host__ __device__ constexpr int perm16(int p) { return 4 * (p >> 3) + (p & 3) + 8 * ((p >> 2) & 1); }
+
+// ---------------------------------------------------------------------------------------------------------------- image
+struct ImgArgs {
+  const float* a1; long long a1_rs, a1_cs;   // A1[j, k] = a1[j * a1_rs + k * a1_cs]      j < NMID, k < KIN
+  const float* a2; long long a2_rs, a2_cs;   // A2[n, j] = a2[n * a2_rs + j * a2_cs]      n < NOUT, j < NMID
+  const float* bias1;                        // [NMID] or null
+  unsigned char* img;
+  int kin, nmid, nout;
+  int a1_stride, a1_bytes, a2_bytes, bias_off, stage;
+  long long slots;
+};
+
+__global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) {
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < g.slots; s += (long long)gridDim.x * 256) {
+    const long long byte = s * 16;
+    const int jt = (int)(byte / g.stage), off = (int)(byte % g.stage);
+    u32x4_t o = {0u, 0u, 0u, 0u};
+    if (off < g.a1_bytes) {
+      const int row = off / g.a1_stride, cb = off % g.a1_stride;
+      if (cb < g.kin * 2) {
+        const int c = cb / 32, half = (cb % 32) / 16;
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * c + perm16(8 * half + e);
+          h[e] = f2bf(g.a1[(long long)(jt * 32 + row) * g.a1_rs + (long long)k * g.a1_cs]);
+        }
+        o = u32x4_t{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16),
+                    (unsigned)h[6] | ((unsigned)h[7] << 16)};
+      }
+    } else if (off < g.a1_bytes + g.a2_bytes) {
+      const int o2 = off - g.a1_bytes;
+      const int n = o2 / 80, sl = (o2 % 80) / 16;
+      if (sl < 4 && n < g.nout) {
+        const int f = sl >> 1, half = sl & 1;
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = jt * 32 + 16 * f + perm16(8 * half + e);
+          h[e] = f2bf(g.a2[(long long)n * g.a2_rs + (long long)j * g.a2_cs]);
+        }
+        o = u32x4_t{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16),
+                    (unsigned)h[6] | ((unsigned)h[7] << 16)};
+      }
+    } else if (off < g.bias_off + 128) {
+      const int i0 = (off - g.bias_off) / 4;
+      if (g.bias1 != nullptr) {
+        o = u32x4_t{__float_as_uint(g.bias1[jt * 32 + i0 + 0]), __float_as_uint(g.bias1[jt * 32 + i0 + 1]),
+                    __float_as_uint(g.bias1[jt * 32 + i0 + 2]), __float_as_uint(g.bias1[jt * 32 + i0 + 3])};
+      }
+    }
+    *reinterpret_cast<u32x4_t*>(g.img + byte) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- chain
+struct ChainArgs {
+  long long M;
+  const bf16_t* in; long long ld_in;
+  const unsigned char* image;
+  const float* bias2; const float* gamma; const float* beta; float eps;
+  bf16_t* s_out; bf16_t* y_out; long long ld_out;
+  float* stats;
+  bf16_t* mid_out; long long ld_mid;
+  unsigned short* mask;
+  int tiles;
+};
+
+// LDS fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) while an LDS-DMA is in
+// flight (it cannot tell the ring stages apart), which would serialise the weight stream with the multiplies.  LDS returns in
+// order, so "at most n outstanding" releases the oldest reads; the waits name the registers they release ("+v") so that no MFMA is
+// scheduled above them.
+template <int OFF> __device__ __forceinline__ void ch_read128(bf16x8_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void ch_read128f(f32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N> __device__ __forceinline__ void ch_wait(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d, bf16x8_t& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "i"(N));
+}
+template <int N> __device__ __forceinline__ void ch_wait4f(f32x4_t& a, f32x4_t& b, f32x4_t& c, f32x4_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+
+__device__ __forceinline__ void swap_lo(unsigned& a, unsigned& b) {
+  // v_permlane32_swap: lanes 32-63 of a  <->  lanes 0-31 of b
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+
+template <typename G, int MODE>
+__global__ __launch_bounds__(CH_NT, 1) void chain2_kernel(const ChainArgs g) {
+  constexpr int KC = G::KC, NJT = G::NJT, NOT = G::NOT, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_NS * STAGE];   // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ml = lane & 31, hi = lane >> 5;
+  const unsigned lds0 = (unsigned)(unsigned long long)((lds_vp)smem);
+  const unsigned a1_lane = lds0 + ml * G::A1_STRIDE + 16 * hi;
+  const unsigned a2_lane = lds0 + G::A2_OFF + ml * G::A2_STRIDE + 16 * hi;
+  const unsigned bias_lane = lds0 + G::BIAS_OFF + 16 * hi;
+
+  const __amdgpu_buffer_rsrc_t rimg =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.image), 0, (int)G::IMAGE_BYTES, 0x00020000);
+  auto issue = [&](int buf, int jt) {
+    unsigned char* sb = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+    for (int p = 0; p < PER_WAVE; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)(sb + p * 4096), 16, lane * 16, jt * STAGE + wave * 1024 + p * 4096, 0, 0);
+  };
+
+  const int G_ = (int)gridDim.x;
+  int my_tiles = 0;
+  for (int t = (int)blockIdx.x; t < g.tiles; t += G_) ++my_tiles;
+  const int total_stages = my_tiles * NJT;
+  if (total_stages == 0) return;
+  // ring prologue: stages 0 and 1
+  issue(0, 0);
+  if (total_stages > 1) issue(1, 1 % NJT);
+  int gs = 0;   // global stage counter of this workgroup
+
+  for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
+    const long long row0 = (long long)tile * 128 + wave * 32;
+    const long long m = row0 + ml;
+    const bool mvalid = m < g.M;
+    const long long mc = mvalid ? m : (g.M - 1);
+    // ---- input rows -> B fragments (k permuted inside every 16-chunk: the lower lane takes elements 0-3 | 8-11, the upper 4-7 | 12-15)
+    bf16x8_t X[KC];
+    {
+      const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        uint4 v = *reinterpret_cast<const uint4*>(xr + 16 * c);
+        if (!mvalid) v = make_uint4(0u, 0u, 0u, 0u);
+        swap_lo(v.x, v.z);
+        swap_lo(v.y, v.w);
+        X[c] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+    f32x16_t Y[NOT];
+#pragma unroll
+    for (int t = 0; t < NOT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
+    // relu-gate bits of mid tile jt are fetched one iteration ahead, BEFORE that iteration's DMA is issued: memory operations
+    // complete in order, so a load younger than a DMA would make its consumer wait for the whole stage
+    const long long blk = row0 >> 5;
+    unsigned bits_next = 0;
+    if constexpr (MODE == DMT_CHAIN_FFN_BWD) bits_next = g.mask[(blk * NJT + 0) * 64 + lane];
+
+#pragma unroll 1
+    for (int jt = 0; jt < NJT; ++jt, ++gs) {
+      const int buf = gs % CH_NS;
+      // stage gs has landed for this wavefront: everything but the DMA of stage gs + 1 (if issued) is complete
+      if (gs + 1 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // ... and for every wavefront; all of them have left stage gs - 1 (= buffer of stage gs + 2)
+      unsigned bits = bits_next;
+      if constexpr (MODE == DMT_CHAIN_FFN_BWD) {
+        if (jt + 1 < NJT) bits_next = g.mask[(blk * NJT + jt + 1) * 64 + lane];
+        asm volatile("" ::: "memory");
+      }
+      if (gs + 2 < total_stages) issue((gs + 2) % CH_NS, (jt + 2) % NJT);
+
+      const unsigned so = (unsigned)buf * STAGE;
+      // ---- GEMM 1: mid^T tile [32 j x 32 m] = A1[j, :] . in^T
+      f32x16_t H;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H[r] = 0.f;
+      {
+        constexpr int NB = (KC % 5 == 0) ? 5 : 4;
+        constexpr int NBATCH = KC / NB;
+        static_assert(KC % NB == 0, "KIN / 16 must be a multiple of 4 or 5");
+        bf16x8_t R0[5], R1[5];
+        const unsigned a1a = a1_lane + so;
+        auto rd = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int c = b * NB + (i < NB ? i : 0);
+            ch_read128<c * 32>(R[i], a1a);
+          });
+        };
+        auto mm = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+#pragma unroll
+          for (int i = 0; i < NB; ++i) H = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[b * NB + i], H, 0, 0, 0);
+        };
+        rd(R0, std::integral_constant<int, 0>{});
+        sfor<NBATCH>([&](auto bic) {
+          constexpr int b = decltype(bic)::value;
+          if constexpr (b + 1 < NBATCH) {
+            if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
+            else rd(R0, std::integral_constant<int, b + 1>{});
+            if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<5>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          } else {
+            if constexpr ((b & 1) == 0) { ch_wait<0>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          }
+        });
+      }
+      // ---- mid op on the accumulator: lane (m, hi) holds j = jt*32 + 8 q + 4 hi + i in register 4 q + i
+      unsigned hb[8];
+      if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+        f32x4_t b4[4];
+        sfor<4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          ch_read128f<q * 32>(b4[q], bias_lane + so);
+        });
+        ch_wait4f<0>(b4[0], b4[1], b4[2], b4[3]);
+        bits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = H[4 * q + i] + b4[q][i];
+            const bool pos = v > 0.f;
+            bits |= pos ? (1u << (4 * q + i)) : 0u;
+            H[4 * q + i] = pos ? v : 0.f;
+          }
+        if (g.mask != nullptr) g.mask[(blk * NJT + jt) * 64 + lane] = (unsigned short)bits;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[r] = ((bits >> r) & 1u) ? H[r] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) hb[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
+      if (g.mid_out != nullptr) {
+        // row m, columns jt*32 + 16 p + 8 hi .. +8 after pairing q = 2p (kept by the lower lane) with q = 2p + 1 (upper lane)
+        unsigned o[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) o[p] = hb[p];
+        swap_lo(o[0], o[2]); swap_lo(o[1], o[3]);
+        swap_lo(o[4], o[6]); swap_lo(o[5], o[7]);
+        if (mvalid) {
+          bf16_t* dst = g.mid_out + m * g.ld_mid + jt * 32 + 8 * hi;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<uint4*>(dst + 16) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+      }
+      const bf16x8_t Hb0 = __builtin_bit_cast(bf16x8_t, make_uint4(hb[0], hb[1], hb[2], hb[3]));
+      const bf16x8_t Hb1 = __builtin_bit_cast(bf16x8_t, make_uint4(hb[4], hb[5], hb[6], hb[7]));
+      // ---- GEMM 2: out^T [NOUT x 32 m] += A2[:, tile] . mid^T tile
+      {
+        constexpr int NF = 2 * NOT;
+        constexpr int NB = (NF % 5 == 0) ? 5 : ((NF % 4 == 0) ? 4 : 3);
+        constexpr int NBATCH = NF / NB;
+        static_assert(NF % NB == 0, "2 * output tiles must be a multiple of 3, 4 or 5");
+        bf16x8_t R0[5], R1[5];
+        const unsigned a2a = a2_lane + so;
+        auto rd = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fi = b * NB + (i < NB ? i : 0);
+            constexpr int t = fi >> 1, f = fi & 1;
+            ch_read128<t * 32 * G::A2_STRIDE + f * 32>(R[i], a2a);
+          });
+        };
+        auto mm = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<NB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fi = b * NB + i;
+            constexpr int t = fi >> 1, f = fi & 1;
+            Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], f == 0 ? Hb0 : Hb1, Y[t], 0, 0, 0);
+          });
+        };
+        rd(R0, std::integral_constant<int, 0>{});
+        sfor<NBATCH>([&](auto bic) {
+          constexpr int b = decltype(bic)::value;
+          if constexpr (b + 1 < NBATCH) {
+            if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
+            else rd(R0, std::integral_constant<int, b + 1>{});
+            if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<5>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          } else {
+            if constexpr ((b & 1) == 0) { ch_wait<0>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          }
+        });
+      }
+    }
+
+    // ---- epilogue: accumulator register (t, 4 q + i) of lane (m, hi) is output column n = 32 t + 8 q + 4 hi + i of row m
+    //      bias2 / residual (the permuted input fragments hold x[m, n] at fragment 2 t + (q >> 1), element 4 (q & 1) + i)
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NOT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = 32 * t + 8 * q + 4 * hi;
+        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == DMT_CHAIN_FFN_LN && n0 < G::NOUT) b = *reinterpret_cast<const f32x4_t*>(g.bias2 + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = 0.f;
+          constexpr int KCc = KC;
+          const int c = 2 * t + (q >> 1);
+          if (c < KCc) x = bf2f((bf16_t)X[c < KCc ? c : 0][4 * (q & 1) + i]);
+          float v = Y[t][4 * q + i] + b[i] + x;
+          if constexpr (G::NOUT % 32 != 0) { if (n0 + i >= G::NOUT) v = 0.f; }   // padded output columns
+          Y[t][4 * q + i] = v;
+          sum += v;
+        }
+      }
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+      sum += __shfl_xor(sum, 32, 64);
+      mean = sum / (float)G::NOUT;
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < NOT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int n = 32 * t + 8 * q + 4 * hi + i;
+            const float d = (n < G::NOUT) ? (Y[t][4 * q + i] - mean) : 0.f;
+            sq += d * d;
+          }
+      sq += __shfl_xor(sq, 32, 64);
+      const float den = sqrtf(sq / (float)G::NOUT + g.eps);
+      rstd = 1.f / den;
+      if (g.stats != nullptr && mvalid && hi == 0) { g.stats[2 * m] = mean; g.stats[2 * m + 1] = rstd; }
+    }
+    // stores: 16 bytes per lane after pairing q = 2p (lower lane) with q = 2p + 1 (upper lane): row m, columns 32 t + 16 p + 8 hi .. +8
+#pragma unroll
+    for (int t = 0; t < NOT; ++t) {
+      unsigned su[8], yu[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = 32 * t + 8 * q + 4 * hi;
+        su[2 * q] = dmt_pack_bf16(Y[t][4 * q + 0], Y[t][4 * q + 1]);
+        su[2 * q + 1] = dmt_pack_bf16(Y[t][4 * q + 2], Y[t][4 * q + 3]);
+        if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+          f32x4_t gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+          if (n0 < G::NOUT) { gm = *reinterpret_cast<const f32x4_t*>(g.gamma + n0); bt = *reinterpret_cast<const f32x4_t*>(g.beta + n0); }
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = gm[i] * ((Y[t][4 * q + i] - mean) * rstd) + bt[i];
+          yu[2 * q] = dmt_pack_bf16(o[0], o[1]);
+          yu[2 * q + 1] = dmt_pack_bf16(o[2], o[3]);
+        }
+      }
+      swap_lo(su[0], su[2]); swap_lo(su[1], su[3]);
+      swap_lo(su[4], su[6]); swap_lo(su[5], su[7]);
+      if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+        swap_lo(yu[0], yu[2]); swap_lo(yu[1], yu[3]);
+        swap_lo(yu[4], yu[6]); swap_lo(yu[5], yu[7]);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int col = 32 * t + 16 * p + 8 * hi;
+        if (mvalid && col < G::NOUT) {
+          if (g.s_out != nullptr)
+            *reinterpret_cast<uint4*>(g.s_out + m * g.ld_out + col) = make_uint4(su[4 * p], su[4 * p + 1], su[4 * p + 2], su[4 * p + 3]);
+          if constexpr (MODE == DMT_CHAIN_FFN_LN)
+            *reinterpret_cast<uint4*>(g.y_out + m * g.ld_out + col) = make_uint4(yu[4 * p], yu[4 * p + 1], yu[4 * p + 2], yu[4 * p + 3]);
+        }
+      }
+    }
+  }
+}
+
+template <typename G>
+int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
+  ChainArgs a;
+  a.M = d->M;
+  a.in = (const bf16_t*)d->in; a.ld_in = d->ld_in;
+  a.image = (const unsigned char*)d->image;
+  a.bias2 = d->bias2; a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
+  a.s_out = (bf16_t*)d->s_out; a.y_out = (bf16_t*)d->y_out; a.ld_out = d->ld_out;
+  a.stats = d->stats;
+  a.mid_out = (bf16_t*)d->mid_out; a.ld_mid = d->ld_mid;
+  a.mask = (unsigned short*)d->mask;
+  a.tiles = (int)cdiv64(d->M, 128);
+  const int grid = a.tiles < 256 ? a.tiles : 256;
+  if (d->mode == DMT_CHAIN_FFN_LN)
+    hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN>), dim3(grid), dim3(CH_NT), 0, st, a);
+  else
+    hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_BWD>), dim3(grid), dim3(CH_NT), 0, st, a);
+  DMT_CHECK_LAUNCH("dmt_chain2");
+  return DMT_OK;
+}
+
+template <typename F>
+int chain_dispatch(int kin, int nmid, int nout, F&& f) {
+  if (kin == 320 && nmid == 1280 && nout == 320) return f(Geo<320, 1280, 320>{});
+  if (kin == 80 && nmid == 320 && nout == 80) return f(Geo<80, 320, 80>{});
+  dmt_set_error("dmt_chain: unsupported geometry kin=%d nmid=%d nout=%d (built: 320/1280/320, 80/320/80)", kin, nmid, nout);
+  return DMT_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int dmt_chain_supported(int32_t kin, int32_t nmid, int32_t nout) {
+  return (kin == 320 && nmid == 1280 && nout == 320) || (kin == 80 && nmid == 320 && nout == 80);
+}
+
+extern "C" int dmt_chain_image_bytes(int32_t kin, int32_t nmid, int32_t nout, int64_t* bytes) {
+  DMT_CHECK_ARG(bytes != nullptr, "dmt_chain_image_bytes: null output");
+  return chain_dispatch(kin, nmid, nout, [&](auto geo) {
+    *bytes = decltype(geo)::IMAGE_BYTES;
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_chain_image_build(int32_t kin, int32_t nmid, int32_t nout, const float* a1, int64_t a1_rs, int64_t a1_cs, const float* a2,
+                                     int64_t a2_rs, int64_t a2_cs, const float* bias1, void* image, void* stream) {
+  DMT_CHECK_ARG(a1 && a2 && image, "dmt_chain_image_build: null pointer");
+  return chain_dispatch(kin, nmid, nout, [&](auto geo) {
+    typedef decltype(geo) G;
+    ImgArgs g;
+    g.a1 = a1; g.a1_rs = a1_rs; g.a1_cs = a1_cs;
+    g.a2 = a2; g.a2_rs = a2_rs; g.a2_cs = a2_cs;
+    g.bias1 = bias1;
+    g.img = (unsigned char*)image;
+    g.kin = kin; g.nmid = nmid; g.nout = nout;
+    g.a1_stride = G::A1_STRIDE; g.a1_bytes = G::A1_BYTES; g.a2_bytes = G::A2_BYTES; g.bias_off = G::BIAS_OFF; g.stage = G::STAGE;
+    g.slots = G::IMAGE_BYTES / 16;
+    long long nb = cdiv64(g.slots, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(chain_image_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
+    DMT_CHECK_LAUNCH("dmt_chain_image_build");
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_chain2(const dmt_chain_desc* d, void* stream) {
+  DMT_CHECK_ARG(d != nullptr, "dmt_chain2: null descriptor");
+  DMT_CHECK_ARG(d->mode == DMT_CHAIN_FFN_LN || d->mode == DMT_CHAIN_FFN_BWD, "dmt_chain2: bad mode %d", d->mode);
+  DMT_CHECK_ARG(d->M > 0 && d->in && d->image, "dmt_chain2: bad argument");
+  DMT_CHECK_ARG(d->ld_in % 8 == 0 && ((uintptr_t)d->in & 15) == 0, "dmt_chain2: input rows must be 16-byte aligned");
+  DMT_CHECK_ARG(d->M < (1ll << 31) - 256, "dmt_chain2: too many rows");
+  if (d->mode == DMT_CHAIN_FFN_LN) {
+    DMT_CHECK_ARG(d->bias2 && d->gamma && d->beta && d->y_out, "dmt_chain2(ffn_ln): bias2 / gamma / beta / y_out are required");
+    DMT_CHECK_ARG(d->kin == d->nout, "dmt_chain2(ffn_ln): the residual needs kin == nout");
+  } else {
+    DMT_CHECK_ARG(d->mask && d->s_out, "dmt_chain2(ffn_bwd): mask and s_out (dx) are required");
+    DMT_CHECK_ARG(d->kin == d->nout, "dmt_chain2(ffn_bwd): the residual needs kin == nout");
+  }
+  DMT_CHECK_ARG(d->ld_out % 8 == 0 && (((uintptr_t)d->s_out | (uintptr_t)d->y_out) & 15) == 0, "dmt_chain2: output rows must be 16-byte aligned");
+  DMT_CHECK_ARG(d->mid_out == nullptr || (d->ld_mid % 8 == 0 && ((uintptr_t)d->mid_out & 15) == 0), "dmt_chain2: mid rows must be 16-byte aligned");
+  return chain_dispatch(d->kin, d->nmid, d->nout, [&](auto geo) { return launch_chain<decltype(geo)>(d, (hipStream_t)stream); });
+}

@@ -25,6 +25,7 @@ extern "C" int dmt_struct_size(int which) {
     case 5: return (int)sizeof(dmt_attn_bwd_desc);
     case 6: return (int)sizeof(dmt_table_map);
     case 7: return (int)sizeof(dmt_cast_job);
+    case 8: return (int)sizeof(dmt_chain_desc);
     default: return -1;
   }
 }

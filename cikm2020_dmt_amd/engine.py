@@ -271,6 +271,7 @@ class DMTEngine:
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
         self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
+        self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
 
     def gather_bytes(self, batch, seq_T) -> float:
         """Algorithmic HBM bytes of one gather launch: int32 indices read once, fp32 table rows for
@@ -397,6 +398,10 @@ class DMTEngine:
 
     def ff(self, x, ffs):
         """ff(inputs, [d_ff, d_model]) (TransformerModel_util.py:212-235)."""
+        chain = self.store.chain.get(ffs) if x.dtype == torch.bfloat16 else None
+        if chain is not None and self.use_chain:
+            return ops.FFNLNChainFn.apply(x, self._lf(ffs + "dense/kernel"), self._lf(ffs + "dense/bias"), self._lf(ffs + "dense_1/kernel"),
+                                          self._lf(ffs + "dense_1/bias"), self._lf(ffs + "ln/gamma"), self._lf(ffs + "ln/beta"), chain, 1e-8)
         s = ops.FFNFn.apply(x, self._lf(ffs + "dense/kernel"), self._lf(ffs + "dense/bias"), self._lf(ffs + "dense_1/kernel"),
                             self._lf(ffs + "dense_1/bias"), self._w(ffs + "dense/kernel"), self._w(ffs + "dense_1/kernel"))
         return ops.layer_norm(s, self._lf(ffs + "ln/gamma"), self._lf(ffs + "ln/beta"))

@@ -349,6 +349,104 @@ class FFNFn(torch.autograd.Function):
         return dx.reshape(ctx.xshape), dW1, db1, dW2, db2, None, None
 
 
+# ------------------------------------------------------------------------------------------------ fused ff + ln
+def chain_image_bytes(kin, nmid, nout):
+    """Size of a dmt_chain2 weight image for this geometry, or None when no kernel is built for it."""
+    if not L.load().dmt_chain_supported(kin, nmid, nout):
+        return None
+    n = C.c_int64(0)
+    L.call("dmt_chain_image_bytes", kin, nmid, nout, C.byref(n))
+    return int(n.value)
+
+
+def chain_image_build(geo, a1, a1_rs, a1_cs, a2, a2_rs, a2_cs, bias1, image):
+    L.call("dmt_chain_image_build", geo[0], geo[1], geo[2], p(a1), a1_rs, a1_cs, p(a2), a2_rs, a2_cs, p(bias1), p(image), stream_ptr())
+
+
+def _chain_call(mode, geo, x2, image, M, *, bias2=None, gamma=None, beta=None, eps=0.0, s_out=None, y_out=None, stats=None, mid_out=None, mask=None):
+    d = L.ChainDesc()
+    d.mode, d.kin, d.nmid, d.nout, d.M = mode, geo[0], geo[1], geo[2], M
+    d.in_, d.ld_in = x2.data_ptr(), x2.stride(0)
+    d.image = image.data_ptr()
+    d.bias2, d.gamma, d.beta, d.eps = (bias2.data_ptr() if bias2 is not None else None, gamma.data_ptr() if gamma is not None else None,
+                                        beta.data_ptr() if beta is not None else None, float(eps))
+    out = s_out if s_out is not None else y_out
+    d.s_out = s_out.data_ptr() if s_out is not None else None
+    d.y_out = y_out.data_ptr() if y_out is not None else None
+    d.ld_out = out.stride(0)
+    d.stats = stats.data_ptr() if stats is not None else None
+    d.mid_out, d.ld_mid = (mid_out.data_ptr(), mid_out.stride(0)) if mid_out is not None else (None, 0)
+    d.mask = mask.data_ptr() if mask is not None else None
+    flops = 2.0 * M * geo[1] * (geo[0] + geo[2])
+    with _Timed("gemm_bf16", flops):
+        L.call("dmt_chain2", C.byref(d), stream_ptr())
+    if PROFILE is not None:
+        byt = M * (geo[0] + geo[2] * ((s_out is not None) + (y_out is not None))) * 2 + (M * geo[1] * 2 if mid_out is not None else 0)
+        PROFILE.setdefault("gemm_bytes", []).append(float(byt + image.numel()))
+
+
+class FFNLNChainFn(torch.autograd.Function):
+    """y = ln(relu(x W1 + b1) W2 + b2 + x): ff() + ln() of TransformerModel_util.py:212-235 as ONE launch (dmt_chain2), the
+    d_ff-wide activation never re-read from memory.  Backward: LayerNorm gradient (dmt_ln_bwd), then dh / dx by the same kernel
+    in its FFN_BWD mode (relu gate from the bit mask the forward wrote), weight gradients by the reduction GEMMs over h / dh."""
+
+    @staticmethod
+    def forward(ctx, x, w1_leaf, b1_leaf, w2_leaf, b2_leaf, gamma, beta, chain, eps):
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d)
+        if x2.stride(-1) != 1 or x2.stride(0) % 8 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        geo = chain["geo"]
+        dev = x.device
+        train = any(ctx.needs_input_grad[:7])
+        y = torch.empty((M, d), dtype=BF16, device=dev)
+        if train:
+            s = torch.empty((M, d), dtype=BF16, device=dev)
+            stats = torch.empty((M, 2), dtype=F32, device=dev)
+            h = torch.empty((M, geo[1]), dtype=BF16, device=dev)
+            mask = torch.empty((4 * ((M + 127) // 128), geo[1] // 32, 64), dtype=torch.int16, device=dev)
+        else:
+            s = stats = h = mask = None
+        _chain_call(L.DMT_CHAIN_FFN_LN, geo, x2, chain["fwd"], M, bias2=b2_leaf, gamma=gamma, beta=beta, eps=eps, s_out=s, y_out=y,
+                    stats=stats, mid_out=h, mask=mask)
+        ctx.chain, ctx.leaves, ctx.gb = chain, (w1_leaf, b1_leaf, w2_leaf, b2_leaf), (gamma, beta)
+        ctx.xshape = x.shape
+        if train:
+            ctx.save_for_backward(x2, s, stats, h, mask)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, s, stats, h, mask = ctx.saved_tensors
+        M, d = x2.shape
+        geo = ctx.chain["geo"]
+        dy2 = dy.reshape(-1, d)
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        gamma, beta = ctx.gb
+        # ---- LayerNorm gradient: ds, dgamma / dbeta straight into the gradient arena
+        ds = torch.empty((M, d), dtype=BF16, device=x2.device)
+        gg, gbv = _grad_view(gamma), _grad_view(beta)
+        direct = gg is not None and gbv is not None and gg.dim() == 1 and gbv.dim() == 1
+        dg = gg if direct else torch.zeros((d,), dtype=F32, device=x2.device)
+        db = gbv if direct else torch.zeros((d,), dtype=F32, device=x2.device)
+        npart = L.load().dmt_ln_bwd_partials(M)
+        partials = torch.empty((npart, 2 * d), dtype=F32, device=x2.device)
+        L.call("dmt_ln_bwd", L.DMT_BF16, M, d, p(s), s.stride(0), p(gamma), p(stats), p(dy2), _row_major2d(dy2, "dy"), p(ds), d, p(dg), p(db),
+               p(partials), stream_ptr())
+        # ---- dh = (ds W2^T) * [h > 0], dx = dh W1^T + ds
+        dx = torch.empty((M, d), dtype=BF16, device=x2.device)
+        dh = torch.empty((M, geo[1]), dtype=BF16, device=x2.device)
+        _chain_call(L.DMT_CHAIN_FFN_BWD, geo, ds, ctx.chain["bwd"], M, s_out=dx, mid_out=dh, mask=mask)
+        w1_leaf, b1_leaf, w2_leaf, b2_leaf = ctx.leaves
+        dW2, db2 = linear_backward_weight(h, ds, w_leaf=w2_leaf, b_leaf=b2_leaf)
+        dW1, db1 = linear_backward_weight(x2, dh, w_leaf=w1_leaf, b_leaf=b1_leaf)
+        return (dx.reshape(ctx.xshape), dW1, db1, dW2, db2, None if direct else dg, None if direct else db, None, None)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out):
     d = L.AttnDesc()

@@ -210,6 +210,17 @@ class VariableStore:
         self.table: Dict[str, torch.Tensor] = {}
         for name, info in self.tables.items():
             self.table[name] = self.tab_p[info.offset: info.offset + info.numel].view(info.shape)
+        # weight images of the fused feed-forward kernels (dmt_chain2), one forward + one backward image per ff scope
+        self.chain: Dict[str, dict] = {}
+        if bf:
+            d, dff = self.spec["d_model"], self.spec["d_ff"]
+            nbytes = ops.chain_image_bytes(d, dff, d)
+            if nbytes is not None:
+                for name in self.leaves:
+                    if name.endswith("/dense/kernel") and "positionwise_feedforward" in name:
+                        scope = name[: -len("dense/kernel")]
+                        self.chain[scope] = dict(geo=(d, dff, d), fwd=torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                                                 bwd=torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
     # ------------------------------------------------------------------ values
     def initialize(self, seed: int = 0):
@@ -258,6 +269,11 @@ class VariableStore:
             self._cast_jobs = ops.cast_shadow_jobs([(self.weight[n].f32, self.weight[n].lp, self.weight[n].lp_t) for n in self._w2d],
                                                    self.device)
         ops.cast_shadow_batched(self._cast_jobs)
+        for scope, ch in self.chain.items():
+            w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
+            # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]
+            ops.chain_image_build(ch["geo"], w1, 1, w1.stride(0), w2, 1, w2.stride(0), b1, ch["fwd"])
+            ops.chain_image_build(ch["geo"], w2, w2.stride(0), 1, w1, w1.stride(0), 1, None, ch["bwd"])
 
     def zero_grad(self):
         self.grads.zero_()

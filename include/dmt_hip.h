@@ -41,7 +41,7 @@ int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
 const char* dmt_build_arch(void);
 /* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
- * 5 attn_bwd_desc, 6 table_map (lets a binding verify its struct layout). */
+ * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc (lets a binding verify its struct layout). */
 int dmt_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -349,6 +349,51 @@ int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk,
 int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, const void* P, void* dP_dS, void* Pd,
                     int64_t ld, const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed,
                     float drop_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused position-wise feed-forward + LayerNorm (bf16): two chained MFMA GEMMs whose d_ff-wide intermediate stays on the
+ * compute unit (registers), input rows resident in registers, weights streamed through LDS from a prebuilt image.
+ * Replaces: ff(inputs, [d_ff, d_model]) -- dense(relu) -> dense -> += inputs -> ln()
+ *           (model/net/TransformerModel_util.py:212-235 with ln() :58-78) as ONE launch, and its input gradient.
+ *   mode DMT_CHAIN_FFN_LN : s = relu(in A1^T + bias1) A2^T + bias2 + in;  y = gamma (s - mean) / sqrt(var + eps) + beta
+ *        A1[j, k] = W1[k, j]  ("dense/kernel"   [d_model, d_ff]),  A2[n, j] = W2[j, n]  ("dense_1/kernel" [d_ff, d_model])
+ *        outputs: y_out, s_out (pre-LN sum, or NULL), stats [M, 2] = (mean, 1/sqrt(var + eps)) (or NULL),
+ *                 mid_out = h [M, nmid] (or NULL: inference), mask = relu gate bits (or NULL)
+ *   mode DMT_CHAIN_FFN_BWD: dh = (in A1^T) * gate;  dx = dh A2^T + in        (in = ds, the gradient w.r.t. s)
+ *        A1[j, n] = W2[j, n],  A2[k, j] = W1[k, j];  outputs: s_out = dx, mid_out = dh (for the weight gradients), mask = input
+ * Images are built by dmt_chain_image_build from the fp32 masters (after every optimizer step); geometry (kin, nmid, nout) must
+ * be one dmt_chain_supported() accepts.  mask: uint16 [4 * ceil(M / 128)][nmid / 32][64] (one bit per element of mid, in the
+ * kernel's own lane order: only dmt_chain2 reads it back).
+ * ------------------------------------------------------------------------------------------------ */
+#define DMT_CHAIN_FFN_LN 0
+#define DMT_CHAIN_FFN_BWD 1
+
+typedef struct {
+  int32_t mode;
+  int32_t kin, nmid, nout;
+  int64_t M;
+  const void* in;        /* bf16 [M, kin], row stride ld_in (multiple of 8), 16-byte aligned */
+  int64_t ld_in;
+  const void* image;     /* dmt_chain_image_build output for this mode                       */
+  const float* bias2;    /* fp32 [nout]   (FFN_LN)                                           */
+  const float* gamma;    /* fp32 [nout]   (FFN_LN)                                           */
+  const float* beta;     /* fp32 [nout]   (FFN_LN)                                           */
+  float eps;             /* 1e-8 in the reference (TransformerModel_util.py:58)              */
+  void* s_out;           /* bf16 [M, nout] pre-LN sum (FFN_LN, optional) / dx (FFN_BWD)      */
+  void* y_out;           /* bf16 [M, nout] (FFN_LN)                                          */
+  int64_t ld_out;
+  float* stats;          /* fp32 [M, 2] or NULL                                              */
+  void* mid_out;         /* bf16 [M, nmid] or NULL                                           */
+  int64_t ld_mid;
+  void* mask;            /* see above                                                        */
+} dmt_chain_desc;
+
+int dmt_chain_supported(int32_t kin, int32_t nmid, int32_t nout);
+int dmt_chain_image_bytes(int32_t kin, int32_t nmid, int32_t nout, int64_t* bytes);
+/* A1[j, k] = a1[j * a1_rs + k * a1_cs] (j < nmid, k < kin), A2[n, j] = a2[n * a2_rs + j * a2_cs] (n < nout, j < nmid), bias1 [nmid] or NULL */
+int dmt_chain_image_build(int32_t kin, int32_t nmid, int32_t nout, const float* a1, int64_t a1_rs, int64_t a1_cs, const float* a2,
+                          int64_t a2_rs, int64_t a2_cs, const float* bias1, void* image, void* stream);
+int dmt_chain2(const dmt_chain_desc* d, void* stream);
 
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
