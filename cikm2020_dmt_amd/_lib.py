@@ -78,6 +78,11 @@ class ChainDesc(C.Structure):
 DMT_CHAIN_FFN_LN, DMT_CHAIN_FFN_BWD = 0, 1
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [("A", c_vp), ("ld_a", c_i64), ("a_cols", c_i32), ("B", c_vp), ("ld_b", c_i64), ("M", c_i64), ("N", c_i32), ("C", c_vp),
+                ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32)]
+
+
 class TableMap(C.Structure):
     _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
                 ("elem_off", c_i64 * DMT_MAX_TABLES)]
@@ -124,6 +129,7 @@ _SIGS = {
     "dmt_chain_image_bytes": [c_i32, c_i32, c_i32, C.POINTER(c_i64)],
     "dmt_chain_image_build": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "dmt_chain2": [C.POINTER(ChainDesc), c_vp],
+    "dmt_wgrad320": [C.POINTER(WgradDesc), c_vp],
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported"])

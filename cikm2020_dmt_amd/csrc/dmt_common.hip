@@ -26,6 +26,7 @@ extern "C" int dmt_struct_size(int which) {
     case 6: return (int)sizeof(dmt_table_map);
     case 7: return (int)sizeof(dmt_cast_job);
     case 8: return (int)sizeof(dmt_chain_desc);
+    case 9: return (int)sizeof(dmt_wgrad_desc);
     default: return -1;
   }
 }

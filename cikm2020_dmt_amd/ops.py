@@ -7,6 +7,7 @@ raises (cikm2020_dmt_amd/_lib.py).
 from __future__ import annotations
 
 import ctypes as C
+import ctypes as _ct
 import math
 from typing import Optional, Sequence
 
@@ -168,6 +169,28 @@ def _grad_view(leaf):
     return g
 
 
+WGRAD320_MIN_ROWS = 16384
+
+
+def wgrad320(A, B, C, transposed, bias=None, bias_of=0):
+    """C[320, N] (+)= A[M, 320]^T B[M, N]  (transposed: C[N, 320]); bias (+)= column sums of B (bias_of 1) or of A (2).  fp32 atomics."""
+    d = L.WgradDesc()
+    d.A, d.ld_a, d.a_cols = A.data_ptr(), A.stride(0), A.shape[1]
+    d.B, d.ld_b = B.data_ptr(), B.stride(0)
+    d.M, d.N = A.shape[0], B.shape[1]
+    d.C, d.ldc = C.data_ptr(), C.stride(0)
+    d.transposed = 1 if transposed else 0
+    d.bias, d.bias_of = (bias.data_ptr(), bias_of) if bias is not None else (None, 0)
+    if PROFILE is not None:
+        PROFILE.setdefault("gemm_bytes", []).append(float((A.numel() + B.numel()) * 2 + C.numel() * 4))
+    with _Timed("gemm_bf16", 2.0 * A.shape[0] * A.shape[1] * B.shape[1]):
+        L.call("dmt_wgrad320", _ct.byref(d), stream_ptr())
+
+
+def _wgrad320_operand_ok(t):
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
 def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     """dW[K,N] = x^T dz, db[N] = colsum(dz) (ones row), fp32, split over the (long) row dimension.
     When the parameter leaves expose their gradient-arena views the result is ACCUMULATED there by the kernel
@@ -180,6 +203,15 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     rows = K + 1 if want_bias else K
     tiles = ((rows + 127) // 128) * ((N + 127) // 128)
     split = _pick_split(tiles, M)
+    if (gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
+            and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
+            and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
+        # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block
+        if K == 320:
+            wgrad320(x, dz, gw, False, gb if want_bias else None, 1)
+        else:
+            wgrad320(dz, x, gw, True, gb if want_bias else None, 2)
+        return None, None
     if gw is not None and (gb is not None or not want_bias):
         gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
              split_k=split, accumulate=True)

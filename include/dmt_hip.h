@@ -41,7 +41,7 @@ int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
 const char* dmt_build_arch(void);
 /* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
- * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc (lets a binding verify its struct layout). */
+ * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc (lets a binding verify its struct layout). */
 int dmt_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -394,6 +394,27 @@ int dmt_chain_image_bytes(int32_t kin, int32_t nmid, int32_t nout, int64_t* byte
 int dmt_chain_image_build(int32_t kin, int32_t nmid, int32_t nout, const float* a1, int64_t a1_rs, int64_t a1_cs, const float* a2,
                           int64_t a2_rs, int64_t a2_cs, const float* bias1, void* image, void* stream);
 int dmt_chain2(const dmt_chain_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradient of a dense layer whose input OR output is 320 (= d_model of the E64 configuration) wide, as one wide-block
+ * reduction over the batch x sequence rows (bf16 operands, fp32 ACCUMULATED into C by atomics -- C is the gradient arena):
+ *     transposed == 0:  C[i * ldc + j] += sum_m A[m, i] B[m, j]      (dW = X^T dY with X 320 wide:  A = X, B = dY)
+ *     transposed == 1:  C[j * ldc + i] += sum_m A[m, i] B[m, j]      (dW = X^T dY with dY 320 wide: A = dY, B = X)
+ *     bias_of == 1: bias[j] += sum_m B[m, j];   bias_of == 2: bias[i] += sum_m A[m, i]   (db = column sums of dY)
+ * Replaces: the kernel / bias gradients of tf.layers.dense at model/net/TransformerModel_util.py:188-190 (Q, K, V) and
+ *           :224-228 (position-wise feed-forward), i.e. what dmt_gemm computes with a_ones_row for any shape.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* A; int64_t ld_a; int32_t a_cols;   /* bf16 [M, 320]                                   */
+  const void* B; int64_t ld_b;                   /* bf16 [M, N]                                     */
+  int64_t M;
+  int32_t N;                                     /* multiple of 8                                   */
+  float* C; int64_t ldc;
+  int32_t transposed;
+  float* bias;
+  int32_t bias_of;
+} dmt_wgrad_desc;
+int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream);
 
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
