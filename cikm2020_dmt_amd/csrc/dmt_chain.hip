@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((address_space(3))) void* lds_vp;
 
-constexpr int CH_NT = 256;   // 4 wavefronts
+constexpr int CH_NT = 512;   // 8 wavefronts = 4 producer / consumer pairs
 constexpr int CH_NS = 3;     // DMA ring depth
 
 template <int KIN_, int NMID_, int NOUT_>
@@ -52,12 +52,13 @@ struct Geo {
   static constexpr int A2_BYTES = NOT * 32 * A2_STRIDE;
   static constexpr int BIAS_OFF = A2_OFF + A2_BYTES;
   static constexpr int RAW = BIAS_OFF + 128;
-  static constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
-  static constexpr int PER_WAVE = STAGE / 4096;    // DMA instructions (1 KB each) per wavefront and stage
-  static constexpr int NST = NJT + 2;              // image stages: stage u = A1 / bias1 of mid tile u  |  A2 of mid tile u - 2
+  static constexpr int STAGE = (RAW + 8191) / 8192 * 8192;
+  static constexpr int PER_WAVE = STAGE / 8192;    // DMA instructions (1 KB each) per wavefront and stage
+  static constexpr int HAND_BYTES = 4 * 4096;      // producer -> consumer hand-off: [pair][slot 2][fragment 2][64 lanes][16 B]
+  static constexpr int NST = NJT + 1;              // image stages: stage u = A1 / bias1 of mid tile u  |  A2 of mid tile u - 1
   static constexpr long long IMAGE_BYTES = (long long)NST * STAGE;
   static_assert(KIN % 16 == 0 && NMID % 32 == 0, "chain geometry");
-  static_assert(CH_NS * STAGE <= 160 * 1024, "LDS ring exceeds 160 KB");
+  static_assert(CH_NS * STAGE + HAND_BYTES <= 160 * 1024, "LDS ring exceeds 160 KB");
 };
 
 template <int... I, typename F>
@@ -83,7 +84,7 @@ struct ImgArgs {
 __global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) {
   for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < g.slots; s += (long long)gridDim.x * 256) {
     const long long byte = s * 16;
-    const int u = (int)(byte / g.stage), off = (int)(byte % g.stage);   // stage u: A1 / bias1 of mid tile u, A2 of mid tile u - 2
+    const int u = (int)(byte / g.stage), off = (int)(byte % g.stage);   // stage u: A1 / bias1 of mid tile u, A2 of mid tile u - 1
     const int njt = g.nmid / 32;
     u32x4_t o = {0u, 0u, 0u, 0u};
     if (off < g.a1_bytes) {
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) {
     } else if (off < g.a1_bytes + g.a2_bytes) {
       const int o2 = off - g.a1_bytes;
       const int n = o2 / 80, sl = (o2 % 80) / 16;
-      if (sl < 4 && n < g.nout && u >= 2) {
-        const int jt = u - 2;
+      if (sl < 4 && n < g.nout && u >= 1) {
+        const int jt = u - 1;
         const int f = sl >> 1, half = sl & 1;
         unsigned short h[8];
 #pragma unroll
@@ -153,6 +154,8 @@ template <int OFF> __device__ __forceinline__ void ch_read128f(f32x4_t& dst, uns
 template <int N> __device__ __forceinline__ void ch_wait(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d, bf16x8_t& e) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "i"(N));
 }
+__device__ __forceinline__ void ch_write128(unsigned addr, u32x4_t v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int N> __device__ __forceinline__ void ch_wait2(bf16x8_t& a, bf16x8_t& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N)); }
 __device__ __forceinline__ void ch_fake(bf16x8_t& r) { asm volatile("" : "=v"(r)); }
 __device__ __forceinline__ void ch_keep(f32x16_t& h) { asm volatile("" : "+v"(h)); }
 template <int N> __device__ __forceinline__ void ch_wait8(bf16x8_t (&R)[8]) {
@@ -168,36 +171,41 @@ __device__ __forceinline__ void swap_lo(unsigned& a, unsigned& b) {
   a = r[0]; b = r[1];
 }
 
-// DBG (timing experiments only, results are garbage): 1 no DMA, 2 no side-output stores (mid, mask), 4 plain instead of non-temporal stores,
-// 8 no LDS fragment reads, 16 no mid op, 32 no barrier / DMA wait
+// DBG (timing experiments only, results are garbage): 1 no DMA, 2 no side-output stores (mid, mask), 64 no main loop
 template <typename G, int MODE, int DBG = 0>
-__global__ __launch_bounds__(CH_NT, 1) void chain2_kernel(const ChainArgs g) {
+__global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
   constexpr int KC = G::KC, NJT = G::NJT, NOT = G::NOT, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE, NST = G::NST;
   constexpr int NF = 2 * NOT;   // GEMM-2 fragments (output tile, k half) per mid tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_NS * STAGE];   // the ONLY LDS object
+  // 8 wavefronts = 4 producer / consumer pairs on the 4 SIMDs (wavefronts w and w + 4 share a SIMD), a pair owns 32 rows:
+  //   producer (w < 4):  holds the input rows as B fragments, GEMM 1 of every mid tile, mid op, hands the tile over through LDS
+  //   consumer (w >= 4): holds the output accumulators, GEMM 2 of every mid tile, epilogue (LayerNorm, stores)
+  // Both sides issue 20 MFMAs per mid tile into the same matrix pipe; whatever one of them waits for (LDS reads, the accumulator
+  // conversion, DMA issue, the dependent GEMM-1 chain) the other one's MFMAs fill.
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_NS * STAGE + G::HAND_BYTES];   // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3;
+  const bool producer = wave < 4;
   const int ml = lane & 31, hi = lane >> 5;
   const unsigned lds0 = (unsigned)(unsigned long long)((lds_vp)smem);
   const unsigned a1_lane = lds0 + ml * G::A1_STRIDE + 16 * hi;
   const unsigned a2_lane = lds0 + G::A2_OFF + ml * G::A2_STRIDE + 16 * hi;
   const unsigned bias_lane = lds0 + G::BIAS_OFF + 16 * hi;
+  const unsigned hand_lane = lds0 + CH_NS * STAGE + pair * 4096 + lane * 16;   // [slot 2][frag 2][64 lanes][16 B] per pair
 
   const __amdgpu_buffer_rsrc_t rimg =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.image), 0, (int)G::IMAGE_BYTES, 0x00020000);
-  // one 1 KB piece of stage `u` of the image -> ring buffer `buf` (piece p of this wavefront)
   auto issue1 = [&](int buf, int u, int p) {
     if constexpr ((DBG & 1) != 0) return;
-    unsigned char* sb = smem + buf * STAGE + wave * 1024 + p * 4096;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + wave * 1024 + p * 4096, 0, 0);
+    unsigned char* sb = smem + buf * STAGE + wave * 1024 + p * 8192;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + wave * 1024 + p * 8192, 0, 0);
   };
 
   const int G_ = (int)gridDim.x;
-  int my_tiles = 0;
-  for (int t = (int)blockIdx.x; t < g.tiles; t += G_) ++my_tiles;
-  const int total_stages = my_tiles * NST;
-  if (total_stages == 0) return;
-  // ring prologue: stages 0 and 1
+  if ((int)blockIdx.x >= g.tiles) return;
+  // static priority for the producers: their 20 MFMAs of a mid tile go first, so the accumulator conversion that follows them runs
+  // beside the consumer's MFMAs instead of after them (the condition is wave-uniform: s_setprio ignores EXEC)
+  if (wave < 4) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
   for (int p = 0; p < PER_WAVE; ++p) issue1(0, 0, p);
 #pragma unroll
@@ -205,114 +213,105 @@ __global__ __launch_bounds__(CH_NT, 1) void chain2_kernel(const ChainArgs g) {
   int gs = 0;   // global stage counter of this workgroup
 
   for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
-    const long long row0 = (long long)tile * 128 + wave * 32;
+    const long long row0 = (long long)tile * 128 + pair * 32;
     const long long m = row0 + ml;
     const bool mvalid = m < g.M;
     const long long mc = mvalid ? m : (g.M - 1);
-    // ---- input rows -> B fragments (k permuted inside every 16-chunk: the lower lane takes elements 0-3 | 8-11, the upper 4-7 | 12-15)
-    bf16x8_t X[KC];
-    {
-      const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
-        uint4 v = make_uint4(vl[0], vl[1], vl[2], vl[3]);
-        if (!mvalid) v = make_uint4(0u, 0u, 0u, 0u);
-        swap_lo(v.x, v.z);
-        swap_lo(v.y, v.w);
-        X[c] = __builtin_bit_cast(bf16x8_t, v);
-      }
-    }
-    f32x16_t Y[NOT];
-#pragma unroll
-    for (int t = 0; t < NOT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Y[t][r] = 0.f;
-    // relu-gate bits of a mid tile are fetched one iteration before its mid op, BEFORE that iteration's DMA is issued: memory
-    // operations complete in order, so a load younger than a DMA would make its consumer wait for the whole stage
     const long long blk = row0 >> 5;
-    unsigned bits_next = 0;
-    unsigned hbc[8];   // mid tile u - 2 as two bf16 B fragments (what iteration u multiplies by A2)
+
+    // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
+    auto top = [&](int u) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");   // (only the pieces of stage gs + 1 / younger stores may be open)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      (void)u;
+    };
+
+    if (producer) {
+      // ---- input rows -> B fragments (k permuted inside every 16-chunk: the lower lane takes elements 0-3 | 8-11, the upper 4-7 | 12-15)
+      bf16x8_t X[KC];
+      {
+        const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) hbc[p] = 0u;
-    f32x16_t HA, HB;   // mid-tile accumulators: one is being accumulated (tile u), the other converted (tile u - 1)
-
-    // Iteration u of a row tile (stage u of the image = A1 / bias1 of mid tile u  |  A2 of mid tile u - 2), three independent streams:
-    //     GEMM 1 of mid tile u      Hcur = bias1 + A1[tile u] . in^T                          (u < NJT)        -- matrix pipe
-    //     mid op of mid tile u - 1  relu / gate, bf16 pack, store of h                        (1 <= u <= NJT)   -- VALU
-    //     GEMM 2 of mid tile u - 2  out^T += A2[:, tile u-2] . mid^T                          (u >= 2)          -- matrix pipe
-    // The MFMAs of the two GEMMs alternate, so no MFMA depends on its predecessor (a chain into one accumulator issues at half
-    // rate), and the accumulator -> B-fragment conversion of a tile has a whole iteration of MFMAs to hide behind.
-    auto iteration = [&](auto g1c, auto midc, auto g2c, int u, f32x16_t& Hcur, f32x16_t& Hprev) {
-      constexpr bool DO_G1 = decltype(g1c)::value, DO_MID = decltype(midc)::value, DO_G2 = decltype(g2c)::value;
-      constexpr int PB = 4;   // fragments of one GEMM per batch (2 x 2 x PB x 4 registers hold the two batches in flight)
-      constexpr int NBAT = (((DO_G1 ? KC : 0) + PB - 1) / PB > ((DO_G2 ? NF : 0) + PB - 1) / PB) ? ((DO_G1 ? KC : 0) + PB - 1) / PB
-                                                                                                 : ((DO_G2 ? NF : 0) + PB - 1) / PB;
-      constexpr int K1 = DO_G1 ? (KC + NBAT - 1) / NBAT : 0;   // GEMM-1 fragments per batch
-      constexpr int K2 = DO_G2 ? (NF + NBAT - 1) / NBAT : 0;   // GEMM-2 fragments per batch
-      constexpr int KB = K1 + K2;                              // reads per batch (always issued in full: the waits count them)
-      static_assert(KB >= 1 && KB <= 8, "batch size");
-      const int buf = gs % CH_NS;
-      // stage gs has landed for this wavefront: at most the 12 youngest memory operations (DMA pieces of stage gs + 1, stores) are open
-      if constexpr ((DBG & 32) == 0) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // ... and for every wavefront; all of them have left stage gs - 1 (= buffer of stage gs + 2)
+        for (int c = 0; c < KC; ++c) {
+          const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
+          uint4 v = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+          if (!mvalid) v = make_uint4(0u, 0u, 0u, 0u);
+          swap_lo(v.x, v.z);
+          swap_lo(v.y, v.w);
+          X[c] = __builtin_bit_cast(bf16x8_t, v);
+        }
       }
-      unsigned bits = bits_next;      // gate bits of mid tile u - 1
-      if constexpr (MODE == DMT_CHAIN_FFN_BWD && DO_G1) {
-        bits_next = g.mask[(blk * NJT + u) * 64 + lane];
-        asm volatile("" ::: "memory");
-      }
-      const int dbuf = (gs + 2) % CH_NS;
-      const int du = (u + 2) % NST;
-      const unsigned so = (unsigned)buf * STAGE;
-      const unsigned a1a = a1_lane + so, a2a = a2_lane + so;
-
-      bf16x8_t R0[8], R1[8];
-      f32x4_t b4[4];
-      auto rd = [&](bf16x8_t (&R)[8], auto bic) {
-        constexpr int b = decltype(bic)::value;
-        sfor<KB>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr ((DBG & 8) != 0) {
-            ch_fake(R[i]);
-          } else if constexpr (i < K1) {
-            constexpr int c = (b * K1 + i < KC) ? b * K1 + i : 0;
+      unsigned bits_next = 0;
+      if constexpr (MODE == DMT_CHAIN_FFN_BWD) bits_next = g.mask[(blk * NJT + 0) * 64 + lane];
+#pragma unroll 1
+      for (int u = 0; u < NJT; ++u, ++gs) {
+        const int buf = gs % CH_NS;
+        top(u);
+        unsigned bits = bits_next;
+        if constexpr (MODE == DMT_CHAIN_FFN_BWD) {
+          bits_next = g.mask[(blk * NJT + (u + 1 < NJT ? u + 1 : u)) * 64 + lane];   // gate bits of the next tile, older than the DMA below
+          asm volatile("" ::: "memory");
+        }
+        const int dbuf = (gs + 2) % CH_NS, du = (u + 2) % NST;
+        const unsigned so = (unsigned)buf * STAGE;
+        const unsigned a1a = a1_lane + so;
+        constexpr int PB = (KC % 5 == 0) ? 5 : 4, NBAT = KC / PB;
+        static_assert(KC % PB == 0, "KIN / 16 must be a multiple of 4 or 5");
+        bf16x8_t R0[5], R1[5];
+        f32x4_t b4[4];
+        f32x16_t Ha;   // (one accumulator chain: the consumer's MFMAs on the same SIMD fill its dependency gaps)
+        auto rd = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int c = b * PB + (i < PB ? i : 0);
             ch_read128<c * 32>(R[i], a1a);
-          } else {
-            constexpr int fi = (b * K2 + (i - K1) < NF) ? b * K2 + (i - K1) : 0;
-            constexpr int t = fi >> 1, f = fi & 1;
-            ch_read128<t * 32 * G::A2_STRIDE + f * 32>(R[i], a2a);
+          });
+        };
+        auto mm = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<PB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int c = b * PB + i;
+            Ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[c], Ha, 0, 0, 0);
+          });
+        };
+        if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+          sfor<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            ch_read128f<q * 32>(b4[q], bias_lane + so);
+          });
+        }
+        rd(R0, std::integral_constant<int, 0>{});
+        sfor<NBAT>([&](auto bic) {
+          constexpr int b = decltype(bic)::value;
+          if constexpr (b + 1 < NBAT) {
+            if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
+            else rd(R0, std::integral_constant<int, b + 1>{});
           }
-        });
-      };
-      const bf16x8_t Hb0 = __builtin_bit_cast(bf16x8_t, make_uint4(hbc[0], hbc[1], hbc[2], hbc[3]));
-      const bf16x8_t Hb1 = __builtin_bit_cast(bf16x8_t, make_uint4(hbc[4], hbc[5], hbc[6], hbc[7]));
-      auto mm = [&](bf16x8_t (&R)[8], auto bic) {
-        constexpr int b = decltype(bic)::value;
-        constexpr int KM = K1 > K2 ? K1 : K2;
-        sfor<KM>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i < K1 && b * K1 + i < KC) {
-            constexpr int c = b * K1 + i;
-            Hcur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[c], Hcur, 0, 0, 0);
-          }
-          if constexpr (i < K2 && b * K2 + i < NF) {
-            constexpr int fi = b * K2 + i;
-            constexpr int t = fi >> 1, f = fi & 1;
-            Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[K1 + i], f == 0 ? Hb0 : Hb1, Y[t], 0, 0, 0);
-          }
-        });
-      };
-      unsigned hbn[8];   // mid tile u - 1 (bf16 pairs): what the next iteration multiplies
-      unsigned ho[8];    // ... and in store order (halves paired)
-      if constexpr (DO_MID && (DBG & 16) != 0) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) { hbn[p] = hbc[p] + 1u; ho[p] = hbc[p]; }
-        ch_keep(Hprev);
-      } else if constexpr (DO_MID) {
-        f32x16_t H = Hprev;   // (bias1 was the accumulator's initial value)
+          for (int p = (PER_WAVE * b) / NBAT; p < (PER_WAVE * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
+          if constexpr (b == 0) {
+            if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+              ch_wait4f<(NBAT > 1 ? 10 : 5)>(b4[0], b4[1], b4[2], b4[3]);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Ha[r] = b4[r >> 2][r & 3];   // bias1 is the accumulator's initial value
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Ha[r] = 0.f;
+            }
+          }
+          if constexpr (b + 1 < NBAT) {
+            if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<5>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          } else {
+            if constexpr ((b & 1) == 0) { ch_wait<0>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          }
+        });
+        // ---- mid op on the accumulator: lane (m, hi) holds j = 32 u + 8 q + 4 hi + i in register 4 q + i
+        f32x16_t H = Ha;
         if constexpr (MODE == DMT_CHAIN_FFN_LN) {
           bits = 0;
 #pragma unroll
@@ -325,167 +324,197 @@ __global__ __launch_bounds__(CH_NT, 1) void chain2_kernel(const ChainArgs g) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) H[r] = ((bits >> r) & 1u) ? H[r] : 0.f;
         }
+        unsigned hb[8], ho[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) hbn[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) ho[p] = hbn[p];
-        // row m, columns 16 p + 8 hi .. +8 of the tile after pairing q = 2p (kept by the lower lane) with q = 2p + 1 (upper lane)
-        swap_lo(ho[0], ho[2]); swap_lo(ho[1], ho[3]);
-        swap_lo(ho[4], ho[6]); swap_lo(ho[5], ho[7]);
-      }
-
-      if constexpr (DO_G1 && MODE == DMT_CHAIN_FFN_LN) {
-        sfor<4>([&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          ch_read128f<q * 32>(b4[q], bias_lane + so);
-        });
-      }
-      rd(R0, std::integral_constant<int, 0>{});
-      sfor<NBAT>([&](auto bic) {
-        constexpr int b = decltype(bic)::value;
-        if constexpr (b + 1 < NBAT) {
-          if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
-          else rd(R0, std::integral_constant<int, b + 1>{});
-        }
-        // this batch's share of the DMA pieces of stage gs + 2.  (Issued unconditionally -- a branch here would cut the iteration into
-        // basic blocks and keep the scheduler from overlapping the mid op with the MFMAs; past the last stage the pieces
-        // re-fetch a valid stage into the ring buffer nobody reads any more.)
-#pragma unroll
-        for (int p = (PER_WAVE * b) / NBAT; p < (PER_WAVE * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
-        if constexpr (b == 0 && DO_G1) {
+        for (int p = 0; p < 8; ++p) hb[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
+        // hand the tile to the consumer: two B fragments, slot u & 1
+        ch_write128(hand_lane + (u & 1) * 2048, u32x4_t{hb[0], hb[1], hb[2], hb[3]});
+        ch_write128(hand_lane + (u & 1) * 2048 + 1024, u32x4_t{hb[4], hb[5], hb[6], hb[7]});
+        if constexpr ((DBG & 2) == 0) {
           if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-            ch_wait4f<((NBAT > 1 ? 2 * KB : KB) > 15 ? 15 : (NBAT > 1 ? 2 * KB : KB))>(b4[0], b4[1], b4[2], b4[3]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Hcur[r] = b4[r >> 2][r & 3];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Hcur[r] = 0.f;
+            if (g.mask != nullptr) g.mask[(blk * NJT + u) * 64 + lane] = (unsigned short)bits;
           }
-        }
-        constexpr int LEFT = (b + 1 < NBAT) ? KB : 0;   // reads of the next batch may stay outstanding
-        if constexpr ((b & 1) == 0) { ch_wait8<LEFT>(R0); mm(R0, bic); }
-        else { ch_wait8<LEFT>(R1); mm(R1, bic); }
-      });
-      if constexpr (DO_MID && (DBG & 2) == 0) {
-        if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-          if (g.mask != nullptr) g.mask[(blk * NJT + u - 1) * 64 + lane] = (unsigned short)bits;
-        }
-        if (g.mid_out != nullptr && mvalid) {
-          bf16_t* dst = g.mid_out + m * g.ld_mid + (u - 1) * 32 + 8 * hi;
-          // (plain stores: a row receives 64 bytes per iteration, the L2 merges the pieces of a line; non-temporal partial-line
-          //  stores were 4x slower)
-          if constexpr ((DBG & 4) == 0) {
-            *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{ho[0], ho[1], ho[2], ho[3]};
-            *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{ho[4], ho[5], ho[6], ho[7]};
-          } else {
-            __builtin_nontemporal_store(u32x4_t{ho[0], ho[1], ho[2], ho[3]}, reinterpret_cast<u32x4_t*>(dst));
-            __builtin_nontemporal_store(u32x4_t{ho[4], ho[5], ho[6], ho[7]}, reinterpret_cast<u32x4_t*>(dst + 16));
+          if (g.mid_out != nullptr) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) ho[p] = hb[p];
+            // row m, columns 16 p + 8 hi .. +8 of the tile after pairing q = 2p (kept by the lower lane) with q = 2p + 1 (upper lane)
+            swap_lo(ho[0], ho[2]); swap_lo(ho[1], ho[3]);
+            swap_lo(ho[4], ho[6]); swap_lo(ho[5], ho[7]);
+            if (mvalid) {
+              bf16_t* dst = g.mid_out + m * g.ld_mid + u * 32 + 8 * hi;
+              // (plain stores: a row receives 64 bytes per mid tile, the L2 merges the pieces of a line; non-temporal partial-line
+              //  stores were 4x slower)
+              *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{ho[0], ho[1], ho[2], ho[3]};
+              *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{ho[4], ho[5], ho[6], ho[7]};
+            }
           }
         }
       }
-      if constexpr (DO_MID) {
+      // (iteration NJT: the consumer multiplies the last mid tile; the producer only keeps the ring going)
+      top(NJT);
+      {
+        const int dbuf = (gs + 2) % CH_NS, du = (NJT + 2) % NST;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) hbc[p] = hbn[p];
+        for (int p = 0; p < PER_WAVE; ++p) issue1(dbuf, du, p);
       }
       ++gs;
-    };
-
-    static_assert(NJT % 2 == 0 && NJT >= 4, "mid tiles are processed in pairs");
-    constexpr std::true_type T_{};
-    constexpr std::false_type F_{};
-    if constexpr ((DBG & 64) == 0) {
-      iteration(T_, F_, F_, 0, HA, HB);
-      iteration(T_, T_, F_, 1, HB, HA);
-#pragma unroll 1
-      for (int u = 2; u < NJT; u += 2) {
-        iteration(T_, T_, T_, u, HA, HB);
-        iteration(T_, T_, T_, u + 1, HB, HA);
-      }
-      iteration(F_, T_, T_, NJT, HA, HB);
-      iteration(F_, F_, T_, NJT + 1, HB, HA);
-    }
-
-    // ---- epilogue: accumulator register (t, 4 q + i) of lane (m, hi) is output column n = 32 t + 8 q + 4 hi + i of row m
-    //      bias2 / residual (the permuted input fragments hold x[m, n] at fragment 2 t + (q >> 1), element 4 (q & 1) + i)
-    float sum = 0.f;
+    } else {
+      // ---- consumer: out^T accumulators start as bias2 + residual (register (t, 4 q + i) of lane (m, hi) is column 32 t + 8 q + 4 hi + i)
+      f32x16_t Y[NOT];
+      {
+        const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
 #pragma unroll
-    for (int t = 0; t < NOT; ++t)
+        for (int t = 0; t < NOT; ++t) {
+          unsigned xv[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n0 = 32 * t + 8 * q + 4 * hi;
-        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == DMT_CHAIN_FFN_LN && n0 < G::NOUT) b = *reinterpret_cast<const f32x4_t*>(g.bias2 + n0);
+          for (int p = 0; p < 2; ++p) {
+            const int col = 32 * t + 16 * p + 8 * hi;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (col < G::KIN && mvalid) v = *reinterpret_cast<const u32x4_t*>(xr + 32 * t + 16 * p);
+            xv[4 * p + 0] = v[0]; xv[4 * p + 1] = v[1]; xv[4 * p + 2] = v[2]; xv[4 * p + 3] = v[3];
+          }
+          // undo the store pairing: the lower lane holds columns 16 p + 0..7, the upper 16 p + 8..15; register group q wants 8 q + 4 hi + 0..3
+          swap_lo(xv[0], xv[2]); swap_lo(xv[1], xv[3]);
+          swap_lo(xv[4], xv[6]); swap_lo(xv[5], xv[7]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float x = 0.f;
-          const int c = 2 * t + (q >> 1);
-          if (c < KC) x = bf2f((bf16_t)X[c < KC ? c : 0][4 * (q & 1) + i]);
-          float v = Y[t][4 * q + i] + b[i] + x;
-          if constexpr (G::NOUT % 32 != 0) { if (n0 + i >= G::NOUT) v = 0.f; }   // padded output columns
-          Y[t][4 * q + i] = v;
-          sum += v;
+          for (int q = 0; q < 4; ++q) {
+            const int n0 = 32 * t + 8 * q + 4 * hi;
+            f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == DMT_CHAIN_FFN_LN && n0 < G::NOUT) b = *reinterpret_cast<const f32x4_t*>(g.bias2 + n0);
+            Y[t][4 * q + 0] = b[0] + __uint_as_float(xv[2 * q] << 16);
+            Y[t][4 * q + 1] = b[1] + __uint_as_float(xv[2 * q] & 0xFFFF0000u);
+            Y[t][4 * q + 2] = b[2] + __uint_as_float(xv[2 * q + 1] << 16);
+            Y[t][4 * q + 3] = b[3] + __uint_as_float(xv[2 * q + 1] & 0xFFFF0000u);
+          }
         }
       }
-    float mean = 0.f, rstd = 1.f;
-    if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-      sum += __shfl_xor(sum, 32, 64);
-      mean = sum / (float)G::NOUT;
-      float sq = 0.f;
+      // (iteration 0: nothing produced yet; the consumer only keeps the ring going)
+      top(0);
+      {
+        const int dbuf = (gs + 2) % CH_NS, du = 2 % NST;
 #pragma unroll
-      for (int t = 0; t < NOT; ++t)
+        for (int p = 0; p < PER_WAVE; ++p) issue1(dbuf, du, p);
+      }
+      ++gs;
+#pragma unroll 1
+      for (int u = 1; u <= NJT; ++u, ++gs) {
+        const int buf = gs % CH_NS;
+        top(u);
+        const int dbuf = (gs + 2) % CH_NS, du = (u + 2) % NST;
+        const unsigned so = (unsigned)buf * STAGE;
+        const unsigned a2a = a2_lane + so;
+        constexpr int PB = (NF % 5 == 0) ? 5 : ((NF % 4 == 0) ? 4 : 3), NBAT = NF / PB;
+        static_assert(NF % PB == 0, "2 * output tiles must be a multiple of 3, 4 or 5");
+        bf16x8_t R0[5], R1[5];
+        bf16x8_t Hb0, Hb1;
+        ch_read128<0>(Hb0, hand_lane + ((u - 1) & 1) * 2048);
+        ch_read128<1024>(Hb1, hand_lane + ((u - 1) & 1) * 2048);
+        auto rd = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fi = b * PB + (i < PB ? i : 0);
+            constexpr int t = fi >> 1, f = fi & 1;
+            ch_read128<t * 32 * G::A2_STRIDE + f * 32>(R[i], a2a);
+          });
+        };
+        auto mm = [&](bf16x8_t (&R)[5], auto bic) {
+          constexpr int b = decltype(bic)::value;
+          sfor<PB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fi = b * PB + i;
+            constexpr int t = fi >> 1, f = fi & 1;
+            Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], f == 0 ? Hb0 : Hb1, Y[t], 0, 0, 0);
+          });
+        };
+        rd(R0, std::integral_constant<int, 0>{});
+        sfor<NBAT>([&](auto bic) {
+          constexpr int b = decltype(bic)::value;
+          if constexpr (b + 1 < NBAT) {
+            if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
+            else rd(R0, std::integral_constant<int, b + 1>{});
+          }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+          for (int p = (PER_WAVE * b) / NBAT; p < (PER_WAVE * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
+          if constexpr (b == 0) ch_wait2<(NBAT > 1 ? 10 : 5)>(Hb0, Hb1);
+          if constexpr (b + 1 < NBAT) {
+            if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<5>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          } else {
+            if constexpr ((b & 1) == 0) { ch_wait<0>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+            else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+          }
+        });
+      }
+
+      // ---- epilogue (consumer): LayerNorm over the row (spread over the lanes m and m + 32), stores
+      float mean = 0.f, rstd = 1.f;
+      if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+        float sum = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int n = 32 * t + 8 * q + 4 * hi + i;
-            const float d = (n < G::NOUT) ? (Y[t][4 * q + i] - mean) : 0.f;
+        for (int t = 0; t < NOT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if constexpr (G::NOUT % 32 != 0) { if (n >= G::NOUT) Y[t][r] = 0.f; }
+            sum += Y[t][r];
+          }
+        sum += __shfl_xor(sum, 32, 64);
+        mean = sum / (float)G::NOUT;
+        float sq = 0.f;
+#pragma unroll
+        for (int t = 0; t < NOT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + 8 * (r >> 2) + 4 * hi + (r & 3);
+            const float d = (n < G::NOUT) ? (Y[t][r] - mean) : 0.f;
             sq += d * d;
           }
-      sq += __shfl_xor(sq, 32, 64);
-      const float den = sqrtf(sq / (float)G::NOUT + g.eps);
-      rstd = 1.f / den;
-      if (g.stats != nullptr && mvalid && hi == 0) { g.stats[2 * m] = mean; g.stats[2 * m + 1] = rstd; }
-    }
-    // stores: 16 bytes per lane after pairing q = 2p (lower lane) with q = 2p + 1 (upper lane): row m, columns 32 t + 16 p + 8 hi .. +8
+        sq += __shfl_xor(sq, 32, 64);
+        const float den = sqrtf(sq / (float)G::NOUT + g.eps);
+        rstd = 1.f / den;
+        if (g.stats != nullptr && mvalid && hi == 0) { g.stats[2 * m] = mean; g.stats[2 * m + 1] = rstd; }
+      }
+      // stores: 16 bytes per lane after pairing q = 2p (lower lane) with q = 2p + 1 (upper lane): row m, columns 32 t + 16 p + 8 hi .. +8
 #pragma unroll
-    for (int t = 0; t < NOT; ++t) {
-      unsigned su[8], yu[8];
+      for (int t = 0; t < NOT; ++t) {
+        unsigned su[8], yu[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n0 = 32 * t + 8 * q + 4 * hi;
-        su[2 * q] = dmt_pack_bf16(Y[t][4 * q + 0], Y[t][4 * q + 1]);
-        su[2 * q + 1] = dmt_pack_bf16(Y[t][4 * q + 2], Y[t][4 * q + 3]);
-        if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-          f32x4_t gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
-          if (n0 < G::NOUT) { gm = *reinterpret_cast<const f32x4_t*>(g.gamma + n0); bt = *reinterpret_cast<const f32x4_t*>(g.beta + n0); }
-          float o[4];
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = 32 * t + 8 * q + 4 * hi;
+          su[2 * q] = dmt_pack_bf16(Y[t][4 * q + 0], Y[t][4 * q + 1]);
+          su[2 * q + 1] = dmt_pack_bf16(Y[t][4 * q + 2], Y[t][4 * q + 3]);
+          if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+            f32x4_t gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+            if (n0 < G::NOUT) { gm = *reinterpret_cast<const f32x4_t*>(g.gamma + n0); bt = *reinterpret_cast<const f32x4_t*>(g.beta + n0); }
+            float o[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = gm[i] * ((Y[t][4 * q + i] - mean) * rstd) + bt[i];
-          yu[2 * q] = dmt_pack_bf16(o[0], o[1]);
-          yu[2 * q + 1] = dmt_pack_bf16(o[2], o[3]);
+            for (int i = 0; i < 4; ++i) o[i] = gm[i] * ((Y[t][4 * q + i] - mean) * rstd) + bt[i];
+            yu[2 * q] = dmt_pack_bf16(o[0], o[1]);
+            yu[2 * q + 1] = dmt_pack_bf16(o[2], o[3]);
+          }
         }
-      }
-      swap_lo(su[0], su[2]); swap_lo(su[1], su[3]);
-      swap_lo(su[4], su[6]); swap_lo(su[5], su[7]);
-      if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-        swap_lo(yu[0], yu[2]); swap_lo(yu[1], yu[3]);
-        swap_lo(yu[4], yu[6]); swap_lo(yu[5], yu[7]);
-      }
+        swap_lo(su[0], su[2]); swap_lo(su[1], su[3]);
+        swap_lo(su[4], su[6]); swap_lo(su[5], su[7]);
+        if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+          swap_lo(yu[0], yu[2]); swap_lo(yu[1], yu[3]);
+          swap_lo(yu[4], yu[6]); swap_lo(yu[5], yu[7]);
+        }
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int col = 32 * t + 16 * p + 8 * hi;
-        if (mvalid && col < G::NOUT) {
-          if (g.s_out != nullptr)
-            *reinterpret_cast<u32x4_t*>(g.s_out + m * g.ld_out + col) = u32x4_t{su[4 * p], su[4 * p + 1], su[4 * p + 2], su[4 * p + 3]};
-          if constexpr (MODE == DMT_CHAIN_FFN_LN)
-            *reinterpret_cast<u32x4_t*>(g.y_out + m * g.ld_out + col) = u32x4_t{yu[4 * p], yu[4 * p + 1], yu[4 * p + 2], yu[4 * p + 3]};
+        for (int p = 0; p < 2; ++p) {
+          const int col = 32 * t + 16 * p + 8 * hi;
+          if (mvalid && col < G::NOUT) {
+            if (g.s_out != nullptr)
+              *reinterpret_cast<u32x4_t*>(g.s_out + m * g.ld_out + col) = u32x4_t{su[4 * p], su[4 * p + 1], su[4 * p + 2], su[4 * p + 3]};
+            if constexpr (MODE == DMT_CHAIN_FFN_LN)
+              *reinterpret_cast<u32x4_t*>(g.y_out + m * g.ld_out + col) = u32x4_t{yu[4 * p], yu[4 * p + 1], yu[4 * p + 2], yu[4 * p + 3]};
+          }
         }
       }
     }
   }
   // the ring runs two stages ahead of the last multiply: let those pieces land before the workgroup (and its LDS) goes away
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  (void)total_stages;
 }
 
 template <typename G>
@@ -506,10 +535,7 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
     const int v = dbg ? atoi(dbg) : 0;
     if (v != 0 && d->mode == DMT_CHAIN_FFN_LN) {
       if (v == 1) hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 1>), dim3(grid), dim3(CH_NT), 0, st, a);
-      else if (v == 9) hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 9>), dim3(grid), dim3(CH_NT), 0, st, a);
-      else if (v == 17) hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 17>), dim3(grid), dim3(CH_NT), 0, st, a);
-      else if (v == 65) hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 65>), dim3(grid), dim3(CH_NT), 0, st, a);
-      else hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 57>), dim3(grid), dim3(CH_NT), 0, st, a);
+      else hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 3>), dim3(grid), dim3(CH_NT), 0, st, a);
       DMT_CHECK_LAUNCH("dmt_chain2(debug)");
       return DMT_OK;
     }
