@@ -78,6 +78,12 @@ class ChainDesc(C.Structure):
 DMT_CHAIN_FFN_LN, DMT_CHAIN_FFN_BWD = 0, 1
 
 
+class MhsaDesc(C.Structure):
+    _fields_ = [("d_model", c_i32), ("num_heads", c_i32), ("B", c_i32), ("T", c_i32), ("x", c_vp), ("lens", c_vp), ("image", c_vp),
+                ("bias", c_vp), ("gamma", c_vp), ("beta", c_vp), ("eps", c_f32), ("qkv", c_vp), ("s_out", c_vp), ("y_out", c_vp),
+                ("stats", c_vp), ("drop_seed", C.c_uint32), ("drop_keep", c_f32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("A", c_vp), ("ld_a", c_i64), ("a_cols", c_i32), ("B", c_vp), ("ld_b", c_i64), ("M", c_i64), ("N", c_i32), ("C", c_vp),
                 ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32)]
@@ -130,6 +136,9 @@ _SIGS = {
     "dmt_chain_image_build": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "dmt_chain2": [C.POINTER(ChainDesc), c_vp],
     "dmt_wgrad320": [C.POINTER(WgradDesc), c_vp],
+    "dmt_mhsa_image_bytes": [C.POINTER(c_i64)],
+    "dmt_mhsa_image_build": [c_vp, c_i64, c_vp, c_vp],
+    "dmt_mhsa_block_fwd": [C.POINTER(MhsaDesc), c_vp],
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported"])

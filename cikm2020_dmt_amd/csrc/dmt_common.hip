@@ -27,6 +27,7 @@ extern "C" int dmt_struct_size(int which) {
     case 7: return (int)sizeof(dmt_cast_job);
     case 8: return (int)sizeof(dmt_chain_desc);
     case 9: return (int)sizeof(dmt_wgrad_desc);
+    case 10: return (int)sizeof(dmt_mhsa_desc);
     default: return -1;
   }
 }

@@ -271,6 +271,7 @@ class DMTEngine:
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
         self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
+        self.use_mhsa = True             # fused self-attention block (dmt_mhsa_block_fwd) where the geometry has one
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
 
     def gather_bytes(self, batch, seq_T) -> float:
@@ -382,6 +383,11 @@ class DMTEngine:
         """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "self-attention/"
+        img = self.store.mhsa.get(a) if x.dtype == torch.bfloat16 else None
+        if img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1]):
+            seed, keep = self._attn_drop(stream)
+            return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
+                                         self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8)
         s1 = ops.SelfAttnBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"), lens, H,
                                        *self._attn_drop(stream))
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))

@@ -752,6 +752,95 @@ class SelfAttnBlockFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ fused self-attention block
+def mhsa_supported(d_model, num_heads, T):
+    return d_model == 320 and num_heads == 4 and 1 <= T <= 64
+
+
+def mhsa_image_bytes():
+    n = C.c_int64(0)
+    L.call("dmt_mhsa_image_bytes", C.byref(n))
+    return int(n.value)
+
+
+def mhsa_image_build(wqkv_f32, image):
+    L.call("dmt_mhsa_image_build", p(wqkv_f32), wqkv_f32.stride(0), p(image), stream_ptr())
+
+
+def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_keep, want_side=True):
+    """y, s, stats, qkv = fused multihead_attention(x, x, x) + ln (dmt_mhsa_block_fwd); side outputs None when not wanted."""
+    B, T, d = x.shape
+    dev = x.device
+    y = torch.empty((B, T, d), dtype=BF16, device=dev)
+    s = torch.empty((B, T, d), dtype=BF16, device=dev)
+    stats = torch.empty((B * T, 2), dtype=F32, device=dev) if want_side else None
+    qkv = torch.empty((B, T, 3 * d), dtype=BF16, device=dev) if want_side else None
+    dd = L.MhsaDesc()
+    dd.d_model, dd.num_heads, dd.B, dd.T = d, H, B, T
+    dd.x, dd.lens, dd.image = x.data_ptr(), lens.data_ptr(), image.data_ptr()
+    dd.bias, dd.gamma, dd.beta, dd.eps = bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
+    dd.qkv = qkv.data_ptr() if qkv is not None else None
+    dd.s_out, dd.y_out = s.data_ptr(), y.data_ptr()
+    dd.stats = stats.data_ptr() if stats is not None else None
+    dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
+    flops = 2.0 * B * T * d * 3 * d + 4.0 * B * T * T * d
+    with _Timed("gemm_bf16", flops):
+        L.call("dmt_mhsa_block_fwd", C.byref(dd), stream_ptr())
+    if PROFILE is not None:
+        PROFILE.setdefault("gemm_bytes", []).append(float(B * T * d * 2 * (3 + (3 if want_side else 0)) + image.numel()))
+    return y, s, stats, qkv
+
+
+class MhsaBlockFn(torch.autograd.Function):
+    """y = ln(x + MHA(x, x, x)): the encoder's self-attention block (TransformerModel_util.py:160-209 + ln :58-78) as ONE forward
+    launch.  Backward: LayerNorm gradient, attention gradient from the saved (Q | K | V), dx = dqkv Wqkv^T + ds, weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, gamma, beta, lens, H, image, drop_seed, drop_keep, eps):
+        _chk3(x, "x")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        train = any(ctx.needs_input_grad[:6])
+        y, s, stats, qkv = mhsa_block_fwd(x, lens, image, b_leaf, gamma, beta, eps, H, drop_seed, drop_keep, want_side=train)
+        if train:
+            ctx.save_for_backward(x, qkv, s, stats, lens)
+        ctx.w, ctx.leaves, ctx.gb, ctx.H, ctx.drop = w, (w_leaf, b_leaf), (gamma, beta), H, (int(drop_seed), float(drop_keep))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, s, stats, lens = ctx.saved_tensors
+        B, T, d = x.shape
+        M = B * T
+        gamma, beta = ctx.gb
+        dy2 = dy.reshape(M, d)
+        if dy2.stride(-1) != 1:
+            dy2 = dy2.contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        s2 = s.view(M, d)
+        # ---- LayerNorm gradient (dgamma / dbeta straight into the gradient arena)
+        ds = torch.empty((M, d), dtype=BF16, device=x.device)
+        gg, gbv = _grad_view(gamma), _grad_view(beta)
+        direct = gg is not None and gbv is not None and gg.dim() == 1 and gbv.dim() == 1
+        dg = gg if direct else torch.zeros((d,), dtype=F32, device=x.device)
+        db = gbv if direct else torch.zeros((d,), dtype=F32, device=x.device)
+        npart = L.load().dmt_ln_bwd_partials(M)
+        partials = torch.empty((npart, 2 * d), dtype=F32, device=x.device)
+        L.call("dmt_ln_bwd", L.DMT_BF16, M, d, p(s2), d, p(gamma), p(stats), p(dy2), _row_major2d(dy2, "dy"), p(ds), d, p(dg), p(db), p(partials),
+               stream_ptr())
+        # ---- attention gradient
+        ds3 = ds.view(B, T, d)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
+        attn_core_bwd(q, k, v, lens, lens, None, ds3, dq, dk, dv, ctx.H, *ctx.drop)
+        dz = dqkv.view(M, 3 * d)
+        dx = linear_backward_input(dz, ctx.w, resid=ds).view(B, T, d) if ctx.needs_input_grad[0] else None
+        dW, dbq = linear_backward_weight(x.view(M, d), dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
+        return dx, dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm
 class LNFn(torch.autograd.Function):
     @staticmethod

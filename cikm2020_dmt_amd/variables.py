@@ -222,6 +222,14 @@ class VariableStore:
                         self.chain[scope] = dict(geo=(d, dff, d), fwd=torch.empty(nbytes, dtype=torch.uint8, device=dev),
                                                  bwd=torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
+        # weight images of the fused self-attention block (dmt_mhsa_block_fwd), one per encoder self-attention scope
+        self.mhsa: Dict[str, torch.Tensor] = {}
+        if bf and ops.mhsa_supported(self.spec["d_model"], self.spec["num_heads"], 1):
+            nbytes = ops.mhsa_image_bytes()
+            for name in self.leaves:
+                if name.endswith("self-attention/qkv_kernel"):
+                    self.mhsa[name[: -len("qkv_kernel")]] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
     # ------------------------------------------------------------------ values
     def initialize(self, seed: int = 0):
         rng = np.random.default_rng(seed)
@@ -269,6 +277,8 @@ class VariableStore:
             self._cast_jobs = ops.cast_shadow_jobs([(self.weight[n].f32, self.weight[n].lp, self.weight[n].lp_t) for n in self._w2d],
                                                    self.device)
         ops.cast_shadow_batched(self._cast_jobs)
+        for scope, img in self.mhsa.items():
+            ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
         for scope, ch in self.chain.items():
             w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
             # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]

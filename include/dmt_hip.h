@@ -41,7 +41,7 @@ int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
 const char* dmt_build_arch(void);
 /* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
- * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc (lets a binding verify its struct layout). */
+ * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc, 10 mhsa_desc (lets a binding verify its struct layout). */
 int dmt_struct_size(int which);
 
 /* ------------------------------------------------------------------------------------------------
@@ -415,6 +415,38 @@ typedef struct {
   int32_t bias_of;
 } dmt_wgrad_desc;
 int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-attention block of the sequence encoder in ONE launch (bf16; built for d_model 320 = 4 heads x 80, T <= 64):
+ *     y = ln(x + concat_h softmax(mask(Q_h K_h^T / sqrt(d_h))) V_h),   (Q | K | V) = x Wqkv + bias
+ * QKV projection, key mask, softmax, query mask, attention dropout, P V, head concat, residual and LayerNorm without any
+ * intermediate travelling back from memory.
+ * Replaces: multihead_attention(queries, keys, values, ...) with queries == keys == values (the encoder's self-attention,
+ *           model/net/TransformerModel.py:103-115 -> TransformerModel_util.py:160-209, 11-56, 80-108, 58-78).
+ * image: dmt_mhsa_image_build(Wqkv fp32 [320, 960] packed dense | dense_1 | dense_2 kernels).
+ * Side outputs for the backward pass: qkv [B*T, 960] (or NULL: inference), s_out = pre-LN sum, stats [B*T, 2] = (mean, rstd).
+ * drop_keep in (0, 1): attention-weight dropout with the library's counter mask, element index ((b*H + h)*T + q)*T + k.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t d_model, num_heads;
+  int32_t B, T;
+  const void* x;          /* bf16 [B, T, d_model] contiguous            */
+  const int32_t* lens;    /* [B] valid length (key AND query mask)      */
+  const void* image;
+  const float* bias;      /* fp32 [3 * d_model]                          */
+  const float* gamma;     /* fp32 [d_model]                              */
+  const float* beta;
+  float eps;
+  void* qkv;              /* bf16 [B*T, 3 * d_model] or NULL             */
+  void* s_out;            /* bf16 [B*T, d_model]                         */
+  void* y_out;            /* bf16 [B*T, d_model]                         */
+  float* stats;           /* fp32 [B*T, 2] or NULL                       */
+  uint32_t drop_seed;
+  float drop_keep;
+} dmt_mhsa_desc;
+int dmt_mhsa_image_bytes(int64_t* bytes);
+int dmt_mhsa_image_build(const float* wqkv, int64_t ldw, void* image, void* stream);
+int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream);
 
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */

@@ -1,0 +1,105 @@
+"""dmt_mhsa_block_fwd (QKV projection + masked softmax attention + residual + LayerNorm in one launch) against
+ (a) a plain PyTorch fp32 statement of multihead_attention + ln (TransformerModel_util.py:160-209, 11-56, 80-108, 58-78), incl. the
+     key mask before / query mask after the softmax (-2^32 + 1) and the counter dropout of oracle/dmt_oracle.py, and
+ (b) the unfused HIP path (GEMM + attention + LN kernels) through autograd, forward and every gradient.
+Tolerance: bf16 outputs, |d| <= 2^-6 of the row scale for live rows (the scores pass through bf16 Q, K, P).
+"""
+import numpy as np
+import pytest
+import torch
+
+from cikm2020_dmt_amd import ops
+from oracle import dmt_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+PAD = -4294967295.0
+
+
+def _mk(cuda, B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = 320
+    x = (torch.randn(B, T, d, generator=g)).to(BF)
+    w = torch.randn(d, 3 * d, generator=g) * (1.0 / d) ** 0.5
+    b = torch.randn(3 * d, generator=g) * 0.1
+    gamma = 1.0 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = T
+    if B > 1:
+        lens[1] = 1
+    return [t.to(cuda) for t in (x, w, b, gamma, beta, lens)]
+
+
+def _ref(x, w, b, gamma, beta, lens, H, seed, keep):
+    B, T, d = x.shape
+    dh = d // H
+    xf = x.float()
+    qkv = (xf @ w.to(BF).float() + b).to(BF).float()          # the kernel rounds Q, K, V to bf16 (MFMA operands)
+    q, k, v = (qkv[..., i * d:(i + 1) * d].view(B, T, H, dh).permute(0, 2, 1, 3) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / dh ** 0.5
+    ar = torch.arange(T, device=x.device)
+    km = (ar[None, :] < lens[:, None])[:, None, None, :]
+    qm = (ar[None, :] < lens[:, None])[:, None, :, None]
+    sc = torch.where(km, sc, torch.full_like(sc, PAD))
+    p = torch.softmax(sc, dim=-1)
+    p = torch.where(qm, p, torch.full_like(p, PAD))
+    if 0.0 < keep < 1.0:
+        m = O.dropout_mask(int(seed), B * H * T * T, keep).reshape(B, H, T, T)
+        p = torch.where(torch.as_tensor(m, device=x.device), p / keep, torch.zeros_like(p))
+    o = (p.to(BF).float() @ v).permute(0, 2, 1, 3).reshape(B, T, d)
+    s = o + xf
+    mean = s.mean(-1, keepdim=True)
+    var = ((s - mean) ** 2).mean(-1, keepdim=True)
+    return gamma * (s - mean) / torch.sqrt(var + 1e-8) + beta, s, qkv
+
+
+@pytest.mark.parametrize("B,T", [(5, 50), (3, 64), (9, 33), (7, 32), (6, 17), (11, 10), (13, 1), (300, 50)])
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_mhsa_block_forward(cuda, B, T, keep):
+    x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=B * 100 + T)
+    img = torch.empty(ops.mhsa_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_image_build(w, img)
+    seed = 0x1234567
+    y, s, stats, qkv = ops.mhsa_block_fwd(x, lens, img, b, gamma, beta, 1e-8, 4, seed, keep)
+    torch.cuda.synchronize()
+    y_ref, s_ref, qkv_ref = _ref(x, w, b, gamma, beta, lens, 4, seed, keep)
+    assert ((qkv.float() - qkv_ref).abs() / qkv_ref.abs().amax(-1, keepdim=True)).max() < 2.0 ** -7
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])           # padded query rows hold -2^32-scale values: compare relatively
+    tol = 2.0 ** -6
+    es = ((s.float() - s_ref).abs() / s_ref.abs().amax(-1, keepdim=True).clamp_min(1e-3))
+    assert es[live].max() < tol
+    assert es[~live].max() < 3 * tol if (~live).any() else True
+    ey = ((y.float() - y_ref).abs() / y_ref.abs().amax(-1, keepdim=True).clamp_min(1e-3))
+    assert ey[live].max() < 2 * tol
+    # statistics of the stored (rounded) s
+    sm = s.float().mean(-1).reshape(-1)
+    assert ((stats[:, 0] - sm).abs() / s.float().abs().amax(-1).reshape(-1).clamp_min(1e-3)).max() < 1e-3
+
+
+def test_mhsa_block_autograd_matches_unfused_path(cuda):
+    B, T, d, H = 37, 50, 320, 4
+    x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=77)
+    img = torch.empty(ops.mhsa_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_image_build(w, img)
+    wt = ops.Weight(w, w.to(BF), w.to(BF).t().contiguous())
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(B, T, d, generator=g).to(BF).to(cuda)
+    dy = dy * (torch.arange(T, device=cuda)[None, :, None] < lens[:, None, None])   # (padded rows carry no gradient downstream)
+    outs = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+        xa = x.clone().requires_grad_(True)
+        if fused:
+            y = ops.MhsaBlockFn.apply(xa, leaves[0], leaves[1], wt, leaves[2], leaves[3], lens, H, img, 99, 0.9, 1e-8)
+        else:
+            s1 = ops.SelfAttnBlockFn.apply(xa, leaves[0], leaves[1], wt, lens, H, 99, 0.9)
+            y = ops.layer_norm(s1, leaves[2], leaves[3])
+        y.backward(dy)
+        outs.append((y.detach().float(), xa.grad.float(), [l.grad.float() for l in leaves]))
+    (ya, dxa, ga), (yb, dxb, gb) = outs
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])
+    assert (ya - yb)[live].abs().max() < 0.06
+    assert (dxa - dxb).abs().max() / dxb.abs().max() < 3e-2
+    for a, bb in zip(ga, gb):
+        assert (a - bb).abs().max() / bb.abs().max() < 3e-2
