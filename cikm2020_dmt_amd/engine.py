@@ -6,6 +6,7 @@ compute step is a libdmt_hip.so kernel reached through cikm2020_dmt_amd/ops.py.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional
 
@@ -271,7 +272,9 @@ class DMTEngine:
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
         self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
-        self.use_mhsa = True             # fused self-attention block (dmt_mhsa_block_fwd) where the geometry has one
+        # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
+        # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
+        self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
 
     def gather_bytes(self, batch, seq_T) -> float:
