@@ -124,6 +124,7 @@ _SIGS = {
     "dmt_adam_sparse_rows_bf16": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_catchup_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
+    "dmt_adam_rebase": [c_vp, c_vp, c_i64, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_cast_transpose_bf16_batched": [c_i32, c_vp, c_i32, c_vp],
@@ -132,6 +133,8 @@ _SIGS = {
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "dmt_confusion_counts": [c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "dmt_l2_unique_rows": [c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
     "dmt_chain_image_bytes": [c_i32, c_i32, c_i32, C.POINTER(c_i64)],
     "dmt_chain_image_build": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "dmt_chain2": [C.POINTER(ChainDesc), c_vp],

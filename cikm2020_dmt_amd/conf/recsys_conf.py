@@ -141,6 +141,9 @@ class Conf:
             raise NotImplementedError("only the shipped dmt.conf Transformer options are implemented (position_learn, 1+1 blocks)")
         if self[MODEL][IS_BN] or self[MODEL][IS_DROPOUT]:
             raise NotImplementedError("is_bn / is_dropout are false in dmt.conf and not implemented")
+        if str(self[PARAMETER].get(LOSS_WEIGHT_METHOD, "fixed")).strip() != "fixed":
+            raise NotImplementedError("loss_weight_method = %s: only 'fixed' (dmt.conf) is implemented; 'uncertainty' learns "
+                                      "click_weight / order_weight (inference_mlp.py:244-253)" % self[PARAMETER].get(LOSS_WEIGHT_METHOD))
         m = self[MODEL]
         return dict(
             embedding_list=[tuple(e) for e in self.embedding_list], embedding_list_bias=[tuple(e) for e in self.embedding_list_bias],

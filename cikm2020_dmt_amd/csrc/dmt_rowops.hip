@@ -640,6 +640,49 @@ __global__ __launch_bounds__(256) void auc_hist_kernel(int B, const float* __res
   atomicAdd(&hist[(long long)pos * (n_thr + 1) + lo], 1ULL);
 }
 
+
+// tf.metrics.precision / recall (run_dnn.py:221-227, 230-238): predictions and labels are cast to bool (non-zero);
+// counts = [true positives, false positives, false negatives, true negatives]
+__global__ __launch_bounds__(256) void confusion_kernel(int B, const float* __restrict__ pred, const float* __restrict__ label, float thr,
+                                                        unsigned long long* __restrict__ counts) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  int cls = -1;
+  if (b < B) {
+    const bool p = pred[b] > thr, y = label[b] != 0.f;
+    cls = p ? (y ? 0 : 1) : (y ? 2 : 3);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[c], (unsigned long long)__popcll(m));
+  }
+}
+
+// sum over the DISTINCT ids of one feature of ||E[id]||^2 / 2  (tf.nn.l2_loss(tf.gather(E, tf.unique(ids)))):
+// a row is counted by the first entry that sets its bit in `seen` (rows / 32 words, zeroed by the caller)
+__global__ __launch_bounds__(256) void l2_unique_kernel(int B, int T, const int* __restrict__ idx, const int* __restrict__ lens,
+                                                        const float* __restrict__ table, int rows, int dim, unsigned* __restrict__ seen,
+                                                        float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (e < (long long)B * T) {
+    const int b = (int)(e / T), t = (int)(e % T);
+    if (t < lens[b]) {
+      const int r = idx[e];
+      if (r >= 0 && r < rows) {
+        const unsigned bit = 1u << (r & 31);
+        const unsigned old = atomicOr(&seen[r >> 5], bit);
+        if (!(old & bit)) {
+          const float* row = table + (long long)r * dim;
+          for (int c = 0; c < dim; ++c) acc += row[c] * row[c];
+        }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(out, 0.5f * acc);
+}
+
 template <typename T, typename F>
 int ln_dispatch(int d, F&& f) {
   const int ne = (d + 63) / 64;
@@ -905,5 +948,23 @@ extern "C" int dmt_auc_hist(int32_t B, const float* pred, const float* label, in
   hipLaunchKernelGGL(auc_hist_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, pred, label, n_thr,
                      (unsigned long long*)hist);
   DMT_CHECK_LAUNCH("dmt_auc_hist");
+  return DMT_OK;
+}
+
+extern "C" int dmt_confusion_counts(int32_t B, const float* pred, const float* label, float threshold, long long* counts, void* stream) {
+  DMT_CHECK_ARG(B > 0 && pred && label && counts, "dmt_confusion_counts: bad argument");
+  hipLaunchKernelGGL(confusion_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, pred, label, threshold,
+                     (unsigned long long*)counts);
+  DMT_CHECK_LAUNCH("dmt_confusion_counts");
+  return DMT_OK;
+}
+
+extern "C" int dmt_l2_unique_rows(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows, int32_t dim,
+                                  uint32_t* seen, float* out, void* stream) {
+  DMT_CHECK_ARG(B > 0 && T > 0 && idx && lens && table && seen && out && rows > 0 && dim > 0, "dmt_l2_unique_rows: bad argument");
+  const long long n = (long long)B * T;
+  hipLaunchKernelGGL(l2_unique_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, T, idx, lens, table, rows, dim,
+                     seen, out);
+  DMT_CHECK_LAUNCH("dmt_l2_unique_rows");
   return DMT_OK;
 }

@@ -39,3 +39,36 @@ class StreamingAUC:
 
     def reset(self):
         self.hist.zero_()
+
+
+class StreamingPrecisionRecall:
+    """tf.metrics.precision / tf.metrics.recall as run_dnn.py:221-227, 230-238 use them: prediction = sigmoid score > 0.5
+    (run_dnn.py:190, 195), label cast to bool; running true-positive / false-positive / false-negative totals, 0 when a
+    denominator is 0 (tf.metrics' safe division).  The counts are accumulated on the GPU (dmt_confusion_counts)."""
+
+    def __init__(self, device, threshold: float = 0.5):
+        self.threshold = float(threshold)
+        self.counts = torch.zeros(4, dtype=torch.int64, device=device)     # tp, fp, fn, tn
+
+    def update(self, score: torch.Tensor, label: torch.Tensor):
+        score = score.reshape(-1).float().contiguous()
+        label = label.reshape(-1).float().contiguous()
+        L.call("dmt_confusion_counts", score.numel(), ops.p(score), ops.p(label), self.threshold, ops.p(self.counts), ops.stream_ptr())
+
+    def result(self):
+        tp, fp, fn, _tn = (float(v) for v in self.counts.cpu().numpy())
+        precision = tp / (tp + fp) if tp + fp > 0 else 0.0
+        recall = tp / (tp + fn) if tp + fn > 0 else 0.0
+        return precision, recall
+
+    def reset(self):
+        self.counts.zero_()
+
+
+def precision_recall_reference(scores, labels, threshold: float = 0.5):
+    """Host statement of the same rule (numpy): what tf.metrics.precision / recall return after streaming these batches."""
+    s = np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in scores])
+    y = np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in labels]) != 0
+    p = s > np.float32(threshold)
+    tp, fp, fn = float((p & y).sum()), float((p & ~y).sum()), float((~p & y).sum())
+    return (tp / (tp + fp) if tp + fp > 0 else 0.0), (tp / (tp + fn) if tp + fn > 0 else 0.0)

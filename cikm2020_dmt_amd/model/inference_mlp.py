@@ -24,12 +24,63 @@ class Inference(object):
         from .net.mmoe_transformer import mmoe_transformer
         from .net.mmoe_transformer_unbias import mmoe_transformer_unbias
         self.model = (mmoe_transformer_unbias if self.model_type == "mmoe_transformer_unbias" else mmoe_transformer)(wnd_conf)
+        # is_train=True runs the Transformer dropout 0.1 / bias-tower dropout 0.5 the reference always has in train()
+        # (TransformerModel.py:101,151; mmoe_transformer_unbias.py:274-278).  The mask is counter-based: seed = dropout_seed + number
+        # of training forward passes so far, or whatever set_step_seed() pinned for the next call.
+        self.dropout_seed = int(seed) + 1
+        self._train_calls = 0
+        self._pinned_seed = None
+        self._scorer = None
+
+    def set_step_seed(self, step_seed):
+        """Pin the dropout step seed of the NEXT inference(is_train=True) call (None: back to the running counter)."""
+        self._pinned_seed = None if step_seed is None else int(step_seed)
 
     def inference(self, inputs, is_train=True, is_predict=False):
+        eng = self.rt.engine
+        if is_train and not is_predict:
+            if self._pinned_seed is not None:
+                eng.dropout_step_seed, self._pinned_seed = self._pinned_seed, None
+            else:
+                eng.dropout_step_seed = self.dropout_seed + self._train_calls
+            self._train_calls += 1
+        else:
+            eng.dropout_step_seed = None
         return self.model.inference(inputs, is_train, is_predict)
 
     def online_inference(self, inputs, is_train=False):
-        raise NotImplementedError("serving-side input re-packing (inference_mlp.py:73-143) is outside the train hot path")
+        """inference_mlp.py:122-143 -> online_build_sparsetensor :73-113: the request carries ONE user's id lists (1-D, for every
+        embedding_list entry of side 'u', plus '<f>Wts') and per-candidate item features for BatchSize candidates; the reference tiles
+        the user lists across the batch and runs the predict graph.  Here serving.CandidateScorer does the same request but encodes
+        the user's sequences once.  Returns (click_logit, order_logit), each [BatchSize, 1]."""
+        import numpy as np
+        from ..serving import CandidateScorer
+        if is_train:
+            raise NotImplementedError("online_inference is the serving path (is_train=False in export_model.py)")
+        if self._scorer is None:
+            self._scorer = CandidateScorer(self.rt.engine)
+        spec = self.rt.spec
+        B = int(inputs["BatchSize"])
+        user, item = {}, {}
+        for (_n, _r, _d, f, side) in list(spec["embedding_list"]) + list(spec["embedding_list_bias"]):
+            if f in user or f in item:
+                continue
+            v, w = inputs[f], inputs.get(f + "Wts")
+            if side == "u" and not hasattr(v, "to_padded") and np.asarray(v).ndim == 1:
+                user[f] = (np.asarray(v), None if w is None else np.asarray(w))
+            else:
+                if hasattr(v, "to_padded"):
+                    T = max(int(v.dense_shape[1]), 1)
+                    idx, lens = v.to_padded(T)
+                    wp = w.to_padded(T)[0] if (w is not None and hasattr(w, "to_padded")) else None
+                else:
+                    idx = np.asarray(v).reshape(B, -1)
+                    lens = np.full((B,), idx.shape[1], dtype=np.int32)
+                    wp = None if w is None else np.asarray(w).reshape(B, -1)
+                item[f] = (idx, lens, wp)
+        batch = self._scorer.tile_request(user, item, np.asarray(inputs["features"], dtype=np.float32))
+        self.rt.engine.dropout_step_seed = None
+        return self._scorer.logits(batch)
 
     def _mask(self, mask):
         dev = self.rt.store.device

@@ -6,7 +6,7 @@ import torch
 
 from ... import ops
 from .. import runtime as R
-from .TransformerModel_util import ff, multihead_attention, _leaf
+from .TransformerModel_util import ff, multihead_attention, _leaf, _seq_index
 
 
 class TransformerModel():
@@ -35,15 +35,16 @@ class TransformerModel():
         return ops.ScaleAddPosFn.apply(seq_k, pos, scale)
 
     def encode(self, xs, name="encoder", training=True):
-        if training and self._get("dropout_rate", 0.0):
-            raise NotImplementedError("Transformer dropout is not implemented in the HIP path (use training=False)")
+        rate = float(self._get("dropout_rate", 0.0) or 0.0) if training else 0.0
+        eng = R.get_default().engine
         with R.variable_scope(name):
             seq_emb, seqlens, seq_k_ts = xs
             enc = self.position_encode(seq_emb, seq_k_ts, self._get("maxlen_k"), float(self._d_model()) ** 0.5)
+            enc = ops.dropout(enc, rate, eng.dropout_step_seed if rate else None, 10 * _seq_index() + 0)   # TransformerModel.py:101
             for i in range(self._get("num_blocks_encode", 1)):
                 with R.variable_scope("num_blocks_{}".format(i)):
                     enc = multihead_attention(queries=enc, keys=enc, values=enc, queries_length=seqlens, keys_length=seqlens,
-                                              num_heads=self._get("num_heads"), dropout_rate=0, training=False, causality=False,
+                                              num_heads=self._get("num_heads"), dropout_rate=rate, training=training, causality=False,
                                               scope="self-attention")
                     enc = ff(enc, num_units=[self._get("d_ff"), self._d_model()])
         return enc, seqlens
@@ -53,12 +54,15 @@ class TransformerModel():
             raise NotImplementedError("is_decoder_add_pos_emb=true")
         with R.variable_scope(name):
             query_emb, query_length, key_emb, key_length = ys
+            rate = float(self._get("dropout_rate", 0.0) or 0.0) if training else 0.0
+            eng = R.get_default().engine
             dec = ops.ScaleAddPosFn.apply(query_emb, None, float(self._d_model()) ** 0.5)
+            dec = ops.dropout(dec, rate, eng.dropout_step_seed if rate else None, 10 * _seq_index() + 1)     # TransformerModel.py:151
             for i in range(self._get("num_blocks_decode", 1)):
                 with R.variable_scope("num_blocks_{}".format(i)):
                     dec = multihead_attention(queries=dec, keys=key_emb, values=key_emb, queries_length=query_length,
-                                              keys_length=key_length, num_heads=self._get("num_heads"), dropout_rate=0,
-                                              training=False, causality=False, scope="vanilla_attention")
+                                              keys_length=key_length, num_heads=self._get("num_heads"), dropout_rate=rate,
+                                              training=training, causality=False, scope="vanilla_attention")
                     tied = R.get_default().spec.get("tie_ffn", True)
                     dec = ff(dec, num_units=[self._get("d_ff"), self._d_model()],
                              scope="positionwise_feedforward" if tied else "positionwise_feedforward_dec")

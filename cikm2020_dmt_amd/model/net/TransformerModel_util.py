@@ -3,7 +3,9 @@
     scaled_dot_product_attention :11-56     ln :58-78     mask :80-108     multihead_attention :160-209
     ff :212-235     positional_encoding_learn :281-316
 Variables are looked up by scoped name in the active Runtime's store (the reference creates them under the same
-names with tf.get_variable / tf.layers.dense); dropout is not implemented (parity runs have it off).
+names with tf.get_variable / tf.layers.dense).  Dropout (training=True and dropout_rate > 0) uses the library's counter mask with
+the engine's step seed (engine.dropout_step_seed, set by Inference.inference(is_train=True)); the dropout site is derived from the
+variable scope (sequence i: self-attention weights stream 10 i + 2, vanilla attention 10 i + 3).
 Tensors are device tensors; every op is a libdmt_hip.so kernel.
 """
 from __future__ import annotations
@@ -28,9 +30,21 @@ def _leaf(name):
     return st.leaf[full], st.weight.get(full)
 
 
-def _check_dropout(rate, training):
-    if training and rate:
-        raise NotImplementedError("dropout is not implemented in the HIP path; call with training=False or dropout_rate=0")
+def _seq_index() -> int:
+    """i of the enclosing 'trans_sequence_i' scope (0 outside one)."""
+    import re
+    m = re.search(r"trans_sequence_(\d+)", R.current_scope())
+    return int(m.group(1)) if m else 0
+
+
+def _attn_dropout(rate, training, offset):
+    """(site seed, keep probability) of the attention-weight dropout, or (0, 1.0) when it is off."""
+    eng = R.get_default().engine
+    if not training or not rate:
+        return 0, 1.0
+    if eng.dropout_step_seed is None:
+        raise RuntimeError("training=True with dropout_rate > 0 needs engine.dropout_step_seed (Inference.inference(is_train=True) sets it)")
+    return ops.site_seed(eng.dropout_step_seed, 10 * _seq_index() + offset), 1.0 - float(rate)
 
 
 def ln(inputs, epsilon=1e-8, scope="ln"):
@@ -59,7 +73,7 @@ def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, causality=Fals
     """Q,K,V: [h*N, T, d_k] head-major packing of the reference; masks [N, T] bool / 0-1.  Returns [h*N, T_q, d_k]."""
     if causality:
         raise NotImplementedError("causality=True is never used by DMT")
-    _check_dropout(dropout_rate, training)
+    seed, keep = _attn_dropout(dropout_rate, training, 2)
     N = key_masks.shape[0]
     h = Q.shape[0] // N
     dk = Q.shape[-1]
@@ -71,7 +85,7 @@ def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, causality=Fals
     q_lens = query_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
     k_lens = key_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
     kv = torch.cat([k, v], dim=-1)
-    out = ops.AttnFn.apply(q, kv, None, q_lens, k_lens, h, h * dk, False)
+    out = ops.AttnFn.apply(q, kv, None, q_lens, k_lens, h, h * dk, False, seed, keep)
     return torch.cat(torch.split(out, dk, dim=2), dim=0)
 
 
@@ -79,7 +93,6 @@ def multihead_attention(queries, keys, values, queries_length, keys_length, num_
                         causality=False, scope="multihead_attention"):
     if causality:
         raise NotImplementedError("causality=True is never used by DMT")
-    _check_dropout(dropout_rate, training)
     if values is not keys:
         raise NotImplementedError("DMT always attends with values = keys")
     d = queries.shape[-1]
@@ -92,12 +105,14 @@ def multihead_attention(queries, keys, values, queries_length, keys_length, num_
     ql = queries_length.to(torch.int32).contiguous() if queries_length is not None else None
     kl = keys_length.to(torch.int32).contiguous()
     if queries is keys:
+        seed, keep = _attn_dropout(dropout_rate, training, 2)
         qkv = ops.linear(queries, wl, bl, w)
-        s = ops.AttnFn.apply(qkv, None, queries, ql, kl, num_heads, d, True)
+        s = ops.AttnFn.apply(qkv, None, queries, ql, kl, num_heads, d, True, seed, keep)
     else:
+        seed, keep = _attn_dropout(dropout_rate, training, 3)
         q = ops.linear(queries, wl[:, :d], bl[:d], eng._wslice(w, 0, d))
         kv = ops.linear(keys, wl[:, d:], bl[d:], eng._wslice(w, d, 3 * d))
-        s = ops.AttnFn.apply(q, kv, queries, ql, kl, num_heads, d, False)
+        s = ops.AttnFn.apply(q, kv, queries, ql, kl, num_heads, d, False, seed, keep)
     return ops.layer_norm(s, gamma, beta, 1e-8)
 
 

@@ -35,9 +35,7 @@ class mmoe_transformer_unbias(base):
         sp = self.rt.spec
         if list(units) != list(sp["hidden_units_bottom"]) or num_experts != sp["num_experts"] or num_tasks != sp["num_tasks"]:
             raise ValueError("expert_gate arguments differ from the configured MMoE")
-        with R.variable_scope("mmoe_layers"):
-            pass
-        eng = self.rt.engine
+        eng = self.rt.engine                 # (the variables live under the reference's scope 'mmoe_layers', see variables.py)
         z = features
         if features.shape[1] != eng.plan.K:
             raise ValueError("features must be [B, %d]" % eng.plan.K)
@@ -66,7 +64,8 @@ class mmoe_transformer_unbias(base):
     def trans_core(self, seq_data, is_train=True):
         sp = self.rt.spec
         hp = _HP(d_model=sp["d_model"], d_ff=sp["d_ff"], num_heads=sp["num_heads"], maxlen_k=sp["maxlen_k"],
-                 num_blocks_encode=1, num_blocks_decode=1, position_encoding_method="position_learn", dropout_rate=0.0)
+                 num_blocks_encode=1, num_blocks_decode=1, position_encoding_method="position_learn",
+                 dropout_rate=sp.get("dropout_rate", 0.0))
         states = []
         # the reference calls trans_core inside variable_scope('embedding_trans') (:227); open it when called directly
         import contextlib
@@ -78,7 +77,8 @@ class mmoe_transformer_unbias(base):
                 m = TransformerModel(hp)
                 seq_q = tar_sku_emb.unsqueeze(1)
                 q_lens = torch.ones(seq_q.shape[0], dtype=torch.int32, device=seq_q.device)
-                user_stat = m.encode_decode((seq_q, q_lens, seq_emb, seq_lens, seq_ts_emb), name="encode_decode_" + stag, training=False)
+                user_stat = m.encode_decode((seq_q, q_lens, seq_emb, seq_lens, seq_ts_emb), name="encode_decode_" + stag,
+                                              training=bool(is_train) and self.rt.engine.dropout_step_seed is not None)
             states.append(user_stat)
         return torch.cat(states, -1)
 
@@ -106,9 +106,31 @@ class mmoe_transformer_unbias(base):
 
     # ---- :293-316
     def inference(self, inputs, is_train=True, is_predict=False):
+        """is_train decides the dropout of the forward pass through engine.dropout_step_seed, which Inference.inference sets
+        (None for is_train=False); a caller that uses this class directly sets it the same way."""
         batch = self.rt.as_batch(inputs)
-        out = self.rt.engine.inference(batch, is_predict=is_predict)
+        eng = self.rt.engine
+        if not is_train or is_predict:
+            eng.dropout_step_seed = None
+        out = eng.inference(batch, is_predict=is_predict)
         return out
 
     def l2_norm(self, inputs):
-        raise NotImplementedError("l2_norm is only reached when wnd_wd > 1e-5 (run_dnn.py:174-175); dmt.conf has wnd_wd = 0.0")
+        """mmoe_transformer_unbias.py:42-60: sum over the embedding_list entries of l2_loss(E[unique ids of the feature]) times
+        l2_emb_lambda / batch_size (tf.losses.get_regularization_losses() is empty: no layer registers a regularizer).
+        The VALUE is computed on the GPU (dmt_l2_unique_rows); it is only reached when wnd_wd > 1e-5 (run_dnn.py:174-175, dmt.conf has
+        0.0), and its gradient -- lambda / batch_size times the row, on every distinct row of the batch -- is not propagated here."""
+        eng, sp = self.rt.engine, self.rt.spec
+        batch = self.rt.as_batch(inputs)
+        dev = eng.store.device
+        out = torch.zeros(1, dtype=torch.float32, device=dev)
+        for (name, rows, dim, feat, _side) in sp["embedding_list"]:
+            col = batch.feats[feat]
+            table = eng.store.table["embedding_trans/%s/embedding" % name]
+            seen = torch.zeros(rows // 32 + 1, dtype=torch.int32, device=dev)
+            L.call("dmt_l2_unique_rows", batch.B, col.T, ops.p(col.idx), ops.p(col.lens), ops.p(table), rows, dim, ops.p(seen), ops.p(out),
+                   ops.stream_ptr())
+        m = self.wnd_conf["model"] if self.wnd_conf is not None else {}
+        lam = float(m.get("l2_emb_lambda", 0.01)) if isinstance(m, dict) else 0.01
+        bs = float(m.get("batch_size", batch.B)) if isinstance(m, dict) else float(batch.B)
+        return out[0] * (lam / bs)

@@ -31,6 +31,7 @@ class TFAdam:
         self.lr_hist = torch.zeros(max_steps, dtype=torch.float32, device=dev)
         self.max_steps = max_steps
         self.global_step = 0
+        self._step_base = 0          # global_step at which the device-side step counter / lr history last restarted
         names, row_base, dims, offs = store.table_map()
         tm = L.TableMap()
         tm.n_tables = len(names)
@@ -47,8 +48,11 @@ class TFAdam:
         return self.lrs[-1]
 
     def begin(self):
-        if self.global_step + 1 >= self.max_steps:
-            raise RuntimeError("lr history capacity exhausted (%d steps)" % self.max_steps)
+        # the lr history holds one entry per step since the last restart of the device-side counter (reset_slots / rebase), NOT per
+        # global step: a run resumed from model.ckpt-1500000 starts it at 0.  When it fills up, pending lazy rows are flushed (so no
+        # row needs an older entry) and the history restarts; the Adam state (m, v, beta powers) is untouched.
+        if self.global_step - self._step_base + 1 >= self.max_steps:
+            self.rebase()
         L.call("dmt_adam_begin_step", ops.p(self.state), ops.p(self.lr_hist), self.max_steps, float(self.current_lr()), self.b1,
                self.b2, ops.stream_ptr())
 
@@ -100,6 +104,14 @@ class TFAdam:
         self.state[0], self.state[1] = self.b1, self.b2
         self.global_step = int(global_step)
         self._step_base = int(global_step)
+
+    def rebase(self):
+        """Restart the per-step lr history without changing any value: replay every pending zero-gradient row update (flush), then
+        mark all rows as up to date at local step 0."""
+        self.flush_tables()
+        L.call("dmt_adam_rebase", ops.p(self.state), ops.p(self.store.last_step), self.store.total_rows, ops.stream_ptr())
+        self.lr_hist.zero_()
+        self._step_base = self.global_step
 
     def flush_tables(self):
         """Replay pending zero-gradient updates on every table row (before checkpoint / full-table export)."""

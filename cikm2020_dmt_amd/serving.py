@@ -37,8 +37,13 @@ def normalise_dense(raw: torch.Tensor, const_vec: torch.Tensor, std: torch.Tenso
 
 class CandidateScorer:
     def __init__(self, engine: DMTEngine, export_weight=(1.0, 1.0), mean: Optional[Sequence[float]] = None,
-                 std: Optional[Sequence[float]] = None):
+                 std: Optional[Sequence[float]] = None, optimizer=None):
+        """optimizer: the TFAdam of a LIVE trainer sharing this engine's tables, or None for a frozen / restored model.  The exact lazy
+        Adam leaves zero-gradient updates of untouched rows pending; scoring reads rows without replaying them, so with
+        a live optimizer the tables are flushed before every request that follows a train step."""
         self.engine = engine
+        self.optimizer = optimizer
+        self._flushed_at = -1
         self.spec = engine.spec
         self.w = (float(export_weight[0]), float(export_weight[1]))
         dev = engine.store.device
@@ -87,6 +92,9 @@ class CandidateScorer:
     def logits(self, batch: DeviceBatch):
         """(click_logit, order_logit) [B, 1] for B candidate rows of one user; user-side columns are read from row 0."""
         eng, spec = self.engine, self.spec
+        if self.optimizer is not None and self.optimizer.global_step != self._flushed_at:
+            self.optimizer.flush_tables()
+            self._flushed_at = self.optimizer.global_step
         saved_seed, eng.dropout_step_seed = eng.dropout_step_seed, None        # predict graph: is_train=False
         try:
             b1 = self._row0(batch)
@@ -137,11 +145,18 @@ class GraphedScorer:
             raise ValueError("request does not match the captured shape (B=%d)" % st.B)
         for f, col in batch.feats.items():
             dst = st.feats[f]
-            if col.idx.shape != dst.idx.shape or (col.wts is None) != (dst.wts is None):
-                raise ValueError("feature %s: id-list shape / weights differ from the captured request" % f)
+            if col.idx.shape != dst.idx.shape:
+                raise ValueError("feature %s: id-list shape differs from the captured request" % f)
+            # whether a weights column exists is a property of the captured graph, not of a request's values: a request whose weights
+            # are all 1.0 arrives without the column (tile_request drops it) and is served by writing ones
+            if dst.wts is None and col.wts is not None:
+                raise ValueError("feature %s: the captured request has no weights column but this request has weights != 1" % f)
             dst.idx.copy_(col.idx); dst.lens.copy_(col.lens)
-            if col.wts is not None:
-                dst.wts.copy_(col.wts)
+            if dst.wts is not None:
+                if col.wts is not None:
+                    dst.wts.copy_(col.wts)
+                else:
+                    dst.wts.fill_(1.0)
         st.dense.copy_(batch.dense)
         self.graph.replay()
         return self.out

@@ -21,8 +21,8 @@ from .variables import VariableStore
 
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
-                 step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = False, dropout_seed: int = 1,
-                 dp_exchange: str = "owner", force_dp: bool = False):
+                 step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
+                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None):
         self.spec = spec
         self.device = torch.device(device)
         self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init)
@@ -30,8 +30,10 @@ class Trainer:
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
         # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in
-        # train().  Off by default here because parity runs need it off; bench.py turns it on.
+        # train(), so it is the default here; parity runs against the oracle pass dropout=False (or the same seeds).
         self.dropout, self.dropout_seed = dropout, dropout_seed
+        if fused_mhsa is not None:
+            self.engine.use_mhsa = bool(fused_mhsa)
         if dp_exchange not in ("owner", "allgather"):
             raise ValueError("dp_exchange must be 'owner' or 'allgather'")
         self.dp_exchange = dp_exchange     # how the embedding-gradient rows cross ranks (parallel.py)

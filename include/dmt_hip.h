@@ -320,6 +320,9 @@ int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m, float* v,
 /* Bring every row of every table up to date (before checkpoint / evaluation of untouched rows).      */
 int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                         const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream);
+/* After dmt_adam_flush_rows: restart the device-side step counter that indexes lr_hist (state[3] = 0, last_step[:] = 0), so a run
+ * longer than the history's capacity -- or one resumed from model.ckpt-<large N> -- keeps going.  Values are untouched. */
+int dmt_adam_rebase(float* state, int32_t* last_step, int64_t rows, void* stream);
 
 /* fp32 -> bf16 shadow copies of 2-D weights, plain and transposed: dst[n*ld_t + k] = src[k*ld + n].    */
 int dmt_cast_bf16(int64_t n, const float* src, void* dst, void* stream);
@@ -460,6 +463,13 @@ int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, fl
 /* Streaming 200-threshold confusion histogram behind tf.metrics.auc (run_dnn.py:228-241):
  * hist[(label?1:0) * (n_thr+1) + #thresholds below pred] += 1 (int64).                                */
 int dmt_auc_hist(int32_t B, const float* pred, const float* label, int32_t n_thr, long long* hist, void* stream);
+/* Streaming confusion counts behind tf.metrics.precision / tf.metrics.recall (run_dnn.py:221-227, 230-238; predictions are
+ * tf.greater(p, 0.5) there, labels are cast to bool):  counts[0..3] += (tp, fp, fn, tn) with prediction = pred > threshold. */
+int dmt_confusion_counts(int32_t B, const float* pred, const float* label, float threshold, long long* counts, void* stream);
+/* out += sum over the DISTINCT ids of one feature of ||E[id]||^2 / 2: the per-feature term of l2_norm
+ * (model/net/mmoe_transformer_unbias.py:42-60: tf.nn.l2_loss(tf.gather(E, tf.unique(ids)))).  seen: rows / 32 + 1 zeroed words. */
+int dmt_l2_unique_rows(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows, int32_t dim,
+                       uint32_t* seen, float* out, void* stream);
 
 #ifdef __cplusplus
 }

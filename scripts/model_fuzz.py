@@ -14,7 +14,7 @@ for B in (1, 7, 64, 300):
     for seed in (1, 2, 3):
         P = O.init_params(so, seed=seed)
         inputs, mask, label = make_batch(sp, B, seed=100 * seed + B, lengths="ragged", weights="random")
-        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False)
+        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False, dropout=False)
         tr.store.load_state(P)
         loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
         loss = tr.forward_backward(tr.make_batch(inputs, mask, label))

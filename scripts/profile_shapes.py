@@ -8,7 +8,7 @@ from cikm2020_dmt_amd.train import Trainer
 dims = sys.argv[1] if len(sys.argv) > 1 else 'e64'
 dt = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == 'bf16') else torch.float32
 sp = S.e64_spec() if dims == 'e64' else S.default_spec()
-tr = Trainer(sp, device='cuda', compute_dtype=dt, seed=1)
+tr = Trainer(sp, device='cuda', compute_dtype=dt, seed=1, dropout=False)
 inputs, mask, label = make_batch(sp, 4096, seed=1, lengths='full')
 b = tr.make_batch(inputs, mask, label)
 orig = ops.gemm

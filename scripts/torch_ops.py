@@ -16,11 +16,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     tr.train_step(b)
     torch.cuda.synchronize()
-agg = collections.Counter(); tim = collections.Counter()
-for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name.startswith("aten::") and ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::zeros", "aten::empty_like", "aten::sum", "aten::cat", "aten::index", "aten::select_backward", "aten::slice_backward"):
-        st = [f for f in (ev.stack or []) if "cikm2020_dmt_amd" in f or "bench" in f]
-        key = (ev.name, st[0].strip() if st else "(autograd engine)")
-        agg[key] += 1; tim[key] += ev.device_time_total if hasattr(ev, "device_time_total") else ev.cuda_time_total
-for k, n in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:60]:
-    print("%4d x %-18s %8.1f us  %s" % (n, k[0], tim[k], k[1][:150]))
+import traceback
+rows = prof.key_averages(group_by_stack_n=12)
+sel = [r for r in rows if r.key in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::clone", "aten::_to_copy", "aten::zeros", "aten::cat", "aten::sum", "aten::index_select", "aten::slice_backward")]
+sel.sort(key=lambda r: -(r.device_time_total if hasattr(r, "device_time_total") else r.cuda_time_total))
+for r in sel[:40]:
+    st = [f for f in r.stack if ("cikm2020" in f or "bench" in f)]
+    t = r.device_time_total if hasattr(r, "device_time_total") else r.cuda_time_total
+    print("%3d x %-14s %7.1f us | %s" % (r.count, r.key, t, " <- ".join(x.split("/")[-1][:60] for x in st[:3])))

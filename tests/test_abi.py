@@ -28,7 +28,8 @@ def test_ctypes_struct_layouts_match_the_header():
     lib = L.load()
     lib.dmt_struct_size.restype = C.c_int
     lib.dmt_struct_size.argtypes = [C.c_int]
-    for i, st in enumerate([L.GatherFeature, L.GatherDesc, L.EmbGradDesc, L.GemmDesc, L.AttnDesc, L.AttnBwdDesc, L.TableMap, L.CastJob]):
+    for i, st in enumerate([L.GatherFeature, L.GatherDesc, L.EmbGradDesc, L.GemmDesc, L.AttnDesc, L.AttnBwdDesc, L.TableMap, L.CastJob,
+                            L.ChainDesc, L.WgradDesc, L.MhsaDesc]):
         assert C.sizeof(st) == lib.dmt_struct_size(i), st.__name__
     assert C.sizeof(L.EmbGradDesc) < 4096 and C.sizeof(L.GatherDesc) < 4096   # passed by value as kernel arguments
 
@@ -41,3 +42,31 @@ def test_argument_validation_needs_no_gpu():
     assert b"dmt_gemm" in lib.dmt_last_error()
     assert lib.dmt_gather_fwd(None, None) == -1
     assert lib.dmt_ln_bwd_partials(10 ** 7) == 1024
+
+
+def test_integration_md_gemm_binding_matches_the_header():
+    """The ctypes stub INTEGRATION.md shows a maintainer is executed as written: its GemmDesc must have the header's fields, in
+    order, and sizeof(dmt_gemm_desc) (a stale snippet mis-lays every field behind the missing one)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class GemmDesc\(C\.Structure\):.*?\n(\s+_fields_ = \[.*?\)\])", text, flags=re.S)
+    assert m, "GemmDesc snippet not found in INTEGRATION.md"
+    ns = {"C": C}
+    exec("class GemmDesc(C.Structure):\n" + m.group(1), ns)
+    doc = ns["GemmDesc"]
+    lib = L.load()
+    lib.dmt_struct_size.restype = C.c_int
+    lib.dmt_struct_size.argtypes = [C.c_int]
+    assert C.sizeof(doc) == lib.dmt_struct_size(3)
+    assert [f[0] for f in doc._fields_] == [f[0] for f in L.GemmDesc._fields_]
+    # ... and the header's own field list
+    hdr = open(os.path.join(ROOT, "include", "dmt_hip.h")).read()
+    body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} dmt_gemm_desc;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.sub(r"[\*\s]", " ", part).split()[-1])
+    assert names == [f[0] for f in doc._fields_]

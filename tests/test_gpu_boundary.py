@@ -1,0 +1,178 @@
+"""The reference-shaped boundary: Inference.inference(is_train) dropout semantics, online_inference, l2_norm,
+streaming precision / recall, and the optimizer's long-run behaviour (lr-history restart, bounded lazy replay)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dmt_oracle as O
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch
+from cikm2020_dmt_amd.metrics import StreamingPrecisionRecall, precision_recall_reference
+from cikm2020_dmt_amd.model.inference_mlp import Inference
+from cikm2020_dmt_amd.optim import TFAdam
+from cikm2020_dmt_amd.variables import VariableStore
+from tests.util import small_specs
+
+pytestmark = pytest.mark.gpu
+
+
+def _inference(cuda, dtype=torch.float32, seed=9):
+    so, sp = small_specs()
+    so = dict(so, dropout_rate=0.1, dropout_rate_bias=[0.5, 0.5])
+    P = O.init_params(so, seed=seed)
+    inf = Inference(None, device=cuda, compute_dtype=dtype, seed=4, spec=sp)
+    inf.rt.store.load_state(P)
+    return so, sp, P, inf
+
+
+def test_facade_is_train_applies_the_reference_dropout(cuda):
+    """inference(inputs, is_train=True) runs Transformer dropout 0.1 + bias-tower dropout 0.5 (TransformerModel.py:101,151;
+    mmoe_transformer_unbias.py:274-278); is_train=False and is_predict never drop.  Same counter mask as the oracle."""
+    so, sp, P, inf = _inference(cuda)
+    inputs, mask, _label = make_batch(sp, 19, seed=2, lengths="ragged", weights="random")
+    (c0, o0), yb0 = O.inference(inputs, P, so)
+    with torch.no_grad():
+        (c, o), yb = inf.inference(inputs, is_train=False)
+    assert np.abs(c.cpu().numpy() - c0).max() < 3e-4 and np.abs(yb.cpu().numpy() - yb0).max() < 3e-4
+    inf.set_step_seed(4242)
+    with torch.no_grad():
+        (cd, od), ybd = inf.inference(inputs, is_train=True)
+    (c1, o1), yb1 = O.inference(inputs, P, so, step_seed=4242)
+    assert np.abs(c1 - c0).max() > 1e-3                                   # dropout changes the outputs ...
+    assert np.abs(cd.cpu().numpy() - c1).max() < 3e-4                     # ... exactly as the oracle's masks do
+    assert np.abs(od.cpu().numpy() - o1).max() < 3e-4
+    assert np.abs(ybd.cpu().numpy() - yb1).max() < 3e-4
+    # the running counter: two training calls use different masks; predict resets to no dropout
+    with torch.no_grad():
+        (ca, _), _ = inf.inference(inputs, is_train=True)
+        (cb, _), _ = inf.inference(inputs, is_train=True)
+        cp, _op = inf.inference(inputs, is_train=True, is_predict=True)
+    assert (ca - cb).abs().max() > 1e-4
+    assert np.abs(cp.cpu().numpy() - c0).max() < 3e-4
+
+
+def test_online_inference_equals_the_tiled_predict_graph(cuda):
+    """inference_mlp.py:73-143: user-side id lists arrive once (1-D) and are tiled across BatchSize candidates."""
+    so, sp, P, inf = _inference(cuda)
+    B = 23
+    inputs, _mask, _label = make_batch(sp, B, seed=6, lengths="ragged", weights="ones")
+    from tests.test_gpu_serving import _tile_user_side
+    tiled = _tile_user_side(sp, inputs)
+    c_or, o_or = O.inference(tiled, P, so, is_predict=True)
+    req = {"BatchSize": B, "features": inputs["features"]}
+    for (_n, _r, _d, f, side) in list(sp["embedding_list"]) + list(sp["embedding_list_bias"]):
+        spv, w = inputs[f], inputs[f + "Wts"]
+        if side == "u":
+            sel = np.asarray(spv.indices)[:, 0] == 0
+            req[f] = np.asarray(spv.values)[sel]
+            req[f + "Wts"] = np.asarray(w.values)[sel]
+        else:
+            req[f], req[f + "Wts"] = spv, w
+    c, o = inf.online_inference(req)
+    assert np.abs(c.cpu().numpy() - c_or).max() < 3e-4
+    assert np.abs(o.cpu().numpy() - o_or).max() < 3e-4
+
+
+def test_l2_norm_matches_the_reference_rule(cuda):
+    """mmoe_transformer_unbias.py:42-60: sum_f l2_loss(E_f[unique ids of f]) * l2_emb_lambda / batch_size."""
+    so, sp, P, inf = _inference(cuda)
+    B = 31
+    inputs, _m, _l = make_batch(sp, B, seed=3, lengths="ragged", weights="ones")
+    want = 0.0
+    for (name, _rows, _dim, feat, _side) in sp["embedding_list"]:
+        ids = np.unique(np.asarray(inputs[feat].values).astype(np.int64))
+        E = P["embedding_trans/%s/embedding" % name].astype(np.float64)
+        want += 0.5 * (E[ids] ** 2).sum()
+    want *= 0.01 / B                                # Inference(None): l2_emb_lambda 0.01 (dmt.conf:76), batch_size = this batch
+    got = float(inf.l2_norm(inputs))
+    assert abs(got - want) / want < 1e-5
+
+
+def test_streaming_precision_recall_matches_the_tf_metrics_rule(cuda):
+    rng = np.random.default_rng(0)
+    m = StreamingPrecisionRecall(cuda)
+    assert m.result() == (0.0, 0.0)                 # safe division before any data
+    scores, labels = [], []
+    for n in (1, 257, 4096, 33):
+        s = rng.random(n).astype(np.float32)
+        s[::7] = 0.5                                # exactly at the threshold: tf.greater(p, 0.5) is False
+        y = (rng.random(n) < 0.3).astype(np.float32) * rng.integers(1, 3, n)     # labels are sums of mask columns: any non-zero is positive
+        scores.append(s); labels.append(y)
+        m.update(torch.as_tensor(s).to(cuda), torch.as_tensor(y.astype(np.float32)).to(cuda))
+    p, r = m.result()
+    pw, rw = precision_recall_reference(scores, labels)
+    assert abs(p - pw) < 1e-12 and abs(r - rw) < 1e-12
+    tp, fp, fn, tn = m.counts.cpu().numpy()
+    assert tp + fp + fn + tn == sum(len(s) for s in scores)
+
+
+def test_optimizer_survives_a_restored_large_step_and_a_full_lr_history(cuda):
+    """restoring model.ckpt-1500000 (reset_slots(1500000)) must not trip the lr-history capacity, and a run longer than
+    the capacity restarts the history (flush + rebase) instead of raising."""
+    _so, sp = small_specs()
+    st = VariableStore(sp, cuda, torch.float32, seed=1)
+    opt = TFAdam(st, max_steps=8)
+    opt.reset_slots(1500000)
+    rng = np.random.default_rng(1)
+    D = max(t.shape[1] for t in st.table.values())
+    ref = VariableStore(sp, cuda, torch.float32, seed=1)
+    oref = TFAdam(ref, max_steps=1 << 12)
+    oref.reset_slots(1500000)
+    for step in range(30):                          # 30 steps through a history of 8 entries: several rebases
+        rows = np.unique(rng.integers(0, st.total_rows, size=50)).astype(np.int32)
+        g = (rng.standard_normal((len(rows), D)) * 0.01).astype(np.float32)
+        for o in (opt, oref):
+            o.begin()
+            o.apply_sparse((torch.tensor(rows, device=cuda), torch.tensor([len(rows)], dtype=torch.int32, device=cuda), torch.tensor(g, device=cuda), len(rows)))
+            o.end()
+    assert opt.global_step == 1500030
+    opt.flush_tables(); oref.flush_tables()
+    assert np.array_equal(st.tab_p.cpu().numpy().view(np.uint32), ref.tab_p.cpu().numpy().view(np.uint32))
+    assert np.array_equal(st.tab_m.cpu().numpy().view(np.uint32), ref.tab_m.cpu().numpy().view(np.uint32))
+
+
+def test_lazy_adam_long_gaps_are_bounded_and_match_the_dense_sweep(cuda):
+    """A row untouched for thousands of steps: p exactly what the dense sweep leaves (it stops moving after ~150 zero-gradient
+    steps), m and v within 1e-4 relative of the dense sweep's serial products (closed-form tail, dmt_optim.hip)."""
+    _so, sp = small_specs()
+    a = VariableStore(sp, cuda, torch.float32, seed=2)
+    b = VariableStore(sp, cuda, torch.float32, seed=2)
+    oa, ob = TFAdam(a, max_steps=1 << 13), TFAdam(b, max_steps=1 << 13)
+    rng = np.random.default_rng(4)
+    D = max(t.shape[1] for t in a.table.values())
+    rows = np.unique(rng.integers(0, a.total_rows, size=300)).astype(np.int32)
+    g = (rng.standard_normal((len(rows), D)) * 0.02).astype(np.float32)
+
+    def dense_grads(rows_, g_):
+        out = {}
+        for name, (base, nr) in b.table_rows.items():
+            dim = b.tables[name].shape[1]
+            gd = np.zeros((nr, dim), np.float32)
+            if rows_ is not None:
+                sel = (rows_ >= base) & (rows_ < base + nr)
+                gd[rows_[sel] - base] = g_[sel][:, :dim]
+            out[name] = torch.tensor(gd, device=cuda)
+        return out
+
+    def sparse(rows_, g_):
+        return (torch.tensor(rows_, device=cuda), torch.tensor([len(rows_)], dtype=torch.int32, device=cuda), torch.tensor(g_, device=cuda), len(rows_))
+
+    oa.begin(); oa.apply_sparse(sparse(rows, g)); oa.end()
+    ob.begin(); ob.apply_dense_tables(dense_grads(rows, g)); ob.end()
+    zero = dense_grads(None, None)
+    one = np.array([int(rows[0])], dtype=np.int32)
+    for _ in range(3000):                           # 3000 steps in which only one row gets gradients
+        g1 = (rng.standard_normal((1, D)) * 0.02).astype(np.float32)
+        oa.begin(); oa.apply_sparse(sparse(one, g1)); oa.end()
+        d = {k: v for k, v in zero.items()}
+        for name, (base, nr) in b.table_rows.items():
+            if base <= one[0] < base + nr:
+                gd = torch.zeros_like(zero[name]); gd[one[0] - base] = torch.tensor(g1[0, : gd.shape[1]], device=cuda); d[name] = gd
+        ob.begin(); ob.apply_dense_tables(d); ob.end()
+    oa.flush_tables()
+    pa, pb = a.tab_p.cpu().numpy(), b.tab_p.cpu().numpy()
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+    for x, y in ((a.tab_m, b.tab_m), (a.tab_v, b.tab_v)):
+        xa, ya = x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
+        big = np.abs(ya) > 1e-30
+        assert (np.abs(xa - ya)[big] / np.abs(ya)[big]).max() < 1e-4
+        assert np.abs(xa[~big]).max() < 1e-29

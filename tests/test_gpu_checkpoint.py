@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def test_save_restore_and_resume_match_the_oracle(cuda, tmp_path):
     so, sp = small_specs()
     P = O.init_params(so, seed=9)
-    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, init=False)
+    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, init=False, dropout=False)
     tr.store.load_state(P)
     adam = O.TFAdam(lr=1e-3)
     Pr = {k: v.copy() for k, v in P.items()}
@@ -36,7 +36,7 @@ def test_save_restore_and_resume_match_the_oracle(cuda, tmp_path):
         assert all(k.startswith("DnnModel/") for k in z.files)
         assert sorted(k[len("DnnModel/"):] for k in z.files) == sorted(P)              # trainable variables only: no slots, no step
     # a fresh process: restore -> identical variables, step 3, Adam slots restarted
-    tr2 = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=123)
+    tr2 = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=123, dropout=False)
     assert CK.restore(tr2, model_path) == 3
     s1, s2 = tr.store.state_dict(), tr2.store.state_dict()
     for k in s1:

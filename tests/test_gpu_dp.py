@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
-    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dp_exchange=dp_exchange)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dp_exchange=dp_exchange, dropout=False)
     tr.store.load_state(P)
     losses = []
     for s in range(steps):
@@ -190,7 +190,7 @@ def _nccl_world1_step(q, bf16):
     P = O.init_params(so, seed=5)
     states = []
     for force in (False, True):
-        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, force_dp=force)
+        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, force_dp=force, dropout=False)
         tr.store.load_state(P)
         for s_ in range(3):
             inputs, mask, _ = make_batch(sp, 9, seed=300 + s_, lengths="ragged", weights="random")

@@ -24,7 +24,7 @@ def _setup(cuda):
     sp = S.scaled_spec(spec_full, comp["rows"])
     so = O.scaled_spec(O.default_spec("12m_10"), comp["rows"])
     P = O.init_params(so, seed=2020)
-    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False)
+    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False, dropout=False)
     tr.store.load_state(P)
     return demo, inputs_all, sp, tr
 

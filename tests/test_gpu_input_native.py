@@ -39,7 +39,7 @@ def test_forward_from_native_parsed_records_is_bit_identical(cuda, tmp_path):
     assert len(batches) == 1
     parser.pinned = True                                  # packed page-locked buffer, single upload, device-side views
     batches_p = list(parser.batches([path], B))
-    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=3)
+    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=3, dropout=False)
     b_nat = DeviceBatch.from_columns(batches[0], sp, cuda)
     b_ref = tr.make_batch(inputs, mask, label, pad_to=max_lens)
     tr.sync_rows(b_ref)

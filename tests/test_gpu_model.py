@@ -31,7 +31,7 @@ def _setup(cuda, dtype, B=24, seed=5, lengths="ragged", weights="random", seq_le
         if k.endswith("/beta") or k.endswith("/bias"):
             P[k] = P[k] + 0.05 * rng.standard_normal(P[k].shape)
     inputs, mask, label = make_batch(sp, B, seed=seed, lengths=lengths, weights=weights, seq_lens=seq_lens)
-    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False)
+    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=False)
     tr.store.load_state(P)
     batch = tr.make_batch(inputs, mask, label)
     return so, sp, P, inputs, mask, tr, batch
@@ -120,7 +120,7 @@ def test_edge_cases_len1_and_unknown_ids(cuda):
     for f in sp["attention_embed_seq_ts"]:
         inputs[f] = SparseTensorValue.from_rows([[0]] * 5, np.int64)
         inputs[f + "Wts"] = SparseTensorValue.from_rows([[1.0]] * 5, np.float32)
-    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False)
+    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False, dropout=False)
     tr.store.load_state(P)
     (c_ref, o_ref), yb_ref = O.inference(inputs, P, so)
     (c, o), yb = tr.engine.inference(tr.make_batch(inputs, mask))
@@ -149,7 +149,7 @@ def test_long_sequence_variant_L200_matches_oracle(cuda):
     long_feats = {grp[0][0]: 200 for grp in sp["attention_embed_pairs"][:2]}     # clk and ord sequences; the cart sequence stays at 10
     inputs, mask, label = make_batch(sp, 5, seed=31, lengths="ragged", weights="random", seq_lens=long_feats)
     assert max(inputs[f].dense_shape[1] for f in long_feats) > 64
-    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False)
+    tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False, dropout=False)
     tr.store.load_state(P)
     loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
     loss = tr.forward_backward(tr.make_batch(inputs, mask, label))
