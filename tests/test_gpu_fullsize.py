@@ -136,3 +136,51 @@ def test_full_size_gradient_is_mean_of_half_batch_gradients(cuda):
     assert torch.equal(touched, touched2)                                 # the same distinct rows
     s2 = full.abs().max().item()
     assert (full - acc).abs().max().item() / s2 < 2e-2
+
+
+def test_full_size_dropout_on_uniform_ids_ragged_lengths(cuda):
+    """BASELINE size with train-mode dropout ON (0.1 / 0.5), uniform ids (worst locality) and ragged lengths -- through
+    the forward AND the backward.  Size-independent properties (the dropout counter of an element depends on its example's position
+    in the batch only):
+      * rows never interact: the first half's logits are bit-identical whether or not the second half is in the batch;
+      * the loss is a mask-weighted mean over the batch (inference_mlp.py:207-213): with the second half's label rows zeroed, the
+        gradient of the full batch is exactly half the gradient of the first half run alone -- dense arena and sparse rows."""
+    sp, tr = _trainer(dropout=True)
+    B = 4096
+    inputs, mask, _ = make_batch(sp, B, seed=9, lengths="ragged", law="uniform")
+    first = np.arange(0, B // 2)
+    inputs_h, mask_h = _subset(inputs, mask, first)
+    mask_a = mask.copy()
+    mask_a[B // 2:] = 0.0
+
+    def run(inp, msk):
+        b = tr.make_batch(inp, msk)
+        tr.forward_backward(b)
+        (c, o), y = tr.last["out"]
+        uniq, n_uniq, rows, _cap = tr.engine.sparse
+        n = int(n_uniq.item())
+        return (c.detach().clone(), o.detach().clone(), y.detach().clone()), tr.store.grads.clone(), uniq[:n].clone().long(), rows[:n].clone()
+
+    (c1, o1, y1), gd, ku, ru = run(inputs, mask_a)
+    (c2, o2, y2), gh, kh, rh = run(inputs_h, mask_h)
+    tr.engine.dropout_step_seed = None
+    (c0, _o0), _y0 = tr.engine.inference(tr.make_batch(inputs_h, mask_h))
+    assert (c0.detach() - c2).abs().max().item() > 1e-3                      # dropout really was on in the runs above
+    h = B // 2
+    assert torch.equal(c1[:h], c2) and torch.equal(o1[:h], o2) and torch.equal(y1[:h], y2)
+    assert torch.isfinite(gd).all() and torch.isfinite(ru).all()
+    scale = gh.abs().max().item()
+    assert (gd - 0.5 * gh).abs().max().item() / (0.5 * scale) < 2e-2
+    total = tr.store.total_rows
+    D = ru.shape[1]
+    full = torch.zeros(total, D, device=cuda); full.index_add_(0, ku, ru)
+    half = torch.zeros(total, D, device=cuda); half.index_add_(0, kh, 0.5 * rh)
+    assert (full - half).abs().max().item() / half.abs().max().item() < 2e-2
+    # the dropped fraction of the block input at this size: 0.1 within sampling noise (65 M elements)
+    tr.engine.dropout_step_seed = 12345
+    X, _tar, _z = tr.engine.gather(tr.make_batch(inputs, mask))
+    x0 = X[0]
+    lens = tr.make_batch(inputs, mask).feats[sp["attention_embed_pairs"][0][-1][0]].lens
+    live = (torch.arange(x0.shape[1], device=cuda)[None, :] < lens[:, None])
+    frac = (x0[live] == 0).float().mean().item()
+    assert abs(frac - 0.1) < 2e-3, frac

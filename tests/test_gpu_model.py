@@ -17,6 +17,11 @@ from tests.util import small_specs, sparse_to_dense_tables, rel_err
 
 pytestmark = pytest.mark.gpu
 
+# element-wise bounds of the bf16 path (see test_gradients_match_oracle): in bf16 ulps (2^-8) of the tensor's scale
+# measured on MI355X (B = 24): worst element 164 ulps on 0.06 % of an MMoE layer-0 gradient; 80-wide vectors: up to 9 % of the
+# elements beyond 16 ulps, none beyond 40
+BF16_MAX_ULPS, BF16_TAIL_ULPS, BF16_TAIL_FRAC = 256.0, 16.0, 0.12
+BF16_FAR_ULPS, BF16_FAR_FRAC = 64.0, 0.003
 TOL = {torch.float32: dict(logit=2e-4, loss=1e-5, grad=2e-3, floor=1e-6), torch.bfloat16: dict(logit=6e-2, loss=3e-2, grad=0.2, floor=3e-3)}
 
 
@@ -70,6 +75,7 @@ def test_gradients_match_oracle(cuda, dtype):
     # key bias, to which softmax is invariant -- are measured against the global gradient scale instead
     gscale = max(np.abs(G[n]).max() for n in got)
     bad = []
+    worst_ulps = {}
     for name, g in got.items():
         ref = G[name]
         denom = max(np.linalg.norm(ref), t["floor"] * gscale * np.sqrt(ref.size))
@@ -77,10 +83,25 @@ def test_gradients_match_oracle(cuda, dtype):
         if not e < t["grad"]:
             bad.append((name, float(e), float(np.abs(ref).max())))
         # ... and element by element (a norm over a whole tensor hides a single wrong row among thousands)
+        if dtype == torch.bfloat16:
+            # bf16 activations, element by element, in bf16 ulps (2^-8) of the TENSOR's scale.  In a 24-example batch a relu unit whose
+            # bf16 pre-activation lands on the other side of 0 adds / removes one example's whole contribution to an element, so single
+            # elements may be off by a visible fraction of the tensor's largest gradient; what must hold is that such elements are RARE
+            # and bounded: (a) no element off by more than BF16_MAX_ULPS, (b) at most BF16_TAIL_FRAC of a tensor beyond BF16_TAIL_ULPS.
+            tscale = max(float(np.abs(ref).max()), 1e-2 * gscale)
+            ulps = np.abs(g - ref).reshape(-1) / (tscale * 2.0 ** -8)
+            frac = float((ulps > BF16_TAIL_ULPS).mean())
+            far = float((ulps > BF16_FAR_ULPS).mean())
+            worst_ulps[name] = (float(ulps.max()), frac)
+            if not (ulps.max() < BF16_MAX_ULPS and frac <= BF16_TAIL_FRAC + 1.0 / ulps.size and far <= BF16_FAR_FRAC + 1.0 / ulps.size):
+                bad.append((name, "bf16 element errors (max ulps, fraction beyond tail)", float(ulps.max()), frac))
         if dtype == torch.float32:
             worst = float(np.abs(g - ref).max())
             if not worst < 5e-4 * max(float(np.abs(ref).max()), 1e-3 * gscale):
                 bad.append((name, "max element error", worst, float(np.abs(ref).max())))
+    if worst_ulps:
+        print("bf16 element errors per tensor (max ulps of the tensor scale, fraction beyond %g ulps):" % BF16_TAIL_ULPS,
+              sorted(worst_ulps.items(), key=lambda kv: -kv[1][0])[:5], "| worst tail:", sorted(worst_ulps.items(), key=lambda kv: -kv[1][1])[:3])
     assert not bad, "gradient mismatches: %s" % bad
 
 
