@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
     ap.add_argument("--long-seq", type=int, default=0, help="BASELINE long-seq variant: click / order histories of this length (e.g. 200) instead of 50")
+    ap.add_argument("--shard-tables", action="store_true", help="BASELINE configs[3]: row-sharded embedding tables (rank r holds rows id %% W == r; "
+                    "all-to-all id / row / gradient-row exchange, owner-only Adam) instead of one replica per GPU")
+    ap.add_argument("--sku-rows", type=int, default=0, help="SKU vocabulary (default: the reference's 5 M); configs[3] quotes 100000000")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -80,12 +83,15 @@ def main():
     from cikm2020_dmt_amd.train import Trainer
 
     sp = S.e64_spec() if args.dims == "e64" else S.default_spec()
+    if args.sku_rows:
+        sp = S.scaled_spec(sp, {"Sku": args.sku_rows})
     seq_lens = None
     if args.long_seq:
         sp = dict(sp, maxlen_k=max(sp["maxlen_k"], args.long_seq))
         seq_lens = {grp[0][0]: args.long_seq for grp in sp["attention_embed_pairs"][:2]}
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp)
+    tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp,
+                 table_layout="sharded" if args.shard_tables else "replicated")
     nb = 4
     batches = []
     for i in range(nb):
@@ -161,8 +167,11 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
                                "per-GPU batch %d, L=%s full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
-                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law, "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
-                   "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law,
+                                  ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
+                                  " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
+                                  "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
+                   "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" + row-sharded tables" if args.shard_tables else "") + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
         "roofline": roofline, "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }
     if not args.no_cpu_baseline and world == 1:

@@ -22,7 +22,7 @@ c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 class GatherFeature(C.Structure):
     _fields_ = [("table", c_vp), ("rows", c_i32), ("dim", c_i32), ("idx", c_vp), ("wts", c_vp), ("lens", c_vp),
                 ("T", c_i32), ("pooled_off", c_i32), ("seq_id", c_i32), ("seq_off", c_i32), ("group", c_i32),
-                ("inv_wsum", c_vp)]
+                ("inv_wsum", c_vp), ("row_stride", c_i32), ("idx_seq", c_vp)]
 
 
 class GatherDesc(C.Structure):
@@ -91,7 +91,7 @@ class WgradDesc(C.Structure):
 
 class TableMap(C.Structure):
     _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
-                ("elem_off", c_i64 * DMT_MAX_TABLES)]
+                ("elem_off", c_i64 * DMT_MAX_TABLES), ("shard_w", c_i32), ("shard_r", c_i32)]
 
 
 _SIGS = {
@@ -99,6 +99,7 @@ _SIGS = {
     "dmt_embgrad_keys": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp],
     "dmt_sort_pairs": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_segment_heads": [c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_vp, c_vp, C.POINTER(C.c_uint64), c_vp],
+    "dmt_entry_slots": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
     "dmt_embgrad_reduce": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
     "dmt_rows_reduce": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
     "dmt_rows_permute": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
@@ -125,6 +126,7 @@ _SIGS = {
     "dmt_adam_catchup_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_rebase": [c_vp, c_vp, c_i64, c_vp],
+    "dmt_rows_gather": [C.POINTER(TableMap), c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_cast_transpose_bf16_batched": [c_i32, c_vp, c_i32, c_vp],

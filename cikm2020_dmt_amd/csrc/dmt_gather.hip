@@ -15,6 +15,8 @@ constexpr int MAX_GF = 8;        // features per group
 struct GFeat {
   const float* table;
   int rows, dim;
+  int stride;              // elements between consecutive rows of `table` (dim for a real table, wider for a row cache)
+  const int32_t* idx_seq;  // optional separate ids of the sequence path (row id - 1, 0 = zero row); null: same as idx
   const int32_t* idx;
   const float* wts;
   const int32_t* lens;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
   const int nf = g.nfeat;
   const int Tmax = g.Tmax;
   int* s_idx = reinterpret_cast<int*>(smem_raw);                       // [nf][Tmax]
-  float* s_w = reinterpret_cast<float*>(s_idx + nf * Tmax);            // [nf][Tmax]
+  int* s_idq = s_idx + nf * Tmax;                                      // [nf][Tmax] ids of the sequence path
+  float* s_w = reinterpret_cast<float*>(s_idq + nf * Tmax);            // [nf][Tmax]
   float* s_wsum = s_w + nf * Tmax;                                     // [MAX_GF]
   int* s_colfeat = reinterpret_cast<int*>(s_wsum + MAX_GF);            // [d_model / VEC]
   int* s_chunkfeat = s_colfeat + (g.d_model / VEC + 1);                // [npc]
@@ -92,14 +95,20 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
     const GFeat& F = g.f[f];
     int len = F.lens ? F.lens[b] : F.T;
     len = len < F.T ? len : F.T;
-    int id = 0;
+    int id = 0, idq = 0;
     float w = 0.f;
     if (t < len) {
       id = F.idx[(long long)b * F.T + t];
       id = id < 0 ? 0 : (id >= F.rows ? F.rows - 1 : id);
+      idq = id;
+      if (F.idx_seq) {
+        idq = F.idx_seq[(long long)b * F.T + t];
+        idq = idq < 0 ? 0 : (idq > F.rows ? F.rows : idq);
+      }
       w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
     }
     s_idx[i] = id;
+    s_idq[i] = idq;
     s_w[i] = w;
   }
   // ---- column -> feature maps
@@ -146,10 +155,10 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
         const int f = s_colfeat[c];
         const GFeat& F = g.f[f];
         const int col = c * VEC;
-        const int id = (t < Tmax) ? s_idx[f * Tmax + t] : 0;
+        const int id = (t < Tmax) ? s_idq[f * Tmax + t] : 0;
         tt[u] = t; cl[u] = col;
         keep[u] = (id > 0) ? g.scale : 0.f;
-        ld_row<VEC>(F.table + (long long)(id > 0 ? id - 1 : 0) * F.dim + (col - F.seq_off), v[u]);
+        ld_row<VEC>(F.table + (long long)(id > 0 ? id - 1 : 0) * F.stride + (col - F.seq_off), v[u]);
         ld_row<VEC>(posp + (g.pos ? (long long)t * g.d_model + col : 0ll), p[u]);   // (no positions: a dummy in-bounds read)
       }
 #pragma unroll
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
             const int t = t0 + u * R;
             const int tc = t < Tf ? t : Tf - 1;
             w[u] = t < Tf ? s_w[f * Tmax + tc] : 0.f;
-            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + tc] * F.dim + cc, v[u]);
+            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + tc] * F.stride + cc, v[u]);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
 template <typename OutT>
 int launch_group(const GGroup& g, bool vec4, hipStream_t st) {
   const int VECc = vec4 ? 4 : 1;
-  size_t lds = (size_t)g.nfeat * g.Tmax * 8 + MAX_GF * 4 + (g.d_model / VECc + 1) * 4 + (size_t)(g.npc + 1) * 8 +
+  size_t lds = (size_t)g.nfeat * g.Tmax * 12 + MAX_GF * 4 + (g.d_model / VECc + 1) * 4 + (size_t)(g.npc + 1) * 8 +
                (size_t)GT * VECc * 4 + 64;
   dim3 grid(g.B), block(GT);
   if (vec4)
@@ -274,6 +283,31 @@ __global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_des
   }
   keys[e] = key;
   vals[e] = (uint32_t)e;
+}
+
+// Row-cache slots of every entry (row-sharded tables): sorted entry j (row keys_s[j], entry vals_s[j], distinct-row number seg[j])
+// reads cache row pos[seg[j]] (pos = where the owner exchange put that distinct row; null: seg[j] itself).  Written in the form the
+// gather kernel consumes: pooled entries -> the slot (0 for padding: any valid row, its weight is 0), sequence entries -> slot + 1
+// (0 = the zero row of [0;E]).
+__global__ __launch_bounds__(256) void entry_slots_kernel(const dmt_embgrad_desc d, const uint32_t* __restrict__ keys_s,
+                                                          const uint32_t* __restrict__ vals_s, const int* __restrict__ seg,
+                                                          const int* __restrict__ pos, long long n, int* __restrict__ slots) {
+  __shared__ int s_base[DMT_MAX_FEATURES + 1];
+  if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
+  __syncthreads();
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const long long e = vals_s[j];
+  int f = 0;
+  while (f + 1 < d.n_features && e >= s_base[f + 1]) ++f;
+  const dmt_gather_feature& F = d.feat[f];
+  const int kind = (F.pooled_off >= 0) ? ((e - s_base[f]) >= (long long)d.B * F.T ? 1 : 0) : 1;
+  int out = 0;
+  if (keys_s[j] < (uint32_t)d.total_rows) {
+    const int u = seg[j];
+    out = (pos ? pos[u] : u) + kind;
+  }
+  slots[e] = out;
 }
 
 __global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t* __restrict__ k, long long n, int* __restrict__ flag) {
@@ -548,6 +582,10 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
       DMT_CHECK_ARG(F.table && F.idx && F.T > 0 && F.dim > 0 && F.rows > 0, "dmt_gather_fwd: feature %d incomplete", i);
       GFeat& o = g.f[g.nfeat++];
       o.table = F.table; o.rows = F.rows; o.dim = F.dim; o.idx = F.idx; o.wts = F.wts; o.lens = F.lens; o.T = F.T;
+      o.stride = F.row_stride > 0 ? F.row_stride : F.dim;
+      o.idx_seq = F.idx_seq;
+      DMT_CHECK_ARG(o.stride >= F.dim, "dmt_gather_fwd: feature %d: row_stride %d < dim %d", i, o.stride, F.dim);
+      if (o.stride % 4 != 0) vec4 = false;
       o.pooled_off = F.pooled_off;
       o.seq_off = (F.seq_id >= 0) ? F.seq_off : -1;
       o.inv_wsum = F.inv_wsum;
@@ -707,5 +745,15 @@ extern "C" int dmt_rows_reduce_bf16(const uint32_t* sorted_keys, const uint32_t*
   hipLaunchKernelGGL((rows_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
                      (long long)n, invalid_key, reinterpret_cast<const bf16_t*>(in_rows_bf16), out_rows, max_dim);
   DMT_CHECK_LAUNCH("dmt_rows_reduce_bf16");
+  return DMT_OK;
+}
+
+extern "C" int dmt_entry_slots(const dmt_embgrad_desc* d, const uint32_t* keys_sorted, const uint32_t* vals_sorted, const int32_t* seg,
+                               const int32_t* slot_of_row, int64_t n, int32_t* slots, void* stream) {
+  DMT_CHECK_ARG(d && keys_sorted && vals_sorted && seg && slots, "dmt_entry_slots: null argument");
+  if (n == 0) return DMT_OK;
+  hipLaunchKernelGGL(entry_slots_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, *d, keys_sorted, vals_sorted, seg,
+                     slot_of_row, (long long)n, slots);
+  DMT_CHECK_LAUNCH("dmt_entry_slots");
   return DMT_OK;
 }

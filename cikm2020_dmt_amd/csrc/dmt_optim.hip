@@ -89,6 +89,14 @@ __device__ __forceinline__ void catch_up(float& pv, float& mv, float& vv, int fr
   }
 }
 
+// Row-sharded tables (tm.shard_w > 1): this rank holds the rows with global id % shard_w == shard_r, densely: local row
+// (row - row_base[t]) / shard_w of table t (every row_base is a multiple of shard_w), last_step index row / shard_w.
+__device__ __forceinline__ int tm_sw(const dmt_table_map& tm) { return tm.shard_w > 1 ? tm.shard_w : 1; }
+__device__ __forceinline__ long long tm_elem(const dmt_table_map& tm, int t, long long row, int dim) {
+  return tm.elem_off[t] + ((row - tm.row_base[t]) / tm_sw(tm)) * dim;
+}
+__device__ __forceinline__ bool tm_owned(const dmt_table_map& tm, long long row) { return tm.shard_w <= 1 || (row % tm.shard_w) == tm.shard_r; }
+
 __device__ __forceinline__ int find_table(const dmt_table_map& tm, int row) {
   int t = 0;
   while (t + 1 < tm.n_tables && row >= tm.row_base[t + 1]) ++t;
@@ -130,8 +138,10 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
     if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables]) continue;   // padding slot of a gathered (rank-major) row list
     const int t = find_table(tm, row);
     const int dim = tm.dim[t];
-    const int last = last_step[row];
-    const long long base = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim;
+    if (!tm_owned(tm, row)) continue;
+    const int lsi = row / tm_sw(tm);
+    const int last = last_step[lsi];
+    const long long base = tm_elem(tm, t, row, dim);
     const GT* gr = grad_rows + u * max_dim;
     if ((dim & 3) == 0 && (max_dim & 3) == 0) {
       for (int j = c * 4; j < dim; j += 64) {
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
         p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
       }
     }
-    if (c == 0) last_step[row] = step;   // only this group touches the row (rows are distinct): the read above is long done
+    if (c == 0) last_step[lsi] = step;   // only this group touches the row (rows are distinct): the read above is long done
   }
 }
 
@@ -173,11 +183,13 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
   const long long groups = (long long)gridDim.x * 16;
   for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
     const int row = (int)uniq[u];
-    const int last = last_step[row];
+    if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables] || !tm_owned(tm, row)) continue;
+    const int lsi = row / tm_sw(tm);
+    const int last = last_step[lsi];
     if (last >= step) continue;
     const int t = find_table(tm, row);
     const int dim = tm.dim[t];
-    const long long base = tm.elem_off[t] + (long long)(row - tm.row_base[t]) * dim;
+    const long long base = tm_elem(tm, t, row, dim);
     if ((dim & 3) == 0) {
       for (int j = c * 4; j < dim; j += 64) {
         float4 pv = ld4(p + base + j), mv = ld4(m + base + j), vv = ld4(v + base + j);
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
         }
       }
     }
-    if (c == 0) last_step[row] = step;
+    if (c == 0) last_step[lsi] = step;
   }
 }
 
@@ -208,16 +220,18 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm,
                                                          const float* __restrict__ state, const float* __restrict__ lr_hist,
                                                          float b1, float b2, float eps) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long lsi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // local row index (= the global row when not sharded)
+  const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
   if (row >= tm.row_base[tm.n_tables]) return;
+  // (a sharded layout pads every table to a multiple of shard_w rows; the padding rows have storage -- zeros -- and are skipped below)
   const int step = reinterpret_cast<const int*>(state)[3];
-  const int last = last_step[row];
+  const int last = last_step[lsi];
   if (last >= step) return;
   const int t = find_table(tm, (int)row);
   const int dim = tm.dim[t];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   for (int j = lane; j < dim; j += 64) {
-    const long long off = tm.elem_off[t] + (row - tm.row_base[t]) * dim + j;
+    const long long off = tm_elem(tm, t, row, dim) + j;
     float pv = p[off], mv = m[off], vv = v[off];
     if (mv != 0.f || vv != 0.f) {
       catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm,
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) last_step[row] = step;
+  if (lane == 0) last_step[lsi] = step;
 }
 
 }  // namespace
@@ -308,10 +322,40 @@ extern "C" int dmt_adam_rebase(float* state, int32_t* last_step, int64_t rows, v
 extern "C" int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                                    const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
   DMT_CHECK_ARG(tm && p && m && v && last_step && state && lr_hist, "dmt_adam_flush_rows: null argument");
-  const long long rows = tm->row_base[tm->n_tables];
+  const long long rows = cdiv64(tm->row_base[tm->n_tables], tm->shard_w > 1 ? tm->shard_w : 1);
   const unsigned nb = (unsigned)cdiv64(rows, 4);
   hipLaunchKernelGGL(adam_flush_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, state, lr_hist, beta1,
                      beta2, eps);
   DMT_CHECK_LAUNCH("dmt_adam_flush_rows");
+  return DMT_OK;
+}
+
+// ---- row-sharded tables: the owner's side of the forward exchange (BASELINE configs[3])
+namespace {
+// out[u, 0:dim] = p[row keys[u]] (fp32, row stride max_dim; columns >= dim are zeroed): the rows this rank owns, in request order
+__global__ __launch_bounds__(256) void rows_gather_kernel(const dmt_table_map tm, const float* __restrict__ p, const uint32_t* __restrict__ keys,
+                                                          long long n, float* __restrict__ out, int max_dim) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+  const long long groups = (long long)gridDim.x * 16;
+  for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
+    const uint32_t key = keys[u];
+    float* o = out + u * max_dim;
+    const bool ok = key < (uint32_t)tm.row_base[tm.n_tables] && tm_owned(tm, key);
+    const int t = ok ? find_table(tm, (int)key) : 0;
+    const int dim = ok ? tm.dim[t] : 0;
+    const float* src = p + (ok ? tm_elem(tm, t, key, dim) : 0);
+    for (int j = c; j < max_dim; j += 16) o[j] = j < dim ? src[j] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int dmt_rows_gather(const dmt_table_map* tm, const float* p, const uint32_t* keys, int64_t n, float* out, int32_t max_dim,
+                               void* stream) {
+  DMT_CHECK_ARG(tm && p && (n == 0 || (keys && out)) && max_dim > 0, "dmt_rows_gather: bad argument");
+  if (n == 0) return DMT_OK;
+  long long nb = cdiv64(n, 16);
+  if (nb > SPARSE_GRID) nb = SPARSE_GRID;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, *tm, p, keys, (long long)n, out, max_dim);
+  DMT_CHECK_LAUNCH("dmt_rows_gather");
   return DMT_OK;
 }

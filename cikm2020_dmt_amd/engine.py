@@ -172,12 +172,29 @@ class GatherFn(torch.autograd.Function):
         desc = L.GatherDesc()
         desc.B, desc.n_features = B, len(plan.items)
         inv = torch.empty((len(plan.items), B), dtype=F32, device=dev)
+        cache = engine.row_cache(batch) if store.shard is not None else None
         for i, it in enumerate(plan.items):
             col = batch.feats[it["feature"]]
             f = desc.feat[i]
-            f.table = store.table[it["table"]].data_ptr()
-            f.rows, f.dim = it["rows"], it["dim"]
-            f.idx = col.idx.data_ptr()
+            if cache is None:
+                f.table = store.table[it["table"]].data_ptr()
+                f.rows, f.dim = it["rows"], it["dim"]
+                f.idx = col.idx.data_ptr()
+            else:
+                # row-sharded tables: the rows this batch reads were fetched from their owners into `cache` (Trainer.sync_rows);
+                # ids become cache slots (engine.fetch_rows)
+                rows_c, slots, ebase = cache
+                f.table = rows_c.data_ptr()
+                f.rows, f.dim, f.row_stride = rows_c.shape[0], it["dim"], rows_c.shape[1]
+                per = batch.B * col.T
+                e0 = ebase[i]
+                has_pool, has_seq = it["pooled_off"] >= 0, it["seq_id"] >= 0
+                f.idx = slots[e0: e0 + per].data_ptr()
+                if has_seq:
+                    es = e0 + (per if has_pool else 0)
+                    f.idx_seq = slots[es: es + per].data_ptr()
+                    if not has_pool:
+                        f.idx = f.idx_seq
             f.wts = col.wts.data_ptr() if col.wts is not None else None
             f.lens = col.lens.data_ptr()
             f.T = col.T
@@ -317,6 +334,7 @@ class DMTEngine:
     def gather_raw(self, batch: DeviceBatch):
         """generate_data's outputs: unscaled seq_emb / tar_emb ([0;E] lookups, no positions); no gradient path to the
         tables (API-parity helper; the training path uses gather())."""
+        self._replicated_only("gather_raw")
         spec, plan, store = self.spec, self.plan, self.store
         dev, cdt = store.device, store.compute_dtype
         B, d = batch.B, spec["d_model"]
@@ -347,6 +365,7 @@ class DMTEngine:
         """Inference-only gather WITHOUT the sequence rows: target embedding tar [B, d] and the MMoE input buffer zbuf (dense
         features, pooled id embeddings, bias-tower embeddings).  Used by the serving path, where the behaviour sequences of the
         one user are encoded once (serving.CandidateScorer) and only these per-candidate pieces are needed for every row."""
+        self._replicated_only("gather_pooled")
         spec, plan, store = self.spec, self.plan, self.store
         dev, cdt = store.device, store.compute_dtype
         B, d = batch.B, spec["d_model"]
@@ -572,6 +591,48 @@ class DMTEngine:
         prep = dict(desc=desc, n=n, keys_s=keys_s, vals_s=vals_s, seg=seg.clone(), uniq=uniq[:cap].clone(), n_uniq=n_uniq.clone(), cap=cap)
         batch._prep = prep
         return prep
+
+    # ---- row-sharded tables: fetch the rows a batch reads from their owners (BASELINE configs[3])
+    def fetch_rows(self, batch, opt=None):
+        """Index exchange + row return.  The batch's distinct global rows (engine.prepare) go to their owners (row % W) by
+        all_to_all; every owner first replays the pending lazy-Adam updates of the requested rows (opt.catch_up), gathers them
+        (dmt_rows_gather) and sends them back; the entries' ids are rewritten into slots of the returned row cache
+        (dmt_entry_slots).  The cache lives in batch._prep["cache"] until the next fetch."""
+        from . import parallel
+        prep = self.prepare(batch)
+        store = self.store
+        n = int(prep["n_uniq"].item())
+        uniq = prep["uniq"]
+        perm, recv_k, send_splits, recv_splits = parallel.request_rows(uniq, n)
+        R = recv_k.numel()
+        if opt is not None and opt.global_step > 0 and R > 0:
+            opt.catch_up(recv_k, torch.tensor([R], dtype=torch.int32, device=recv_k.device), R)
+        tm = store.fill_table_map(L.TableMap())
+        D = self.plan.max_dim
+        rows_out = torch.empty((max(R, 1), D), dtype=F32, device=store.device)
+        L.call("dmt_rows_gather", C.byref(tm), ops.p(store.tab_p), ops.p(recv_k), R, ops.p(rows_out), D, ops.stream_ptr())
+        cache = parallel.return_rows(rows_out[:R], n, send_splits, recv_splits)
+        if cache.shape[0] == 0:
+            cache = torch.zeros((1, D), dtype=F32, device=store.device)
+        # slot of distinct row u = its position in the owner-grouped order
+        pos = torch.empty((max(n, 1),), dtype=torch.int32, device=store.device)
+        pos[perm] = torch.arange(n, dtype=torch.int32, device=store.device)
+        slots = torch.empty((prep["n"],), dtype=torch.int32, device=store.device)
+        L.call("dmt_entry_slots", C.byref(prep["desc"]), ops.p(prep["keys_s"]), ops.p(prep["vals_s"]), ops.p(prep["seg"]), ops.p(pos), prep["n"],
+               ops.p(slots), ops.stream_ptr())
+        ebase = [int(prep["desc"].entry_base[i]) for i in range(len(self.plan.items))]
+        prep["cache"] = (cache.contiguous(), slots, ebase)
+        return prep["cache"]
+
+    def _replicated_only(self, what):
+        if self.store.shard is not None and self.store.shard[1] > 1:
+            raise RuntimeError("%s reads whole embedding tables: not available with row-sharded tables (serve from a replicated store)" % what)
+
+    def row_cache(self, batch):
+        prep = getattr(batch, "_prep", None)
+        if prep is None or "cache" not in prep:
+            raise RuntimeError("row-sharded tables: call Trainer.sync_rows(batch) (engine.fetch_rows) before the forward pass")
+        return prep["cache"]
 
     def _input_dropout(self, n_seq):
         """(per-sequence site seeds, keep probability) of the block-input dropout; keep = 0.0 when dropout is off."""

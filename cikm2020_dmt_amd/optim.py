@@ -32,13 +32,7 @@ class TFAdam:
         self.max_steps = max_steps
         self.global_step = 0
         self._step_base = 0          # global_step at which the device-side step counter / lr history last restarted
-        names, row_base, dims, offs = store.table_map()
-        tm = L.TableMap()
-        tm.n_tables = len(names)
-        for i in range(len(names)):
-            tm.row_base[i], tm.dim[i], tm.elem_off[i] = row_base[i], dims[i], offs[i]
-        tm.row_base[len(names)] = store.total_rows
-        self.tm = tm
+        self.tm = store.fill_table_map(L.TableMap())
 
     def current_lr(self) -> float:
         # tf.train.piecewise_constant: values[i] while step <= boundaries[i]
@@ -68,6 +62,8 @@ class TFAdam:
     def apply_sparse(self, sparse, grad_scale: float = 1.0):
         s = self.store
         uniq, n_uniq, grad_rows, cap = sparse
+        if int(cap) == 0:
+            return
         if grad_rows.dtype == torch.bfloat16:      # reduced rows straight off the data-parallel wire
             L.call("dmt_adam_sparse_rows_bf16", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
                    ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.shape[1]), float(grad_scale),
@@ -109,7 +105,7 @@ class TFAdam:
         """Restart the per-step lr history without changing any value: replay every pending zero-gradient row update (flush), then
         mark all rows as up to date at local step 0."""
         self.flush_tables()
-        L.call("dmt_adam_rebase", ops.p(self.state), ops.p(self.store.last_step), self.store.total_rows, ops.stream_ptr())
+        L.call("dmt_adam_rebase", ops.p(self.state), ops.p(self.store.last_step), self.store.last_step.numel(), ops.stream_ptr())
         self.lr_hist.zero_()
         self._step_base = self.global_step
 

@@ -131,6 +131,41 @@ def exchange_to_owners(keys: torch.Tensor, rows: torch.Tensor, n: int, transport
     return recv_k, recv_r
 
 
+def request_rows(keys: torch.Tensor, n: int):
+    """Row-sharded tables, forward exchange, first half (the "all-to-all index exchange" of BASELINE configs[3]): this rank's n distinct
+    global row ids travel to their owners (id % W).  Returns (perm, recv_keys, send_splits, recv_splits): perm[i] = index (into keys)
+    of the i-th id in owner-grouped order -- the order in which the rows will come back --, recv_keys = the ids the other ranks want
+    from this one, concatenated in rank order."""
+    rank, W = world()
+    dev = keys.device
+    k = keys[:n]
+    if W == 1:
+        perm = torch.arange(n, device=dev)
+        return perm, k, [n], [n]
+    owner = owner_of(k, W)
+    counts = torch.bincount(owner.long(), minlength=W)
+    rows_mat = [torch.zeros_like(counts) for _ in range(W)]
+    dist.all_gather(rows_mat, counts)
+    M = torch.stack(rows_mat).cpu()                      # M[s, d] = ids rank s asks of rank d  (one host sync)
+    send_splits, recv_splits = M[rank].tolist(), M[:, rank].tolist()
+    _so, perm = torch.sort(owner, stable=True)
+    send_k = k.index_select(0, perm).contiguous()
+    recv_k = torch.empty((int(sum(recv_splits)),), dtype=keys.dtype, device=dev)
+    _a2a(recv_k, send_k, recv_splits, send_splits)
+    return perm, recv_k, send_splits, recv_splits
+
+
+def return_rows(rows: torch.Tensor, n_back: int, send_splits, recv_splits):
+    """Second half: the owner's rows [R, D] (in the order of request_rows' recv_keys) go back to the ranks that asked; returns
+    [n_back, D] in this rank's owner-grouped request order."""
+    rank, W = world()
+    if W == 1:
+        return rows
+    out = torch.empty((n_back, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    _a2a(out, rows.contiguous(), send_splits, recv_splits)   # what was received is now sent, and vice versa
+    return out
+
+
 def allgather_shards(keys: torch.Tensor, rows: torch.Tensor, m: int, invalid_key: int, transport_dtype=None):
     """Second half: every owner's reduced shard (m distinct keys, rows [>= m, D]) goes to every rank.  Shards are padded to the
     largest one (interleaved ownership keeps them within a few per cent of each other); padding slots carry `invalid_key`,

@@ -22,10 +22,17 @@ from .variables import VariableStore
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
-                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None):
+                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated"):
+        """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
+        same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
+        back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
         self.spec = spec
         self.device = torch.device(device)
-        self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init)
+        if table_layout not in ("replicated", "sharded"):
+            raise ValueError("table_layout must be 'replicated' or 'sharded'")
+        self.table_layout = table_layout
+        shard = parallel.world() if table_layout == "sharded" else None
+        self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init, table_shard=shard)
         self.engine = DMTEngine(spec, self.store)
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
@@ -47,6 +54,9 @@ class Trainer:
     def sync_rows(self, batch: DeviceBatch):
         """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them."""
         prep = self.engine.prepare(batch)
+        if self.table_layout == "sharded":
+            self.engine.fetch_rows(batch, self.opt)      # owners replay the lazy updates of what they send
+            return prep
         if self.opt.global_step > 0:
             self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
         return prep
@@ -81,11 +91,17 @@ class Trainer:
         reduce rows again with the same stable sort + segment reduce."""
         rank, W = parallel.world()
         if W == 1 and not (self.force_dp and parallel.dist.is_initialized()):
-            return sparse
+            return sparse                      # (one rank owns every row: sharded == replicated)
         uniq, n_uniq, grad_rows, _cap = sparse
         n = int(n_uniq.item())
         eng, st = self.engine, self.store
         wire = torch.bfloat16 if st.compute_dtype == torch.bfloat16 else None    # bf16 mode: gradient rows travel as bf16
+        if self.table_layout == "sharded":
+            # every (row, gradient row) pair goes to the row's owner, which reduces them in rank order and is the only one to apply Adam
+            rk, rr = parallel.exchange_to_owners(uniq, grad_rows, n, transport_dtype=wire, group_fn=self._group_by_owner)
+            if rk.numel() > 0:
+                return self.merge_gathered(rk, rr)
+            return (uniq[:0], torch.zeros(1, dtype=torch.int32, device=uniq.device), grad_rows[:0], 0)
         if self.dp_exchange == "allgather":
             all_k, all_r, cap = parallel.allgather_sparse(uniq, grad_rows, n, st.total_rows, transport_dtype=wire)
             return self.merge_gathered(all_k, all_r)

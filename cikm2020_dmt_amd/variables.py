@@ -58,13 +58,20 @@ def _init_array(init: str, shape, rng) -> np.ndarray:
 
 
 class VariableStore:
-    def __init__(self, spec: dict, device, compute_dtype=torch.float32, seed: int = 0, init: bool = True):
+    def __init__(self, spec: dict, device, compute_dtype=torch.float32, seed: int = 0, init: bool = True, table_shard=None):
+        """table_shard = (rank, world): ROW-SHARDED embedding tables (BASELINE configs[3]).  This process then holds, of every table,
+        only the rows r with r % world == rank (p, Adam m / v and last_step alike), densely as local row r // world; every table's
+        global row base is a multiple of `world`, so the owner of a GLOBAL row id g is g % world as well.  None: replicated tables."""
         self.spec = spec
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
+        self.shard = (int(table_shard[0]), int(table_shard[1])) if table_shard is not None else None
+        if self.shard is not None and not (0 <= self.shard[0] < self.shard[1]):
+            raise ValueError("table_shard = (rank, world) with 0 <= rank < world")
         self.leaves: Dict[str, LeafInfo] = {}
         self.views: Dict[str, ViewInfo] = {}
         self.tables: Dict[str, LeafInfo] = {}       # tf_name -> info (offset in table arena)
+        self.local_rows: Dict[str, int] = {}        # tf_name -> rows held by this process (== rows when not sharded)
         self.table_rows: Dict[str, Tuple[int, int]] = {}   # tf_name -> (row_base, rows)
         self._dense_size = 0
         self._table_size = 0
@@ -90,11 +97,14 @@ class VariableStore:
     def _table(self, tf_name, rows, dim):
         if tf_name in self.tables:
             return
+        W = self.shard[1] if self.shard is not None else 1
+        padded = (rows + W - 1) // W * W              # (sharded: every table spans a multiple of W global row ids)
         off = (self._table_size + 63) // 64 * 64
         self.tables[tf_name] = LeafInfo(tf_name, (rows, dim), off)
-        self._table_size = off + rows * dim
+        self.local_rows[tf_name] = padded // W
+        self._table_size = off + (padded // W) * dim
         self.table_rows[tf_name] = (self._total_rows, rows)
-        self._total_rows += rows
+        self._total_rows += padded
 
     def _declare_all(self):
         sp = self.spec
@@ -176,8 +186,9 @@ class VariableStore:
         self.tab_p = torch.zeros(TS, dtype=torch.float32, device=dev)
         self.tab_m = torch.zeros(TS, dtype=torch.float32, device=dev)
         self.tab_v = torch.zeros(TS, dtype=torch.float32, device=dev)
-        self.last_step = torch.zeros(self._total_rows, dtype=torch.int32, device=dev)
-        self.total_rows = self._total_rows
+        W = self.shard[1] if self.shard is not None else 1
+        self.last_step = torch.zeros(self._total_rows // W, dtype=torch.int32, device=dev)
+        self.total_rows = self._total_rows            # size of the GLOBAL row-id space (also the "invalid key")
         self.leaf: Dict[str, torch.Tensor] = {}
         self.weight: Dict[str, Weight] = {}
         bf = self.compute_dtype == torch.bfloat16
@@ -209,7 +220,8 @@ class VariableStore:
                 self._w2d.append(name)
         self.table: Dict[str, torch.Tensor] = {}
         for name, info in self.tables.items():
-            self.table[name] = self.tab_p[info.offset: info.offset + info.numel].view(info.shape)
+            n_loc = self.local_rows[name] * info.shape[1]
+            self.table[name] = self.tab_p[info.offset: info.offset + n_loc].view(self.local_rows[name], info.shape[1])
         # weight images of the fused feed-forward kernels (dmt_chain2), one forward + one backward image per ff scope
         self.chain: Dict[str, dict] = {}
         if bf:
@@ -237,9 +249,20 @@ class VariableStore:
         for tf_name in sorted(self.views):
             v = self.views[tf_name]
             state[tf_name] = _init_array(v.init, v.shape, rng)
+        big = []
         for tf_name in sorted(self.tables):
-            state[tf_name] = _init_array("xavier", self.tables[tf_name].shape, rng)
+            shape = self.tables[tf_name].shape
+            if shape[0] * shape[1] > (1 << 30):
+                big.append(tf_name)                   # (e.g. the 100 M-row SKU table of configs[3]: initialised on the device, below)
+            else:
+                state[tf_name] = _init_array("xavier", shape, rng)
         self.load_state(state)
+        for i, tf_name in enumerate(big):
+            rows, dim = self.tables[tf_name].shape
+            lim = math.sqrt(6.0 / (rows + dim))
+            g = torch.Generator(device=self.device)
+            g.manual_seed(seed * 1000003 + 17 * i + (self.shard[0] if self.shard is not None else 0))
+            self.table[tf_name].uniform_(-lim, lim, generator=g)
 
     def load_state(self, state: Dict[str, np.ndarray]):
         """state: TF variable name (Appendix B, no 'DnnModel/' prefix) -> array."""
@@ -250,7 +273,13 @@ class VariableStore:
                     v = self.views[tf_name]
                     self.leaf[v.leaf][v.index].copy_(a.to(self.device))
                 elif tf_name in self.tables:
-                    self.table[tf_name].copy_(a.to(self.device))
+                    if self.shard is not None:
+                        r, W = self.shard
+                        loc = a[r::W]
+                        self.table[tf_name].zero_()
+                        self.table[tf_name][: loc.shape[0]].copy_(loc.to(self.device))
+                    else:
+                        self.table[tf_name].copy_(a.to(self.device))
                 else:
                     raise KeyError("unknown variable %s" % tf_name)
         self.refresh_shadows()
@@ -260,8 +289,28 @@ class VariableStore:
         for tf_name, v in self.views.items():
             out[tf_name] = self.leaf[v.leaf].detach()[v.index].float().cpu().numpy().copy()
         for tf_name in self.tables:
-            out[tf_name] = self.table[tf_name].float().cpu().numpy().copy()
+            out[tf_name] = self.full_table(tf_name).float().cpu().numpy().copy()
         return out
+
+    def full_table(self, tf_name) -> torch.Tensor:
+        """The whole [rows, dim] table.  Row-sharded layout: gathered from all ranks (a collective: every rank must call it)."""
+        t = self.table[tf_name]
+        if self.shard is None:
+            return t
+        import torch.distributed as dist
+        r, W = self.shard
+        rows, dim = self.tables[tf_name].shape
+        if W == 1 or not (dist.is_available() and dist.is_initialized()):
+            return t[:rows]
+        parts = [torch.empty_like(t) for _ in range(W)]
+        if dist.get_backend() != "nccl" and t.is_cuda:
+            cp = [torch.empty(t.shape, dtype=t.dtype) for _ in range(W)]
+            dist.all_gather(cp, t.cpu())
+            parts = [c.to(t.device) for c in cp]
+        else:
+            dist.all_gather(parts, t.contiguous())
+        full = torch.stack(parts, dim=1).reshape(-1, dim)      # local row l of rank r is global row l * W + r
+        return full[:rows]
 
     def grad_dict(self) -> Dict[str, np.ndarray]:
         out = {}
@@ -292,3 +341,13 @@ class VariableStore:
         """(names, row_base[], dim[], elem_off[]) in global-row order for the sparse optimizer."""
         names = sorted(self.tables, key=lambda n: self.table_rows[n][0])
         return names, [self.table_rows[n][0] for n in names], [self.tables[n].shape[1] for n in names], [self.tables[n].offset for n in names]
+
+    def fill_table_map(self, tm):
+        """Fill a _lib.TableMap (row bases of the GLOBAL id space, element offsets into THIS process's arenas, shard)."""
+        names, row_base, dims, offs = self.table_map()
+        tm.n_tables = len(names)
+        for i in range(len(names)):
+            tm.row_base[i], tm.dim[i], tm.elem_off[i] = row_base[i], dims[i], offs[i]
+        tm.row_base[len(names)] = self.total_rows
+        tm.shard_r, tm.shard_w = self.shard if self.shard is not None else (0, 0)
+        return tm

@@ -65,6 +65,11 @@ typedef struct {
   int32_t seq_off;      /* column inside the d_model-wide sequence / target row                    */
   int32_t group;        /* features with equal group are processed by the same workgroup           */
   float* inv_wsum;      /* [B] out: 1/sum(w) per example (0 when empty), needed by backward; or NULL */
+  /* Row-cache form (row-sharded tables, BASELINE configs[3]): `table` is then the step's cache of the rows this batch reads
+   * ([n_distinct, row_stride] fp32, filled by the all-to-all exchange), idx holds cache slots for the pooled path and idx_seq
+   * (slot + 1, 0 = the zero row of [0;E]) for the sequence path.  Plain tables: row_stride = 0 (= dim), idx_seq = NULL.       */
+  int32_t row_stride;
+  const int32_t* idx_seq;
 } dmt_gather_feature;
 
 #define DMT_SEQ_TARGET 100
@@ -144,6 +149,11 @@ int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_k
 
 /* grad_rows[seg, 0:dim_of(table)] += contribution of every entry (row stride = max_dim, fp32).
  * grad_rows must be zeroed by the caller.                                                            */
+/* Row-sharded tables: the row-cache slot of every entry after dmt_sort_pairs + dmt_segment_heads (keys_sorted, vals_sorted, seg):
+ * slots[entry] = slot_of_row[seg] (or seg when slot_of_row is NULL) for a pooled entry, + 1 for a sequence entry (0 = zero row / padding).
+ * The slices slots[entry_base[f] ...] are the idx / idx_seq columns of dmt_gather_feature in its row-cache form.                  */
+int dmt_entry_slots(const dmt_embgrad_desc* d, const uint32_t* keys_sorted, const uint32_t* vals_sorted, const int32_t* seg,
+                    const int32_t* slot_of_row, int64_t n, int32_t* slots, void* stream);
 int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
                        const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream);
 
@@ -301,6 +311,10 @@ typedef struct {
   int32_t row_base[DMT_MAX_TABLES + 1];   /* ascending; row_base[n_tables] = total_rows              */
   int32_t dim[DMT_MAX_TABLES];
   int64_t elem_off[DMT_MAX_TABLES];       /* offset of the table inside p / m / v                    */
+  /* Row-sharded tables (BASELINE configs[3]): shard_w > 1 -> this rank's p / m / v / last_step hold only the rows with
+   * global id % shard_w == shard_r, densely (local row (row - row_base[t]) / shard_w; every row_base is a multiple of shard_w;
+   * last_step index row / shard_w).  Keys this rank does not own are skipped.  0 / 1: replicated layout.                      */
+  int32_t shard_w, shard_r;
 } dmt_table_map;
 int dmt_adam_sparse_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                          const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* grad_rows,
@@ -323,6 +337,11 @@ int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, i
 /* After dmt_adam_flush_rows: restart the device-side step counter that indexes lr_hist (state[3] = 0, last_step[:] = 0), so a run
  * longer than the history's capacity -- or one resumed from model.ckpt-<large N> -- keeps going.  Values are untouched. */
 int dmt_adam_rebase(float* state, int32_t* last_step, int64_t rows, void* stream);
+/* Row-sharded tables, owner side of the forward exchange: out[u, :] = p[row keys[u]] for u < n (fp32, row stride max_dim, columns
+ * past the table's dim zeroed; keys this rank does not own give zero rows).  The all-to-all that answers the index exchange of
+ * BASELINE configs[3] sends these rows back to the ranks that asked for them (replaces the /cpu:0 embedding_lookup of base.py:81-91
+ * for a table no single device holds).                                                                                          */
+int dmt_rows_gather(const dmt_table_map* tm, const float* p, const uint32_t* keys, int64_t n, float* out, int32_t max_dim, void* stream);
 
 /* fp32 -> bf16 shadow copies of 2-D weights, plain and transposed: dst[n*ld_t + k] = src[k*ld + n].    */
 int dmt_cast_bf16(int64_t n, const float* src, void* dst, void* stream);

@@ -109,5 +109,7 @@ def test_transformer_util_functions_under_scopes(cuda):
     assert np.abs(_np(c) - c_ref).max() < 5e-5
     assert np.abs(_np(f) - O.ff(x, P, blk + "positionwise_feedforward/")).max() < 5e-5
     assert np.abs(_np(n) - O.ln(x, P[blk + "self-attention/ln/gamma"], P[blk + "self-attention/ln/beta"])).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        TU.multihead_attention(xd, xd, xd, ld, ld, num_heads=4, dropout_rate=0.1, training=True, scope="self-attention")
+    # training=True with dropout needs the step seed Inference.inference(is_train=True) sets (tests/test_gpu_boundary.py runs it)
+    with R.variable_scope(pre.rstrip("/")), R.variable_scope("num_blocks_0"):
+        with pytest.raises(RuntimeError, match="dropout_step_seed"):
+            TU.multihead_attention(xd, xd, xd, ld, ld, num_heads=4, dropout_rate=0.1, training=True, scope="self-attention")

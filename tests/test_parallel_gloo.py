@@ -170,3 +170,45 @@ def test_three_rank_owner_reduce_exchange_sums_every_row_once():
             assert np.abs(row - want[int(k)]).max() < 1e-5
         assert np.array_equal(ks, res[0][1]) and np.array_equal(rs, res[0][2])  # identical on every rank (same order too)
     assert sum(t[3] for t in res) == sum(len(_rank_rows(r, total, D)[0]) for r in range(world))   # each pair travelled once
+
+
+def _rows_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(10 + rank)
+    total = 1000
+    table = (np.arange(total, dtype=np.float32)[:, None] * 4 + np.arange(4, dtype=np.float32)[None, :])   # row g = [4g .. 4g+3]
+    mine = table[rank::world]                                      # the shard this rank owns: local row l = global row l*W + rank
+    n = int(rng.integers(0, 60)) if rank else 57                   # ragged request sizes, possibly empty
+    keys = np.sort(rng.choice(total, size=n, replace=False)).astype(np.int32)
+    k_t = torch.tensor(np.concatenate([keys, np.zeros(5, np.int32)]))
+    perm, recv_k, ss, rs = parallel.request_rows(k_t, n)
+    rk = recv_k.numpy()
+    assert (rk % world == rank).all()                              # only ids this rank owns arrive
+    rows = torch.tensor(mine[rk // world].reshape(len(rk), 4))
+    back = parallel.return_rows(rows, n, ss, rs)
+    want = table[keys[perm.numpy()]] if n else np.zeros((0, 4), np.float32)
+    ok = back.shape == (n, 4) and np.array_equal(back.numpy(), want)
+    # owner-grouped order: perm groups by owner, ascending ids inside a group
+    own = keys[perm.numpy()] % world
+    ok = ok and bool((np.diff(own) >= 0).all())
+    q.put((rank, bool(ok), n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_request_and_return_exchange(world):
+    """Row-sharded tables (BASELINE configs[3]): ids to the owners (id % W), rows back, ragged and empty requests."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    assert all(ok for (_r, ok, _n) in res), res
