@@ -166,7 +166,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=%s full, %s ids over 5M/500/12k/190k/230k vocab, TF-Adam (exact lazy rows), train-mode dropout %s"
+                               "per-GPU batch %d, L=%s full, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s"
                                % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",

@@ -108,6 +108,8 @@ _SIGS = {
     "dmt_gemm": [C.POINTER(GemmDesc), c_vp],
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
+    "dmt_attn_long_fwd": [C.POINTER(AttnDesc), c_vp],
+    "dmt_attn_long_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_ln_fwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp],
     "dmt_ln_bwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "dmt_mmoe_mix_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
@@ -146,7 +148,8 @@ _SIGS = {
     "dmt_mhsa_block_fwd": [C.POINTER(MhsaDesc), c_vp],
 }
 
-EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported"])
+EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported",
+                                                 "dmt_attn_long_supported"])
 
 _lib = None
 
@@ -173,6 +176,8 @@ def load():
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
+    lib.dmt_attn_long_supported.restype = c_i32
+    lib.dmt_attn_long_supported.argtypes = [c_i32, c_i32, c_i32, c_i32]
     _lib = lib
     return lib
 

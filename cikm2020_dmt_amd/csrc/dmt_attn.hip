@@ -1579,7 +1579,10 @@ int check_desc(const dmt_attn_desc* d, const char* who) {
   DMT_CHECK_ARG(d->dtype == DMT_F32 || d->dtype == DMT_BF16, "%s: bad dtype", who);
   DMT_CHECK_ARG(d->B > 0 && d->H > 0 && d->dh > 0 && d->Tq > 0 && d->Tk > 0, "%s: bad dims", who);
   DMT_CHECK_ARG(d->Q && d->K && d->V, "%s: null Q/K/V", who);
-  if (d->Tk > 64) { dmt_set_error("%s: Tk=%d > 64 keys per wavefront is not supported yet", who, d->Tk); return DMT_ERR_UNSUPPORTED; }
+  if (d->Tk > 64 || d->Tq > 64) {
+    dmt_set_error("%s: Tq=%d, Tk=%d: sequences over 64 need bf16, dh in 16/32/64/80 and T <= 256 (dmt_attn_long_*)", who, d->Tq, d->Tk);
+    return DMT_ERR_UNSUPPORTED;
+  }
   return DMT_OK;
 }
 
@@ -1611,6 +1614,7 @@ int launch_bwd(const AttnArgs& a, int nw, size_t lds, hipStream_t st) {
 }  // namespace
 
 extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
+  if (d && (d->Tq > 64 || d->Tk > 64) && dmt_attn_long_supported(d->dtype, d->dh, d->Tq, d->Tk)) return dmt_attn_long_fwd(d, stream);
   int rc = check_desc(d, "dmt_attn_fwd");
   if (rc != DMT_OK) return rc;
   DMT_CHECK_ARG(d->out != nullptr, "dmt_attn_fwd: null out");
@@ -1681,6 +1685,7 @@ extern "C" int dmt_attn_fwd(const dmt_attn_desc* d, void* stream) {
 
 extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
   DMT_CHECK_ARG(d != nullptr, "dmt_attn_bwd: null descriptor");
+  if ((d->f.Tq > 64 || d->f.Tk > 64) && dmt_attn_long_supported(d->f.dtype, d->f.dh, d->f.Tq, d->f.Tk)) return dmt_attn_long_bwd(d, stream);
   int rc = check_desc(&d->f, "dmt_attn_bwd");
   if (rc != DMT_OK) return rc;
   DMT_CHECK_ARG(d->dout && d->dQ && d->dK && d->dV, "dmt_attn_bwd: null gradient buffer");

@@ -86,3 +86,18 @@ def make_batch(spec: dict, batch: int, seed: int = DEFAULT_SEED, lengths: str = 
     mask[np.arange(batch), cls] = 1.0
     label = (cls > 0).astype(np.float32)
     return inputs, mask, label
+
+
+def slice_batch(spec: dict, inputs: dict, mask: np.ndarray, a: int, b: int):
+    """Examples [a, b) of a batch made by make_batch (the towers of run_dnn.py:148-207 each take such a slice of the input queue)."""
+    out = {}
+    for k, v in inputs.items():
+        if isinstance(v, SparseTensorValue):
+            idx = np.asarray(v.indices)
+            sel = (idx[:, 0] >= a) & (idx[:, 0] < b)
+            ind = idx[sel].copy()
+            ind[:, 0] -= a
+            out[k] = SparseTensorValue(ind, np.asarray(v.values)[sel], (b - a,) + tuple(v.dense_shape[1:]))
+        else:
+            out[k] = np.asarray(v)[a:b]
+    return out, mask[a:b]

@@ -34,6 +34,11 @@ class DeviceBatch:
     def __init__(self, B, feats: Dict[str, FeatureColumn], dense, mask=None, label=None):
         self.B, self.feats, self.dense, self.mask, self.label = B, feats, dense, mask, label
         self._prep = None
+        # "the upload of this batch is done": what the index-plane stream of the Trainer waits for instead of the whole compute stream
+        self.ready = None
+        if dense.is_cuda:
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(dense.device))
 
     @staticmethod
     def from_inputs(inputs: dict, spec: dict, device, mask=None, label=None, pad_to: Optional[Dict[str, int]] = None) -> "DeviceBatch":
@@ -593,7 +598,7 @@ class DMTEngine:
         return prep
 
     # ---- row-sharded tables: fetch the rows a batch reads from their owners (BASELINE configs[3])
-    def fetch_rows(self, batch, opt=None):
+    def fetch_rows(self, batch, opt=None, plan=None):
         """Index exchange + row return.  The batch's distinct global rows (engine.prepare) go to their owners (row % W) by
         all_to_all; every owner first replays the pending lazy-Adam updates of the requested rows (opt.catch_up), gathers them
         (dmt_rows_gather) and sends them back; the entries' ids are rewritten into slots of the returned row cache
@@ -601,9 +606,12 @@ class DMTEngine:
         from . import parallel
         prep = self.prepare(batch)
         store = self.store
-        n = int(prep["n_uniq"].item())
         uniq = prep["uniq"]
-        perm, recv_k, send_splits, recv_splits = parallel.request_rows(uniq, n)
+        if plan is not None:         # Trainer.plan_exchange already moved the ids (the same lists serve the gradient rows' way back)
+            n, perm, recv_k, send_splits, recv_splits = plan["n"], plan["perm"], plan["recv_k"], plan["send_splits"], plan["recv_splits"]
+        else:
+            n = int(prep["n_uniq"].item())
+            perm, recv_k, send_splits, recv_splits = parallel.request_rows(uniq, n)
         R = recv_k.numel()
         if opt is not None and opt.global_step > 0 and R > 0:
             opt.catch_up(recv_k, torch.tensor([R], dtype=torch.int32, device=recv_k.device), R)
@@ -664,22 +672,23 @@ class DMTEngine:
                ops.p(grad_rows), plan.max_dim, ops.stream_ptr())
         self.sparse = (prep["uniq"], prep["n_uniq"], grad_rows, prep["cap"])
 
-    def sort_segments(self, keys, vals, keys_s, vals_s, n):
-        """Stable sort of (row, entry) pairs + segment ids of equal rows."""
+    def sort_segments(self, keys, vals, keys_s, vals_s, n, tag=""):
+        """Stable sort of (row, entry) pairs + segment ids of equal rows.  `tag` names the scratch set: callers on different streams
+        (index plane / compute stream) must not share one."""
         store = self.store
         st = ops.stream_ptr()
         end_bit = max(1, int(store.total_rows).bit_length())
         need = C.c_uint64(0)
         L.call("dmt_sort_pairs", ops.p(keys), ops.p(keys_s), ops.p(vals), ops.p(vals_s), n, end_bit, None, C.byref(need), st)
-        ws = self._buf("sort_ws", (max(int(need.value), 16),), torch.uint8)
+        ws = self._buf(tag + "sort_ws", (max(int(need.value), 16),), torch.uint8)
         have = C.c_uint64(ws.numel())
         L.call("dmt_sort_pairs", ops.p(keys), ops.p(keys_s), ops.p(vals), ops.p(vals_s), n, end_bit, ops.p(ws), C.byref(have), st)
-        seg = self._buf("seg", (n,), torch.int32)
-        uniq = self._buf("uniq", (n,), torch.int32)
-        n_uniq = self._buf("n_uniq", (1,), torch.int32)
+        seg = self._buf(tag + "seg", (n,), torch.int32)
+        uniq = self._buf(tag + "uniq", (n,), torch.int32)
+        n_uniq = self._buf(tag + "n_uniq", (1,), torch.int32)
         need2 = C.c_uint64(0)
         L.call("dmt_segment_heads", ops.p(keys_s), n, store.total_rows, ops.p(seg), ops.p(uniq), ops.p(n_uniq), None, C.byref(need2), st)
-        ws2 = self._buf("heads_ws", (max(int(need2.value), 16),), torch.uint8)
+        ws2 = self._buf(tag + "heads_ws", (max(int(need2.value), 16),), torch.uint8)
         have2 = C.c_uint64(ws2.numel())
         L.call("dmt_segment_heads", ops.p(keys_s), n, store.total_rows, ops.p(seg), ops.p(uniq), ops.p(n_uniq), ops.p(ws2), C.byref(have2), st)
         return uniq, n_uniq, seg

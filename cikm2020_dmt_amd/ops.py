@@ -593,8 +593,24 @@ class Unbind0Fn(torch.autograd.Function):
         return g
 
 
-# ---- attention core: fused kernels for T <= 64, the unfused batched-GEMM form for longer sequences
+# ---- attention core: fused kernels for T <= 64 (one wavefront per (example, head)) and for 64 < T <= 256 (dmt_attn_long.hip: one
+#      workgroup per (example, head), flash style); the unfused batched-GEMM form remains for what neither takes (fp32, odd head dims)
 ATTN_FUSED_MAX_T = 64
+ATTN_LONG_FUSED = True          # False: force the unfused form for T > 64 (comparison runs, tests)
+
+
+def _rows16(t):
+    return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.stride(2) == 1)
+
+
+def long_fused_ok(H, *tensors):
+    """The flash-style long-sequence kernels take this call: bf16, head dim 16/32/64/80, T <= 256, 16-byte aligned rows."""
+    q, k = tensors[0], tensors[1]
+    if not ATTN_LONG_FUSED or q.dtype != BF16:
+        return False
+    if not L.load().dmt_attn_long_supported(dt_code(q.dtype), q.shape[2] // H, q.shape[1], k.shape[1]):
+        return False
+    return all(_rows16(t) for t in tensors)
 
 
 def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
@@ -649,7 +665,7 @@ def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
     """Returns what the backward needs beyond its inputs: None (fused kernels recompute P) or the saved P of the long form."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
-    if max(Tq, Tk) > ATTN_FUSED_MAX_T:
+    if max(Tq, Tk) > ATTN_FUSED_MAX_T and not long_fused_ok(H, q, k, v, resid, out):
         return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
     desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
     desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)

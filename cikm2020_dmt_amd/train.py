@@ -19,6 +19,20 @@ from .optim import TFAdam
 from .variables import VariableStore
 
 
+def _record_stream(obj, stream):
+    """Tensors made on the index stream and consumed on the compute stream: tell the caching allocator (it would otherwise hand a
+    freed block back to the index stream while the compute stream -- which the host runs far ahead of -- still reads it)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
@@ -47,19 +61,178 @@ class Trainer:
         # run the data-parallel exchange even in a one-rank group (a one-GPU box can still push the real RCCL calls of the
         # N-rank step through a 1-rank communicator: tests/test_gpu_dp.py)
         self.force_dp = bool(force_dp)
+        self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
 
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
 
-    def sync_rows(self, batch: DeviceBatch):
-        """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them."""
-        prep = self.engine.prepare(batch)
+    def sync_rows(self, batch: DeviceBatch, for_training: bool = True):
+        """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them; in a data-parallel
+        training step also the index plane of the gradient exchange (plan_exchange)."""
+        need_plan = (for_training or self.table_layout == "sharded") and self._dp_active() and self.dp_exchange == "owner"
+        prep = getattr(batch, "_prep", None)
+        if prep is None or (need_plan and "xplan" not in prep):
+            # Everything here depends on the batch's ids only -- not on the previous step's results -- so it runs on its own stream,
+            # next to whatever the compute stream still has queued (the tail of the previous step), and its host syncs wait for THIS
+            # stream only: the compute stream never drains.
+            side = self._index_stream()
+            if side is None:
+                prep = self.engine.prepare(batch)
+                if need_plan and "xplan" not in prep:
+                    prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
+            else:
+                main = torch.cuda.current_stream(self.device)
+                if batch.ready is not None:
+                    side.wait_event(batch.ready)
+                else:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    prep = self.engine.prepare(batch)
+                    if need_plan and "xplan" not in prep:
+                        prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
+                    _record_stream(prep, main)
+                main.wait_stream(side)
         if self.table_layout == "sharded":
-            self.engine.fetch_rows(batch, self.opt)      # owners replay the lazy updates of what they send
+            self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
             return prep
         if self.opt.global_step > 0:
             self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
         return prep
+
+    def _index_stream(self):
+        if self.device.type != "cuda" or not self.index_stream:
+            return None
+        if self._ix_stream is None:
+            self._ix_stream = torch.cuda.Stream(self.device)
+        return self._ix_stream
+
+    def _dp_active(self):
+        return parallel.world()[1] > 1 or (self.force_dp and parallel.dist.is_initialized())
+
+    def plan_exchange(self, uniq, n_uniq):
+        """INDEX PLANE of the embedding-gradient exchange, run before the forward pass.  Which rows this rank will hold gradients for
+        is known as soon as the batch's ids are sorted (engine.prepare), so everything that depends only on ids happens here, off the
+        critical path between backward and the optimizer: owner grouping of the distinct rows (row % W), the all_to_all of the row
+        ids, the owner's stable sort + segmentation of what it received (rank order = the order of summation of run_dnn.py:45-80) and --
+        replicated layout -- the all-gather of the owners' distinct-row lists.  The two host syncs this needs (pair counts per
+        (sender, owner); distinct rows per owner) therefore happen while the device queue is still short; after backward only gradient
+        ROWS move (exchange_rows_begin / _finish), with every size already on the host."""
+        eng, st = self.engine, self.store
+        rank, W = parallel.world()
+        dev = uniq.device
+        cap = uniq.numel()
+        iota = torch.arange(cap, dtype=torch.int32, device=dev)
+        owner = torch.where(iota < n_uniq, torch.remainder(uniq, W), W).to(torch.int32)       # slots past n_uniq -> bucket W (sorted last)
+        # stable grouping by owner: one radix pass over the few owner bits; the pair counts per owner fall out of the sorted owner ids
+        own_s = torch.empty((cap,), dtype=torch.int32, device=dev)
+        perm32 = torch.empty((cap,), dtype=torch.int32, device=dev)
+        end_bit = max(1, int(W).bit_length())
+        need = C.c_uint64(0)
+        L.call("dmt_sort_pairs", ops.p(owner), ops.p(own_s), ops.p(iota), ops.p(perm32), cap, end_bit, None, C.byref(need), ops.stream_ptr())
+        ws = eng._buf("ix_own_sort_ws", (max(int(need.value), 16),), torch.uint8)
+        have = C.c_uint64(ws.numel())
+        L.call("dmt_sort_pairs", ops.p(owner), ops.p(own_s), ops.p(iota), ops.p(perm32), cap, end_bit, ops.p(ws), C.byref(have), ops.stream_ptr())
+        edges = torch.searchsorted(own_s, torch.arange(W + 1, dtype=torch.int32, device=dev))
+        counts = edges[1:] - edges[:-1]
+        if parallel.dist.is_initialized():
+            mat = [torch.zeros_like(counts) for _ in range(W)]
+            parallel.dist.all_gather(mat, counts)
+            M = torch.stack(mat).cpu()                                    # host sync 1 of 2 (before the forward pass)
+        else:
+            M = counts.cpu().reshape(1, 1)
+        send_splits, recv_splits = M[rank].tolist(), M[:, rank].tolist()
+        n, Rn = int(sum(send_splits)), int(sum(recv_splits))
+        perm = perm32[:n].long()
+        send_k = uniq.index_select(0, perm)
+        recv_k = torch.empty((Rn,), dtype=uniq.dtype, device=dev)
+        if parallel.dist.is_initialized():
+            parallel._a2a(recv_k, send_k, recv_splits, send_splits)
+        else:
+            recv_k.copy_(send_k)
+        plan = dict(n=n, R=Rn, perm=perm, send_splits=send_splits, recv_splits=recv_splits, recv_k=recv_k)
+        if Rn > 0:
+            vals = torch.arange(Rn, dtype=torch.int32, device=dev)
+            keys_s = torch.empty((Rn,), dtype=torch.int32, device=dev)
+            vals_s = torch.empty((Rn,), dtype=torch.int32, device=dev)
+            uniq2, n_uniq2, seg = eng.sort_segments(recv_k, vals, keys_s, vals_s, Rn)
+            plan.update(keys_s=keys_s, vals_s=vals_s, seg=seg.clone(), uniq2=uniq2[:Rn].clone(), n_uniq2=n_uniq2.clone())
+        else:
+            plan.update(keys_s=None, uniq2=uniq[:0], n_uniq2=torch.zeros(1, dtype=torch.int32, device=dev))
+        if self.table_layout == "sharded":
+            return plan
+        # replicated layout: every rank applies every owner's reduced rows -> the owners' distinct-row lists are all-gathered now
+        cnt = plan["n_uniq2"].to(torch.int64)
+        if parallel.dist.is_initialized():
+            cnts = [torch.zeros_like(cnt) for _ in range(W)]
+            parallel.dist.all_gather(cnts, cnt)
+            c_host = torch.stack(cnts).reshape(-1).cpu()                  # host sync 2 of 2 (still before the forward pass)
+        else:
+            c_host = cnt.cpu()
+        m = int(c_host[rank])
+        cap_m = max(1, int(c_host.max()))
+        k_loc = torch.full((cap_m,), st.total_rows, dtype=uniq.dtype, device=dev)
+        k_loc[:m] = plan["uniq2"][:m]
+        all_k = torch.empty((W * cap_m,), dtype=uniq.dtype, device=dev)
+        if parallel.dist.is_initialized():
+            parallel._all_gather_cat(all_k, k_loc, W, cap_m)
+        else:
+            all_k.copy_(k_loc)
+        plan.update(m=m, cap_m=cap_m, all_k=all_k, n_dev=torch.full((1,), W * cap_m, dtype=torch.int32, device=dev))
+        return plan
+
+    def exchange_rows_begin(self, sparse, plan):
+        """DATA PLANE, first half (right after backward): this rank's gradient rows, grouped by owner and rounded to the wire format by one
+        kernel (dmt_rows_permute), leave in one all_to_all_single.  With RCCL the collective is asynchronous: the dense Adam step runs
+        while the rows are on the links."""
+        _uniq, _n_uniq, grad_rows, _cap = sparse
+        st = self.store
+        wire = torch.bfloat16 if st.compute_dtype == torch.bfloat16 else torch.float32
+        n, Rn, D = plan["n"], plan["R"], int(grad_rows.shape[1])
+        send_r = torch.empty((n, D), dtype=wire, device=grad_rows.device)
+        if n > 0:
+            if grad_rows.dtype == torch.float32 and grad_rows.is_contiguous() and D % 4 == 0:
+                L.call("dmt_rows_permute", ops.p(grad_rows), ops.p(plan["perm"]), n, D, ops.dt_code(wire), ops.p(send_r), ops.stream_ptr())
+            else:
+                send_r.copy_(grad_rows.index_select(0, plan["perm"]))
+        recv_r = torch.empty((Rn, D), dtype=wire, device=grad_rows.device)
+        work = None
+        if not parallel.dist.is_initialized():
+            recv_r.copy_(send_r)
+        elif parallel.dist.get_backend() == "nccl":
+            work = parallel.dist.all_to_all_single(recv_r, send_r, plan["recv_splits"], plan["send_splits"], async_op=True)
+        else:
+            parallel._a2a(recv_r, send_r, plan["recv_splits"], plan["send_splits"])
+        return (work, send_r, recv_r)
+
+    def exchange_rows_finish(self, handle, plan):
+        """DATA PLANE, second half: the owner sums what it received per row, in rank order, with the segments prepared by
+        plan_exchange (dmt_rows_reduce).  Sharded layout: done -- the owner applies Adam to its rows.  Replicated layout: the reduced
+        shards are all-gathered (padded to the largest shard; padding slots carry an invalid key the optimizer kernels skip)."""
+        work, _send_r, recv_r = handle
+        if work is not None:
+            work.wait()
+        eng, st = self.engine, self.store
+        rank, W = parallel.world()
+        Rn, D = plan["R"], int(recv_r.shape[1])
+        sharded = self.table_layout == "sharded"
+        rows_cap = max(1, Rn if sharded else max(plan["cap_m"], Rn))
+        out_rows = eng._buf("m_rows", (rows_cap, D), torch.float32)
+        if Rn > 0:
+            L.call("dmt_zero_rows", ops.p(out_rows), ops.p(plan["n_uniq2"]), 0, rows_cap, D, ops.stream_ptr())
+            L.call("dmt_rows_reduce_bf16" if recv_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(plan["keys_s"]), ops.p(plan["vals_s"]),
+                   ops.p(plan["seg"]), Rn, st.total_rows, ops.p(recv_r), ops.p(out_rows), D, ops.stream_ptr())
+        if sharded:
+            return (plan["uniq2"], plan["n_uniq2"], out_rows, Rn)
+        cap_m = plan["cap_m"]
+        r_loc = out_rows[:cap_m]
+        if recv_r.dtype == torch.bfloat16:
+            r_loc = r_loc.to(torch.bfloat16)          # (rows past this shard's m are never read: their keys are invalid)
+        all_r = torch.empty((W * cap_m, D), dtype=r_loc.dtype, device=r_loc.device)
+        if parallel.dist.is_initialized():
+            parallel._all_gather_cat(all_r, r_loc.contiguous(), W, cap_m)
+        else:
+            all_r.copy_(r_loc)
+        return (plan["all_k"], plan["n_dev"], all_r, W * cap_m)
 
     def forward_backward(self, batch: DeviceBatch):
         self.sync_rows(batch)
@@ -88,7 +261,8 @@ class Trainer:
 
     def merge_sparse(self, sparse):
         """average_gradients for the IndexedSlices: concatenate every rank's (row, grad) pairs in rank order and
-        reduce rows again with the same stable sort + segment reduce."""
+        reduce rows again with the same stable sort + segment reduce.  (One-shot form with its host syncs after backward: used by
+        dp_exchange="allgather" and when no exchange plan was made -- forward_backward called without sync_rows' plan.)"""
         rank, W = parallel.world()
         if W == 1 and not (self.force_dp and parallel.dist.is_initialized()):
             return sparse                      # (one rank owns every row: sharded == replicated)
@@ -153,7 +327,7 @@ class Trainer:
         vals = torch.arange(N, dtype=torch.int32, device=all_k.device)
         keys_s = eng._buf("m_keys_s", (N,), torch.int32)
         vals_s = eng._buf("m_vals_s", (N,), torch.int32)
-        uniq2, n_uniq2, seg = eng.sort_segments(all_k, vals, keys_s, vals_s, N)
+        uniq2, n_uniq2, seg = eng.sort_segments(all_k, vals, keys_s, vals_s, N, tag="m_")
         uniq2, n_uniq2 = uniq2.clone(), n_uniq2.clone()
         capm = min(N, st.total_rows)
         out_rows = eng._buf("m_rows", (capm, grad_rows.shape[1]), torch.float32)
@@ -173,6 +347,21 @@ class Trainer:
                 works = [early[1], parallel.allreduce_dense_(self.store.grads[: early[0]], async_op=True, force=self.force_dp)]
             else:
                 works = [parallel.allreduce_dense_(self.store.grads, async_op=True, force=self.force_dp)]
+            plan = (getattr(batch, "_prep", None) or {}).get("xplan")
+            if plan is not None:
+                # no host sync between backward and the optimizer: sizes were fixed by plan_exchange before the forward pass
+                handle = self.exchange_rows_begin(sparse, plan)
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                loss = parallel.mean_scalar(loss)
+                self.opt.begin()
+                self.opt.apply_dense(1.0 / W)                  # overlaps the row exchange (RCCL: its own stream)
+                sparse = self.exchange_rows_finish(handle, plan)
+                self.opt.apply_sparse(sparse, 1.0 / W)
+                self.opt.end()
+                self.store.refresh_shadows()
+                return loss
             sparse = self.merge_sparse(sparse)
             for w in works:
                 if w is not None:
@@ -184,7 +373,7 @@ class Trainer:
     @torch.no_grad()
     def predict(self, batch: DeviceBatch):
         """run_dnn.predict scoring (run_dnn.py:663-687): sigmoid(logit + y_bias)."""
-        self.sync_rows(batch)
+        self.sync_rows(batch, for_training=False)
         with torch.enable_grad():
             out = self.engine.inference(batch)
         (c, o), yb = out

@@ -237,6 +237,15 @@ typedef struct {
 
 int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream);
 
+/* Long sequences (64 < max(Tq, Tk) <= 256; BASELINE "long-seq variant": clk / ord histories of 200): same operation, same
+ * descriptors, flash-style workgroup kernels (dmt_attn_long.hip) -- no [B,H,T,T] tensor reaches HBM.  dmt_attn_fwd / dmt_attn_bwd
+ * route here by themselves when a sequence is longer than 64; the entry points are exported for direct use and tests.
+ * Requirements: bf16, dh in {16, 32, 64, 80}, every operand row 16-byte aligned (base % 16 == 0, strides % 8 == 0).
+ * Replaces: scaled_dot_product_attention at T = 200 (TransformerModel_util.py:11-56) incl. its three [N*h, T, T] intermediates. */
+int dmt_attn_long_supported(int32_t dtype, int32_t dh, int32_t Tq, int32_t Tk);
+int dmt_attn_long_fwd(const dmt_attn_desc* d, void* stream);
+int dmt_attn_long_bwd(const dmt_attn_bwd_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim, biased variance, eps inside the sqrt (TransformerModel_util.py:58-78).
  *   y = gamma * (x - mean) / sqrt(var + eps) + beta ; stats[r] = {mean, rstd}

@@ -222,3 +222,88 @@ def test_full_train_step_through_one_rank_rccl_group(cuda, bf16):
         assert worst < 4e-3, worst          # three Adam steps move a parameter by at most ~3e-3
     else:
         assert same, worst
+
+
+def _halves_worker(rank, world, port, q, B):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    so, sp = small_specs()
+    P = O.init_params(so, seed=5)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False, dropout=False)
+    tr.store.load_state(P)
+    from cikm2020_dmt_amd.data_feed.synthetic import slice_batch
+    for s in range(2):
+        inputs, mask, _ = make_batch(sp, B, seed=4100 + s, lengths="ragged", weights="random")
+        h = B // world
+        sub_in, sub_mask = slice_batch(sp, inputs, mask, rank * h, (rank + 1) * h)
+        loss = tr.train_step(tr.make_batch(sub_in, sub_mask))
+    tr.opt.flush_tables()
+    torch.cuda.synchronize()
+    q.put((rank, float(loss), tr.store.state_dict()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_half_batches_equal_one_rank_whole_batch(cuda):
+    """run_dnn.py:45-87: the mean over towers of per-tower mean losses / gradients.  With equal tower batches this IS the mean over the
+    whole batch, so 2 ranks x B/2 must train like 1 rank x B.  fp32 mode; equality is to summation-order rounding (the per-rank
+    sums are formed first), which Adam can amplify to ~lr on elements whose gradient is ~0: after two steps all but a few 1e-4 of
+    the parameters agree to 2e-5 and none moves further than 2 Adam steps."""
+    from cikm2020_dmt_amd.train import Trainer
+    B = 12
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_halves_worker, args=(r, 2, port, q, B)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    so, sp = small_specs()
+    P = O.init_params(so, seed=5)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, init=False, dropout=False)
+    tr.store.load_state(P)
+    for s in range(2):
+        inputs, mask, _ = make_batch(sp, B, seed=4100 + s, lengths="ragged", weights="random")
+        loss = tr.train_step(tr.make_batch(inputs, mask))
+    tr.opt.flush_tables()
+    one = tr.store.state_dict()
+    assert abs(float(loss) - res[0][1]) < 2e-5
+    total = sum(v.size for v in one.values())
+    n_off = sum(int((np.abs(res[0][2][k] - one[k]) > 2e-5).sum()) for k in one)
+    worst = max(float(np.abs(res[0][2][k] - one[k]).max()) for k in one)
+    assert n_off <= 3e-4 * total and worst < 2.5e-3, (n_off, total, worst)
+
+
+def test_bench_two_ranks_torchrun_on_one_device(cuda):
+    """The driver's N > 1 launch line (python -m torch.distributed.run ... bench.py --gpus 2), on this one-GPU box: both ranks on
+    cuda:0 (DMT_BENCH_ONE_DEVICE=1) over gloo (RCCL needs two devices).  The JSON line must come out of rank 0 with the aggregate
+    over both ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMT_BENCH_ONE_DEVICE="1", DMT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["config"]["global_batch"] == 512
+    assert abs(j["value"] - 512 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-3
+    assert np.isfinite(j["final_loss"])
+    # the sharded-table variant of the same launch
+    cmd2 = cmd + ["--shard-tables"]
+    cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
+    out2 = subprocess.run(cmd2, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out2.returncode == 0, out2.stderr[-3000:]
+    j2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
+    assert "row-sharded" in j2["config"]["parallelism"] and np.isfinite(j2["final_loss"])

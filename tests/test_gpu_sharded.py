@@ -96,7 +96,7 @@ def test_sharded_tables_three_ranks_padded_shards(cuda):
             assert np.abs(a1[r][2][k] - b1[0][2][k]).max() <= 1e-7, (k, r)
         assert np.array_equal(a1[r][2]["embedding_trans/Sku/embedding"], a1[0][2]["embedding_trans/Sku/embedding"])
     a, b = _run(3, 4, "sharded"), _run(3, 4, "replicated")
-    assert np.abs(np.array(a[0][1]) - np.array(b[0][1])).max() < 1e-4
+    assert np.abs(np.array(a[0][1]) - np.array(b[0][1])).max() < 5e-3
     for k in b[0][2]:
         assert np.abs(a[0][2][k] - b[0][2][k]).max() < 4e-3, k
         for r in (1, 2):
