@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
     ap.add_argument("--long-seq", type=int, default=0, help="BASELINE long-seq variant: click / order histories of this length (e.g. 200) instead of 50")
+    ap.add_argument("--attn-dtype", default="bf16", choices=["bf16", "fp8"], help="BASELINE configs[4]: fp8 = the long-sequence attention forward "
+                    "(64 < L <= 256) multiplies in OCP e4m3 (v_mfma_f32_32x32x16_fp8_fp8); L <= 64 kernels are bf16 either way")
     ap.add_argument("--shard-tables", action="store_true", help="BASELINE configs[3]: row-sharded embedding tables (rank r holds rows id %% W == r; "
                     "all-to-all id / row / gradient-row exchange, owner-only Adam) instead of one replica per GPU")
     ap.add_argument("--sku-rows", type=int, default=0, help="SKU vocabulary (default: the reference's 5 M); configs[3] quotes 100000000")
@@ -91,7 +93,7 @@ def main():
         seq_lens = {grp[0][0]: args.long_seq for grp in sp["attention_embed_pairs"][:2]}
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp,
-                 table_layout="sharded" if args.shard_tables else "replicated")
+                 table_layout="sharded" if args.shard_tables else "replicated", attn_dtype=args.attn_dtype)
     nb = 4
     batches = []
     for i in range(nb):
@@ -166,8 +168,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=%s full, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s"
-                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", args.law,
+                               "per-GPU batch %d, L=%s full%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s"
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10",
+                                  (" (flash-style attention kernels, %s MFMA forward)" % args.attn_dtype) if args.long_seq > 64 else "", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
                                   "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),

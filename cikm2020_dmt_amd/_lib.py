@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdmt_hip.so")
 
-DMT_F32, DMT_BF16 = 0, 1
+DMT_F32, DMT_BF16, DMT_FP8_E4M3 = 0, 1, 2
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
@@ -55,7 +55,7 @@ class AttnDesc(C.Structure):
                 ("Q", c_vp), ("q_bs", c_i64), ("q_rs", c_i64), ("K", c_vp), ("k_bs", c_i64), ("k_rs", c_i64),
                 ("V", c_vp), ("v_bs", c_i64), ("v_rs", c_i64), ("q_lens", c_vp), ("k_lens", c_vp),
                 ("resid", c_vp), ("r_bs", c_i64), ("r_rs", c_i64), ("out", c_vp), ("o_bs", c_i64), ("o_rs", c_i64),
-                ("drop_seed", C.c_uint32), ("drop_keep", c_f32)]
+                ("drop_seed", C.c_uint32), ("drop_keep", c_f32), ("mma_dtype", c_i32)]
 
 
 class AttnBwdDesc(C.Structure):

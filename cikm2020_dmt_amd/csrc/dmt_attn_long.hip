@@ -252,6 +252,184 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (!synced) __syncthreads();
 }
 
+// ----------------------------------------------------------------------------------------------- forward, fp8 (OCP e4m3) MFMA
+// BASELINE configs[4] "fp8 MFMA attention path": S^T = K Q^T and O^T = V^T P^T run on v_mfma_f32_32x32x16_fp8_fp8 (fp32 accumulate).
+//   * Q, K, V are converted bf16 -> e4m3 as they are staged (saturating at +-448: they are projections of LayerNorm outputs, O(1));
+//     K lives in LDS as [key][dh] bytes, V transposed as [dim][key] bytes, so both A operands are plain 4/8-byte LDS reads.
+//   * the weights P in [0, 1/keep] are scaled by 2^8 before the conversion (a uniform 1/200 would otherwise be an e4m3 subnormal with two
+//     mantissa bits); the exact power of two is divided out of O.  Rows of padded queries (weights = -2^32+1, far outside e4m3) carry
+//     the constant in that output scale instead: P8 = 1.
+//   * softmax, masks, dropout and the residual add are the fp32 code of the bf16 kernel.  The backward pass stays bf16
+//     (attn_long_bwd_kernel): it differentiates the bf16 function, the usual pairing for fp8 forward passes.
+// Same MFMA shape and rate as bf16 (the 2x-rate MX-scaled 32x32x64 instruction pays only once this kernel is MFMA-bound: at
+// ~12 % MFMA utilisation its cost is softmax VALU, LDS and latency); what fp8 buys here is half the LDS bytes per workgroup.
+typedef long f8x8_t;      // 8 e4m3 values (2 VGPRs)
+
+__device__ __forceinline__ unsigned cvt4_f8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+__device__ __forceinline__ float sat8(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// 8 bf16 (one 16-byte piece of a row) -> 8 e4m3
+__device__ __forceinline__ uint2 bf16x8_to_f8(const uint4& u) {
+  float f[8];
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = sat8(f[i]);
+  return make_uint2(cvt4_f8(f[0], f[1], f[2], f[3]), cvt4_f8(f[4], f[5], f[6], f[7]));
+}
+__device__ __forceinline__ f8x8_t as_f8x8(const uint2& u) {
+  union { uint2 u; f8x8_t l; } x;
+  x.u = u;
+  return x.l;
+}
+__device__ __forceinline__ f32x16_t mma8(f8x8_t a, f8x8_t b, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+}
+
+template <int DH, int NTK>
+__global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_long_fwd_f8_kernel(const LongArgs a) {
+  typedef LongCfg<DH> CF;
+  constexpr int NK = CF::NK, NDT = CF::NDT, CH = DH / 8;
+  constexpr int RS8 = DH + 8;                  // bytes per K row
+  constexpr int VS8 = NTK * 32 + 8;            // bytes per V^T row (one head dim, all keys)
+  constexpr int VDIMS = NDT * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char Kl[NTK * 32 * RS8];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[VDIMS * VS8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+  const int Tq = a.Tq, Tk = a.Tk;
+  const int half = lane >> 5, l31 = lane & 31;
+  const bf16_t* Qg = a.Q + (long long)b * a.q_bs + h * DH;
+  const bf16_t* Kg = a.K + (long long)b * a.k_bs + h * DH;
+  const bf16_t* Vg = a.V + (long long)b * a.v_bs + h * DH;
+  const bf16_t* Rg = a.resid ? a.resid + (long long)b * a.r_bs + h * DH : nullptr;
+  bf16_t* Og = a.out + (long long)b * a.o_bs + h * DH;
+  // ---- stage K as e4m3 rows, V as e4m3 columns (keys past Tk: zeros -- 0 x anything finite)
+  for (int i = tid; i < VDIMS * VS8 / 4; i += LNW * 64) reinterpret_cast<unsigned*>(Vt)[i] = 0u;
+  __syncthreads();
+  for (int c = tid; c < NTK * 32 * CH; c += LNW * 64) {
+    const int row = c / CH, ch = c - row * CH;
+    uint2 k8 = make_uint2(0u, 0u);
+    if (row < Tk) {
+      k8 = bf16x8_to_f8(*reinterpret_cast<const uint4*>(Kg + (long long)row * a.k_rs + ch * 8));
+      const uint2 v8 = bf16x8_to_f8(*reinterpret_cast<const uint4*>(Vg + (long long)row * a.v_rs + ch * 8));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vt[(ch * 8 + e) * VS8 + row] = (unsigned char)(v8.x >> (8 * e));
+        Vt[(ch * 8 + 4 + e) * VS8 + row] = (unsigned char)(v8.y >> (8 * e));
+      }
+    }
+    *reinterpret_cast<uint2*>(Kl + row * RS8 + ch * 8) = k8;
+  }
+  int klen = a.k_lens ? a.k_lens[b] : Tk;
+  klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  const int qlen = a.q_lens ? a.q_lens[b] : Tq;
+  const float kscale = LOG2E / sqrtf((float)DH);
+  const int kl0 = klen - 4 * half, tk0 = Tk - 4 * half;
+  const int nqt = (Tq + 31) >> 5;
+  bool synced = false;
+  for (int qt = wave; qt < nqt; qt += LNW) {
+    const int q = qt * 32 + l31;
+    int kl = kl0, tk = tk0;
+    asm volatile("" : "+v"(kl), "+v"(tk));
+    f8x8_t bQ[NK];
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2) {
+      const int j0 = s2 * 16 + 8 * half;
+      bQ[s2] = (q < Tq && j0 + 8 <= DH) ? as_f8x8(bf16x8_to_f8(*reinterpret_cast<const uint4*>(Qg + (long long)q * a.q_rs + j0))) : 0L;
+    }
+    uint2 rres[NDT][4];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = dt * 32 + 8 * g + 4 * half;
+        rres[dt][g] = (Rg && q < Tq && j + 4 <= DH) ? *reinterpret_cast<const uint2*>(Rg + (long long)q * a.r_rs + j) : make_uint2(0u, 0u);
+      }
+    if (!synced) { __syncthreads(); synced = true; }
+    f32x16_t acc[NTK];
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) acc[kt] = zero16();
+#pragma unroll
+    for (int s2 = 0; s2 < NK; ++s2) {
+      const int j0 = s2 * 16 + 8 * half;
+#pragma unroll
+      for (int kt = 0; kt < NTK; ++kt) {
+        const f8x8_t kf = (j0 + 8 <= DH) ? as_f8x8(*reinterpret_cast<const uint2*>(Kl + (kt * 32 + l31) * RS8 + j0)) : 0L;
+        acc[kt] = mma8(kf, bQ[s2], acc[kt]);
+      }
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float x = acc[kt][r] * kscale;
+        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+        x = (c >= tk) ? -3.0e38f : x;
+        acc[kt][r] = x;
+        m = fmaxf(m, x);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(acc[kt][r] - m);
+        acc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const bool qpad = (q >= qlen);
+    const float pscale = __builtin_amdgcn_rcpf(sum) * 256.f;          // P * 2^8 -> e4m3
+    const float oscale = qpad ? PADDING_NUM : (1.f / 256.f);
+    const unsigned dbase = (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + 4u * half;
+    f8x8_t pB[2 * NTK];
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+        float p = acc[kt][r] * pscale;
+        if (qpad) p = (c < tk) ? 1.f : 0.f;
+        if (a.drop_on) p = dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? p * a.drop_inv : 0.f;
+        acc[kt][r] = p;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        pB[2 * kt + u] = as_f8x8(make_uint2(cvt4_f8(acc[kt][8 * u + 0], acc[kt][8 * u + 1], acc[kt][8 * u + 2], acc[kt][8 * u + 3]),
+                                            cvt4_f8(acc[kt][8 * u + 4], acc[kt][8 * u + 5], acc[kt][8 * u + 6], acc[kt][8 * u + 7])));
+    }
+    // ---- O^T = V^T P^T: A = V^T rows (dims) in accumulator-slot key order: keys 16u + 4 half + {0..3} and 8 further
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      f32x16_t o = zero16();
+      const unsigned char* vrow = Vt + (dt * 32 + l31) * VS8 + 4 * half;
+#pragma unroll
+      for (int u = 0; u < 2 * NTK; ++u) {
+        const uint2 av = make_uint2(*reinterpret_cast<const unsigned*>(vrow + 16 * u), *reinterpret_cast<const unsigned*>(vrow + 16 * u + 8));
+        o = mma8(as_f8x8(av), pB[u], o);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned w0 = rres[dt][g].x, w1 = rres[dt][g].y;
+        o[4 * g + 0] = o[4 * g + 0] * oscale + __uint_as_float(w0 << 16); o[4 * g + 1] = o[4 * g + 1] * oscale + __uint_as_float(w0 & 0xffff0000u);
+        o[4 * g + 2] = o[4 * g + 2] * oscale + __uint_as_float(w1 << 16); o[4 * g + 3] = o[4 * g + 3] * oscale + __uint_as_float(w1 & 0xffff0000u);
+      }
+      store_direct<DH>(o, Og + (long long)q * a.o_rs, q < Tq, dt, half);
+    }
+  }
+  if (!synced) __syncthreads();
+}
+
 // ----------------------------------------------------------------------------------------------------------- backward
 template <int DH, int NTK>
 __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_long_bwd_kernel(const LongArgs a) {
@@ -776,6 +954,12 @@ extern "C" int dmt_attn_long_fwd(const dmt_attn_desc* d_, void* stream) {
     DMT_CHECK_LAUNCH("dmt_attn_long_fwd(q1)");
     return DMT_OK;
   }
+  if (d_->mma_dtype == DMT_FP8_E4M3) {
+    DMT_LONG_DISPATCH(attn_long_fwd_f8_kernel, a);
+    DMT_CHECK_LAUNCH("dmt_attn_long_fwd(fp8)");
+    return DMT_OK;
+  }
+  DMT_CHECK_ARG(d_->mma_dtype == 0 || d_->mma_dtype == d_->dtype, "dmt_attn_long_fwd: mma_dtype must be 0, the operand dtype or DMT_FP8_E4M3");
   DMT_LONG_DISPATCH(attn_long_fwd_kernel, a);
   DMT_CHECK_LAUNCH("dmt_attn_long_fwd");
   return DMT_OK;

@@ -492,6 +492,7 @@ def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out):
         d.resid, d.r_bs, d.r_rs = resid.data_ptr(), resid.stride(0), resid.stride(1)
     if out is not None:
         d.out, d.o_bs, d.o_rs = out.data_ptr(), out.stride(0), out.stride(1)
+    d.mma_dtype = L.DMT_FP8_E4M3 if ATTN_MMA_FP8 else 0
     return d
 
 
@@ -596,6 +597,7 @@ class Unbind0Fn(torch.autograd.Function):
 # ---- attention core: fused kernels for T <= 64 (one wavefront per (example, head)) and for 64 < T <= 256 (dmt_attn_long.hip: one
 #      workgroup per (example, head), flash style); the unfused batched-GEMM form remains for what neither takes (fp32, odd head dims)
 ATTN_FUSED_MAX_T = 64
+ATTN_MMA_FP8 = False            # True: the long-sequence forward kernel multiplies in OCP e4m3 (Trainer(attn_dtype="fp8"), BASELINE configs[4])
 ATTN_LONG_FUSED = True          # False: force the unfused form for T > 64 (comparison runs, tests)
 
 

@@ -36,12 +36,17 @@ def _record_stream(obj, stream):
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
-                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated"):
+                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None):
         """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
         same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
         back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
         self.spec = spec
         self.device = torch.device(device)
+        if attn_dtype not in (None, "bf16", "fp8"):
+            raise ValueError("attn_dtype must be None, 'bf16' or 'fp8'")
+        if attn_dtype is not None:
+            # BASELINE configs[4]: the long-sequence (64 < T <= 256) attention forward multiplies in OCP e4m3 (process-wide switch)
+            ops.ATTN_MMA_FP8 = attn_dtype == "fp8"
         if table_layout not in ("replicated", "sharded"):
             raise ValueError("table_layout must be 'replicated' or 'sharded'")
         self.table_layout = table_layout

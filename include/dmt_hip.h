@@ -26,6 +26,7 @@ extern "C" {
 
 #define DMT_F32 0
 #define DMT_BF16 1
+#define DMT_FP8_E4M3 2     /* OCP e4m3fn: only as dmt_attn_desc.mma_dtype (long-sequence attention forward) */
 
 #define DMT_OK 0
 #define DMT_ERR_ARG (-1)
@@ -221,6 +222,8 @@ typedef struct {
   uint32_t drop_seed;          /* dropout on the attention weights (TransformerModel_util.py:51), applied after the query mask: */
   float drop_keep;             /* keep probability; >= 1 (or 0) disables.  mask(i) = dmt_dropout_keep(drop_seed, i, keep),      */
                                /* i = ((b*H + h)*Tq + q)*Tk + k                                                                  */
+  int32_t mma_dtype;           /* 0: the MFMAs run in `dtype`.  DMT_FP8_E4M3: long-sequence forward (64 < T <= 256, Tq > 1) converts Q, K, V and   */
+                               /* the weights to OCP e4m3 for its two matrix products (BASELINE configs[4]); ignored elsewhere                 */
 } dmt_attn_desc;
 
 int dmt_attn_fwd(const dmt_attn_desc* d, void* stream);
