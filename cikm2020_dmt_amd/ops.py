@@ -182,8 +182,8 @@ def wgrad320(A, B, C, transposed, bias=None, bias_of=0):
     d.transposed = 1 if transposed else 0
     d.bias, d.bias_of = (bias.data_ptr(), bias_of) if bias is not None else (None, 0)
     if PROFILE is not None:
-        PROFILE.setdefault("gemm_bytes", []).append(float((A.numel() + B.numel()) * 2 + C.numel() * 4))
-    with _Timed("gemm_bf16", 2.0 * A.shape[0] * A.shape[1] * B.shape[1]):
+        PROFILE.setdefault("wgrad320_bytes", []).append(float((A.numel() + B.numel()) * 2 + C.numel() * 4))
+    with _Timed("wgrad320", 2.0 * A.shape[0] * A.shape[1] * B.shape[1]):
         L.call("dmt_wgrad320", _ct.byref(d), stream_ptr())
 
 
@@ -410,11 +410,14 @@ def _chain_call(mode, geo, x2, image, M, *, bias2=None, gamma=None, beta=None, e
     d.mid_out, d.ld_mid = (mid_out.data_ptr(), mid_out.stride(0)) if mid_out is not None else (None, 0)
     d.mask = mask.data_ptr() if mask is not None else None
     flops = 2.0 * M * geo[1] * (geo[0] + geo[2])
-    with _Timed("gemm_bf16", flops):
+    with _Timed("chain2", flops):
         L.call("dmt_chain2", C.byref(d), stream_ptr())
     if PROFILE is not None:
+        # algorithmic HBM bytes: input rows once, every output once, the weight image once per launch (it is re-read from L2 per tile),
+        # the relu bit mask (mid / 8 bytes per row) when written
         byt = M * (geo[0] + geo[2] * ((s_out is not None) + (y_out is not None))) * 2 + (M * geo[1] * 2 if mid_out is not None else 0)
-        PROFILE.setdefault("gemm_bytes", []).append(float(byt + image.numel()))
+        byt += (M * geo[1] // 8) if mask is not None else 0
+        PROFILE.setdefault("chain2_bytes", []).append(float(byt + image.numel()))
 
 
 class FFNLNChainFn(torch.autograd.Function):
@@ -671,7 +674,8 @@ def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
         return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
     desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
     desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
-    L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
+    with _Timed("attn_long" if max(Tq, Tk) > ATTN_FUSED_MAX_T else "attn", 4.0 * B * Tq * Tk * d):
+        L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
     return None
 
 
@@ -687,7 +691,8 @@ def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, dr
     bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), dq.stride(0), dq.stride(1)
     bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), dk.stride(0), dk.stride(1)
     bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), dv.stride(0), dv.stride(1)
-    L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+    with _Timed("attn_long" if max(Tq, Tk) > ATTN_FUSED_MAX_T else "attn", 10.0 * B * Tq * Tk * d):     # S, dP, dQ, dK, dV (recomputation not counted)
+        L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
 
 
 class AttnFn(torch.autograd.Function):
@@ -802,10 +807,10 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     dd.stats = stats.data_ptr() if stats is not None else None
     dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
     flops = 2.0 * B * T * d * 3 * d + 4.0 * B * T * T * d
-    with _Timed("gemm_bf16", flops):
+    with _Timed("mhsa_block", flops):
         L.call("dmt_mhsa_block_fwd", C.byref(dd), stream_ptr())
     if PROFILE is not None:
-        PROFILE.setdefault("gemm_bytes", []).append(float(B * T * d * 2 * (3 + (3 if want_side else 0)) + image.numel()))
+        PROFILE.setdefault("mhsa_block_bytes", []).append(float(B * T * d * 2 * (3 + (3 if want_side else 0)) + image.numel()))
     return y, s, stats, qkv
 
 

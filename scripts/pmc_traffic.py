@@ -1,21 +1,42 @@
-"""Aggregate FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, one counter per pass) over the GEMM kernels of a bench.py run.
-usage: pmc_traffic.py <fetch_dir> <write_dir> <steps_total> -> JSON on stdout (bytes per GEMM launch, gfx950 FETCH x2 correction)"""
+"""Aggregate FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, ONE counter per pass -- the two do not fit one pass and combining TCC counters
+hung nodes on this pool) over the kernel families of a bench.py run.
+usage: pmc_traffic.py <fetch_dir> <write_dir> [steps]  -> JSON on stdout: {family: bytes per launch}, with the gfx950 correction of
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE as reported; both in KB."""
 import csv, glob, json, sys
+
+FAMILIES = {
+    "chain2": ["chain2_kernel"],
+    "gemm_bf16": ["gemm_glds_kernel", "gemm_dw_glds_kernel", "gemm_kernel<"],
+    "wgrad320": ["wgrad320_kernel"],
+    "attn": ["attn_fwd_co_kernel", "attn_bwd_co_kernel", "attn_q1v_kernel"],
+    "attn_long": ["attn_long_fwd", "attn_long_bwd", "attn_q1_long"],
+    "gather_fwd": ["gather_group_kernel"],
+    "embgrad_reduce": ["embgrad_reduce_kernel"],
+    "adam_sparse": ["adam_sparse_kernel"],
+}
+
+
 def load(d, counter):
     f = glob.glob("%s/*/*counter_collection.csv" % d)[0]
-    tot, n = 0.0, 0
+    tot, n = {}, {}
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter: continue
+        if r["Counter_Name"] != counter:
+            continue
         k = r["Kernel_Name"]
-        if "gemm_glds_kernel" in k or "gemm_dw_glds_kernel" in k or "gemm_kernel<" in k:
-            tot += float(r["Counter_Value"]); n += 1
+        for fam, pats in FAMILIES.items():
+            if any(p in k for p in pats):
+                tot[fam] = tot.get(fam, 0.0) + float(r["Counter_Value"])
+                n[fam] = n.get(fam, 0) + 1
     return tot, n
-fetch_kb, n1 = load(sys.argv[1], "FETCH_SIZE")
-write_kb, n2 = load(sys.argv[2], "WRITE_SIZE")
-assert n1 == n2 and n1 > 0, (n1, n2)
-# MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide streaming read
-fetch_b = fetch_kb * 1024 * 2
-write_b = write_kb * 1024
-print(json.dumps({"launches": n1, "fetch_bytes_per_launch": fetch_b / n1, "write_bytes_per_launch": write_b / n1,
-                  "hbm_bytes_per_launch": (fetch_b + write_b) / n1,
-                  "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; GEMM kernels only; FETCH_SIZE doubled (gfx950 half-count), WRITE_SIZE as reported"}))
+
+
+fetch, n1 = load(sys.argv[1], "FETCH_SIZE")
+write, n2 = load(sys.argv[2], "WRITE_SIZE")
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+out = {}
+for fam in fetch:
+    assert n1[fam] == n2.get(fam), (fam, n1[fam], n2.get(fam))
+    fb, wb = fetch[fam] * 1024 * 2, write[fam] * 1024
+    out[fam] = {"launches": n1[fam], "fetch_bytes_per_launch": fb / n1[fam], "write_bytes_per_launch": wb / n1[fam],
+                "hbm_bytes_per_launch": (fb + wb) / n1[fam], "hbm_bytes_per_step": (fb + wb) / steps}
+print(json.dumps(out))
