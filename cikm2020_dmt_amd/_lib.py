@@ -100,11 +100,12 @@ _SIGS = {
     "dmt_sort_pairs": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_segment_heads": [c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_vp, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_entry_slots": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
-    "dmt_embgrad_reduce": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
-    "dmt_rows_reduce": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
+    "dmt_embgrad_reduce": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, C.c_uint64, c_vp],
+    "dmt_rows_reduce": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp, C.c_uint64, c_vp],
     "dmt_rows_permute": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "dmt_zero_rows": [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp],
-    "dmt_rows_reduce_bf16": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp],
+    "dmt_rows_reduce_bf16": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp, C.c_uint64, c_vp],
+    "dmt_set_deterministic": [c_i32],
     "dmt_gemm": [C.POINTER(GemmDesc), c_vp],
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
@@ -149,7 +150,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported",
-                                                 "dmt_attn_long_supported"])
+                                                 "dmt_attn_long_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
 
 _lib = None
 
@@ -176,6 +177,10 @@ def load():
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
+    lib.dmt_get_deterministic.restype = c_i32
+    lib.dmt_get_deterministic.argtypes = []
+    lib.dmt_reduce_det_ws_bytes.restype = C.c_uint64
+    lib.dmt_reduce_det_ws_bytes.argtypes = [c_i64, c_i32]
     lib.dmt_attn_long_supported.restype = c_i32
     lib.dmt_attn_long_supported.argtypes = [c_i32, c_i32, c_i32, c_i32]
     _lib = lib

@@ -10,6 +10,7 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 void dmt_set_error(const char* fmt, ...);
+int dmt_deterministic(void);      // dmt_set_deterministic(): fixed-order reductions instead of fp32 atomics
 
 #define DMT_CHECK_ARG(cond, ...)            \
   do {                                      \

@@ -11,6 +11,13 @@ void dmt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dmt_last_error(void) { return g_err; }
+
+// Deterministic mode: every reduction that normally combines partial sums with fp32 atomics (order = scheduling) takes a fixed-order
+// form instead -- slower, bit-reproducible from run to run.
+static int g_deterministic = 0;
+int dmt_deterministic(void) { return g_deterministic; }
+extern "C" int dmt_set_deterministic(int32_t on) { g_deterministic = on ? 1 : 0; return DMT_OK; }
+extern "C" int dmt_get_deterministic(void) { return g_deterministic; }
 extern "C" int dmt_version(void) { return 1; }
 extern "C" const char* dmt_build_arch(void) { return "gfx950"; }
 

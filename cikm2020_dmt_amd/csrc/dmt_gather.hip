@@ -334,10 +334,14 @@ __global__ __launch_bounds__(256) void finish_heads_kernel(const uint32_t* __res
 //            four consecutive entries are issued together before they are consumed (the chunk is otherwise a chain of
 //            dependent L2/HBM round trips).  Runs of equal rows are summed in registers and flushed with ONE fp32
 //            atomicAdd per element; only runs that cross a chunk boundary meet another wave's partial.
-template <typename GT_>
+// DET (deterministic mode): the first / last run of a chunk go to a side buffer instead of meeting their neighbours in an atomicAdd;
+// boundary_fixup_kernel then sums the pieces of every such run in chunk order.
+//   part [chunk][2][max_dim] fp32, pseg [chunk][2] int (run id, -1: none); slot 0 = first run of the chunk, slot 1 = its last run
+template <typename GT_, bool DET>
 __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_desc d, const uint32_t* __restrict__ skeys,
                                                              const uint32_t* __restrict__ svals, const int* __restrict__ seg,
-                                                             long long n, float* __restrict__ grad_rows, int max_dim) {
+                                                             long long n, float* __restrict__ grad_rows, int max_dim,
+                                                             float* __restrict__ part, int* __restrict__ pseg) {
   __shared__ int s_base[DMT_MAX_FEATURES + 1];
   if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
   __syncthreads();
@@ -401,10 +405,19 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_xor(last_seg, o, 64); last_seg = t2 > last_seg ? t2 : last_seg; }   // run ids ascend
   float acc = 0.f;
   int cur_seg = -1, cur_dim = 0;
+  if constexpr (DET) {
+    if (lane < 2) pseg[wave * 2 + lane] = (lane == 0) ? first_seg : (last_seg != first_seg ? last_seg : -1);
+    if (lane < max_dim) { part[(wave * 2) * max_dim + lane] = 0.f; part[(wave * 2 + 1) * max_dim + lane] = 0.f; }
+  }
   auto flush = [&]() {
     if (cur_seg < 0 || lane >= cur_dim) return;
     float* dst = &grad_rows[(long long)cur_seg * max_dim + lane];
-    if (cur_seg == first_seg || cur_seg == last_seg) atomicAdd(dst, acc); else *dst = acc;
+    if (cur_seg == first_seg || cur_seg == last_seg) {
+      if constexpr (DET) part[(wave * 2 + (cur_seg == first_seg ? 0 : 1)) * max_dim + lane] = acc;
+      else atomicAdd(dst, acc);
+    } else {
+      *dst = acc;
+    }
   };
   constexpr int NBATCH = 4;   // gathers in flight per wave (8 measured the same)
   for (int i0 = 0; i0 < cnt; i0 += NBATCH) {
@@ -442,11 +455,11 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   flush();
 }
 
-template <typename RT>
+template <typename RT, bool DET>
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
                                                           const int* __restrict__ seg, long long n, uint32_t invalid,
                                                           const RT* __restrict__ in_rows, float* __restrict__ out_rows,
-                                                          int max_dim) {
+                                                          int max_dim, float* __restrict__ part, int* __restrict__ pseg) {
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long e0 = wave * 64;
@@ -463,6 +476,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
   int last_seg = my_seg;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_xor(last_seg, o, 64); last_seg = t > last_seg ? t : last_seg; }   // segment ids ascend
+  if constexpr (DET) {
+    if (lane < 2) pseg[wave * 2 + lane] = (lane == 0) ? first_seg : (last_seg != first_seg ? last_seg : -1);
+    for (int j = lane; j < 2 * max_dim; j += 64) part[wave * 2 * max_dim + j] = 0.f;
+  }
   for (int j0 = 0; j0 < max_dim; j0 += 64) {
     const int j = j0 + lane;
     float acc = 0.f;
@@ -470,7 +487,12 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
     auto flush = [&]() {
       if (cur_seg < 0 || j >= max_dim) return;
       float* dst = &out_rows[(long long)cur_seg * max_dim + j];
-      if (cur_seg == first_seg || cur_seg == last_seg) atomicAdd(dst, acc); else *dst = acc;
+      if (cur_seg == first_seg || cur_seg == last_seg) {
+        if constexpr (DET) part[(wave * 2 + (cur_seg == first_seg ? 0 : 1)) * max_dim + j] = acc;
+        else atomicAdd(dst, acc);
+      } else {
+        *dst = acc;
+      }
     };
     // eight row loads in flight per wave (the entries are known up front; summing stays in sorted order)
     if (first_seg < 0) break;                                       // sorted: no valid entry in this chunk at all
@@ -500,6 +522,33 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
       }
     }
     flush();
+  }
+}
+
+// Deterministic mode, second pass: one wavefront per (chunk, slot) record.  The record that STARTS a run (no earlier record carries
+// the same run id) sums the run's pieces in chunk order and stores the row; all other records do nothing.
+__global__ __launch_bounds__(256) void boundary_fixup_kernel(const float* __restrict__ part, const int* __restrict__ pseg, long long n_chunks,
+                                                             float* __restrict__ rows, int max_dim) {
+  const int lane = threadIdx.x & 63;
+  const long long rec = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rec >= 2 * n_chunks) return;
+  const long long c = rec >> 1;
+  const int w = (int)(rec & 1);
+  const int s = pseg[rec];
+  if (s < 0) return;
+  if (w == 0 && c > 0) {
+    const int p1 = pseg[(c - 1) * 2 + 1], p0 = pseg[(c - 1) * 2];
+    if ((p1 >= 0 ? p1 : p0) == s) return;                 // the run began in an earlier chunk
+  }
+  const bool open_end = (w == 1) || (pseg[c * 2 + 1] < 0);   // the run reaches the end of chunk c (slot 0 of a one-run chunk does too)
+  for (int j = lane; j < max_dim; j += 64) {
+    float acc = part[rec * max_dim + j];
+    if (open_end)
+      for (long long k = c + 1; k < n_chunks && pseg[k * 2] == s; ++k) {
+        acc += part[(k * 2) * max_dim + j];
+        if (pseg[k * 2 + 1] >= 0) break;                   // chunk k has a second run: this one ended there
+      }
+    rows[(long long)s * max_dim + j] = acc;
   }
 }
 
@@ -683,8 +732,20 @@ extern "C" int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_
   return DMT_OK;
 }
 
+static int det_ws_check(int64_t n, int32_t max_dim, void* ws, uint64_t ws_bytes, const char* who) {
+  DMT_CHECK_ARG(ws != nullptr && ws_bytes >= dmt_reduce_det_ws_bytes(n, max_dim) && (((uintptr_t)ws) & 15) == 0,
+                "%s: deterministic mode needs a 16-byte aligned workspace of dmt_reduce_det_ws_bytes(n, max_dim) bytes", who);
+  return DMT_OK;
+}
+
+extern "C" uint64_t dmt_reduce_det_ws_bytes(int64_t n, int32_t max_dim) {
+  const uint64_t chunks = (uint64_t)cdiv64(n > 0 ? n : 1, 64);
+  return chunks * 2 * ((uint64_t)max_dim * 4 + 4) + 64;
+}
+
 extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
-                                  const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream) {
+                                  const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* det_ws, uint64_t det_ws_bytes,
+                                  void* stream) {
   DMT_CHECK_ARG(d && sorted_keys && sorted_vals && seg_id && grad_rows, "dmt_embgrad_reduce: null argument");
   DMT_CHECK_ARG(max_dim > 0 && max_dim <= 64, "dmt_embgrad_reduce: max_dim must be in [1,64]");
   for (int f = 0; f < d->n_features; ++f) {
@@ -692,14 +753,29 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
     DMT_CHECK_ARG(d->feat[f].pooled_off < 0 || d->feat[f].inv_wsum != nullptr, "dmt_embgrad_reduce: feature %d lacks inv_wsum", f);
   }
   if (n == 0) return DMT_OK;
-  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
+  const long long chunks = cdiv64(n, 64);
+  const unsigned nb = (unsigned)cdiv64(chunks, 4);
   hipStream_t st = (hipStream_t)stream;
+  if (dmt_deterministic()) {
+    if (det_ws_check(n, max_dim, det_ws, det_ws_bytes, "dmt_embgrad_reduce") != DMT_OK) return DMT_ERR_ARG;
+    float* part = (float*)det_ws;
+    int* pseg = (int*)(part + chunks * 2 * max_dim);
+    if (d->grad_dtype == DMT_F32)
+      hipLaunchKernelGGL((embgrad_reduce_kernel<float, true>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                         (long long)n, grad_rows, max_dim, part, pseg);
+    else
+      hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                         (long long)n, grad_rows, max_dim, part, pseg);
+    hipLaunchKernelGGL(boundary_fixup_kernel, dim3((unsigned)cdiv64(2 * chunks, 4)), dim3(256), 0, st, part, pseg, chunks, grad_rows, max_dim);
+    DMT_CHECK_LAUNCH("dmt_embgrad_reduce(deterministic)");
+    return DMT_OK;
+  }
   if (d->grad_dtype == DMT_F32)
-    hipLaunchKernelGGL((embgrad_reduce_kernel<float>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
-                       (long long)n, grad_rows, max_dim);
+    hipLaunchKernelGGL((embgrad_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                       (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
   else
-    hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
-                       (long long)n, grad_rows, max_dim);
+    hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                       (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
   DMT_CHECK_LAUNCH("dmt_embgrad_reduce");
   return DMT_OK;
 }
@@ -726,26 +802,43 @@ extern "C" int dmt_zero_rows(float* rows, const int32_t* n_rows, int64_t extra, 
   return DMT_OK;
 }
 
-extern "C" int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
-                               uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream) {
-  DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows && out_rows, "dmt_rows_reduce: null argument");
-  if (n == 0) return DMT_OK;
-  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
-  hipLaunchKernelGGL((rows_reduce_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
-                     (long long)n, invalid_key, in_rows, out_rows, max_dim);
-  DMT_CHECK_LAUNCH("dmt_rows_reduce");
+template <typename RT>
+static int rows_reduce_launch(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n, uint32_t invalid_key,
+                              const RT* in_rows, float* out_rows, int32_t max_dim, void* det_ws, uint64_t det_ws_bytes, hipStream_t st,
+                              const char* who) {
+  const long long chunks = cdiv64(n, 64);
+  const unsigned nb = (unsigned)cdiv64(chunks, 4);
+  if (dmt_deterministic()) {
+    if (det_ws_check(n, max_dim, det_ws, det_ws_bytes, who) != DMT_OK) return DMT_ERR_ARG;
+    float* part = (float*)det_ws;
+    int* pseg = (int*)(part + chunks * 2 * max_dim);
+    hipLaunchKernelGGL((rows_reduce_kernel<RT, true>), dim3(nb), dim3(256), 0, st, sorted_keys, sorted_vals, seg_id, (long long)n, invalid_key,
+                       in_rows, out_rows, max_dim, part, pseg);
+    hipLaunchKernelGGL(boundary_fixup_kernel, dim3((unsigned)cdiv64(2 * chunks, 4)), dim3(256), 0, st, part, pseg, chunks, out_rows, max_dim);
+  } else {
+    hipLaunchKernelGGL((rows_reduce_kernel<RT, false>), dim3(nb), dim3(256), 0, st, sorted_keys, sorted_vals, seg_id, (long long)n, invalid_key,
+                       in_rows, out_rows, max_dim, (float*)nullptr, (int*)nullptr);
+  }
+  DMT_CHECK_LAUNCH(who);
   return DMT_OK;
 }
 
+extern "C" int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
+                               uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* det_ws,
+                               uint64_t det_ws_bytes, void* stream) {
+  DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows && out_rows, "dmt_rows_reduce: null argument");
+  if (n == 0) return DMT_OK;
+  return rows_reduce_launch<float>(sorted_keys, sorted_vals, seg_id, n, invalid_key, in_rows, out_rows, max_dim, det_ws, det_ws_bytes,
+                                   (hipStream_t)stream, "dmt_rows_reduce");
+}
+
 extern "C" int dmt_rows_reduce_bf16(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
-                                    uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* stream) {
+                                    uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* det_ws,
+                                    uint64_t det_ws_bytes, void* stream) {
   DMT_CHECK_ARG(sorted_keys && sorted_vals && seg_id && in_rows_bf16 && out_rows, "dmt_rows_reduce_bf16: null argument");
   if (n == 0) return DMT_OK;
-  const unsigned nb = (unsigned)cdiv64(cdiv64(n, 64), 4);
-  hipLaunchKernelGGL((rows_reduce_kernel<bf16_t>), dim3(nb), dim3(256), 0, (hipStream_t)stream, sorted_keys, sorted_vals, seg_id,
-                     (long long)n, invalid_key, reinterpret_cast<const bf16_t*>(in_rows_bf16), out_rows, max_dim);
-  DMT_CHECK_LAUNCH("dmt_rows_reduce_bf16");
-  return DMT_OK;
+  return rows_reduce_launch<bf16_t>(sorted_keys, sorted_vals, seg_id, n, invalid_key, reinterpret_cast<const bf16_t*>(in_rows_bf16), out_rows,
+                                    max_dim, det_ws, det_ws_bytes, (hipStream_t)stream, "dmt_rows_reduce_bf16");
 }
 
 extern "C" int dmt_entry_slots(const dmt_embgrad_desc* d, const uint32_t* keys_sorted, const uint32_t* vals_sorted, const int32_t* seg,

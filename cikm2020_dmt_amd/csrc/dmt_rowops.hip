@@ -848,12 +848,13 @@ extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const 
                                float keep_prob, void* stream) {
   DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum_drop: bad argument");
   DMT_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "dmt_colsum_drop: keep_prob must be in (0, 1]");
-  const int rpb = 64;
+  const bool det = dmt_deterministic() != 0;        // one row block per column: a single, ordered sum (one atomicAdd onto the accumulator)
+  const int rpb = det ? (int)(rows < 0x7fffffff ? rows : 0x7fffffff) : 64;
   dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
   DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum_drop: too many rows");
   const uint32_t thr = (uint32_t)(keep_prob * 16777216.0f);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DMT_BF16 && cols % 8 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 256) {
+  if (!det && dtype == DMT_BF16 && cols % 8 == 0 && ((uintptr_t)x & 15) == 0 && rows >= 256) {
     const int rpb8 = 64;
     dim3 g8((unsigned)cdiv64(cols / 8, 64), (unsigned)cdiv64(rows, rpb8));
     DMT_CHECK_ARG(g8.y <= 65535, "dmt_colsum_drop: too many rows");
@@ -872,7 +873,7 @@ extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const 
 extern "C" int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
                           void* stream) {
   DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum: bad argument");
-  const int rpb = 64;
+  const int rpb = dmt_deterministic() ? (int)(rows < 0x7fffffff ? rows : 0x7fffffff) : 64;     // deterministic: one ordered sum per column
   dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
   DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum: too many rows");
   hipStream_t st = (hipStream_t)stream;

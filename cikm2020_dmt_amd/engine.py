@@ -668,8 +668,9 @@ class DMTEngine:
         grad_rows = self._buf("grad_rows", (prep["cap"], plan.max_dim), F32)
         # only the first n_uniq rows are accumulated into (segment ids are < n_uniq); the count lives on the device
         L.call("dmt_zero_rows", ops.p(grad_rows), ops.p(prep["n_uniq"]), 0, prep["cap"], plan.max_dim, ops.stream_ptr())
+        ws, wsb = ops.det_ws(n, plan.max_dim, self.store.device, "embgrad")
         L.call("dmt_embgrad_reduce", C.byref(desc), ops.p(prep["keys_s"]), ops.p(prep["vals_s"]), ops.p(prep["seg"]), n,
-               ops.p(grad_rows), plan.max_dim, ops.stream_ptr())
+               ops.p(grad_rows), plan.max_dim, ws, wsb, ops.stream_ptr())
         self.sparse = (prep["uniq"], prep["n_uniq"], grad_rows, prep["cap"])
 
     def sort_segments(self, keys, vals, keys_s, vals_s, n, tag=""):

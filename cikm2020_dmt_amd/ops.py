@@ -40,6 +40,29 @@ class _Timed:
         return False
 
 
+# Deterministic mode (DMT_DETERMINISTIC=1 or set_deterministic(True)): fixed-order reductions instead of fp32 atomics (include/dmt_hip.h)
+DETERMINISTIC = False
+_det_ws = {}
+
+
+def set_deterministic(on: bool):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    L.call("dmt_set_deterministic", 1 if on else 0)
+
+
+def det_ws(n: int, max_dim: int, device, tag=""):
+    """(pointer, bytes) of the workspace dmt_embgrad_reduce / dmt_rows_reduce* need in deterministic mode; (None, 0) otherwise."""
+    if not DETERMINISTIC:
+        return None, 0
+    need = int(L.load().dmt_reduce_det_ws_bytes(int(n), int(max_dim)))
+    t = _det_ws.get((tag, str(device)))
+    if t is None or t.numel() < need:
+        t = torch.empty(need, dtype=torch.uint8, device=device)
+        _det_ws[(tag, str(device))] = t
+    return t.data_ptr(), need
+
+
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -104,7 +127,7 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
 def _pick_split(tiles: int, red: int) -> int:
     """Split-K factor of a weight-gradient GEMM.  Splitting only pays while the output tiles alone cannot fill the 256 CUs:
     every extra split adds one fp32 atomic pass over the whole output (MMoE layer-0 dW, 25 MB: split 2 is 4x slower than 1)."""
-    if tiles >= 192:
+    if tiles >= 192 or DETERMINISTIC:      # (split-K partials meet in fp32 atomics)
         return 1
     s = max(1, min(1024 // max(tiles, 1), red // 512))
     return int(max(1, min(s, 512)))
@@ -203,7 +226,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     rows = K + 1 if want_bias else K
     tiles = ((rows + 127) // 128) * ((N + 127) // 128)
     split = _pick_split(tiles, M)
-    if (gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
+    if (not DETERMINISTIC and gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
             and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
             and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
         # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block
@@ -231,6 +254,18 @@ def relu_bwd_(dy, y, ncols=None):
     return dy
 
 
+def relu_bwd(dy, y, ncols=None):
+    """dz = dy * (y > 0) on the first ncols columns (the others pass through).  Never writes into dy (autograd owns it): all columns
+    gated -> ONE out-of-place launch; a partial gate copies first."""
+    rows, cols = dy.shape
+    n = cols if ncols is None else ncols
+    if n < cols:
+        return relu_bwd_(dy.clone(), y, n)
+    dz = torch.empty((rows, cols), dtype=dy.dtype, device=dy.device)
+    L.call("dmt_relu_bwd", dt_code(dy.dtype), rows, cols, p(dy), _row_major2d(dy, "dy"), p(y), _row_major2d(y, "y"), p(dz), cols, stream_ptr())
+    return dz
+
+
 class LinearFn(torch.autograd.Function):
     """y = relu?(x W + b) (+ resid), the op behind base.dense_layer / tf.layers.dense call sites."""
 
@@ -253,8 +288,8 @@ class LinearFn(torch.autograd.Function):
         if dz.dtype != x2.dtype:
             dz = dz.to(x2.dtype)
         if ctx.act_ncols > 0:
-            dz = relu_bwd_(dz.clone() if dz.data_ptr() == dy.data_ptr() else dz, y.to(dz.dtype) if y.dtype != dz.dtype else y,
-                           ctx.act_ncols)
+            yy = y.to(dz.dtype) if y.dtype != dz.dtype else y
+            dz = relu_bwd(dz, yy, ctx.act_ncols) if dz.data_ptr() == dy.data_ptr() else relu_bwd_(dz, yy, ctx.act_ncols)
         elif dz.stride(-1) != 1:
             dz = dz.contiguous()
         dx = linear_backward_input(dz, ctx.w) if ctx.needs_input_grad[0] else None
@@ -319,7 +354,7 @@ class ExpertLayerFn(torch.autograd.Function):
         M = x.shape[0]
         K, N = ws[0].f32.shape
         dz = dy.to(x.dtype) if dy.dtype != x.dtype else dy
-        dz = relu_bwd_(dz.clone() if dz.data_ptr() == dy.data_ptr() else dz, y, E * N)
+        dz = relu_bwd(dz, y, E * N) if dz.data_ptr() == dy.data_ptr() else relu_bwd_(dz, y, E * N)
         ldx, ldz = _row_major2d(x, "x"), _row_major2d(dz, "dz")
         # ---- dx_e = dz_e W_e^T
         dx = None
@@ -947,20 +982,24 @@ class LossUnbiasFn(torch.autograd.Function):
         loss = torch.empty((1,), dtype=F32, device=c.device)
         pc = torch.empty((Bn,), dtype=F32, device=c.device)
         pv = torch.empty((Bn,), dtype=F32, device=c.device)
-        dc, do, db = (torch.empty((Bn,), dtype=F32, device=c.device) for _ in range(3))
+        dall = torch.empty((3, Bn), dtype=F32, device=c.device)       # one buffer: the backward scales all three with one launch
+        dc, do, db = dall[0], dall[1], dall[2]
         L.call("dmt_loss_unbias", Bn, p(c), p(o), p(yb), p(mask5), p(w_ctr), p(w_ecvr), float(lw[0]), float(lw[1]), int(method),
                int(ctr_rel), 1.0, p(loss), p(pc), p(pv), p(dc), p(do), p(db), stream_ptr())
-        ctx.save_for_backward(dc, do, db)
+        ctx.save_for_backward(dall)
         ctx.shapes = (click.shape, order.shape, ybias.shape, click.dtype, order.dtype, ybias.dtype)
         ctx.mark_non_differentiable(pc, pv)
+        ctx.set_materialize_grads(False)
         return loss.reshape(()), pc, pv
 
     @staticmethod
     def backward(ctx, gloss, _a, _b):
-        dc, do, db = ctx.saved_tensors
+        (dall,) = ctx.saved_tensors
         s0, s1, s2, t0, t1, t2 = ctx.shapes
-        return ((dc * gloss).reshape(s0).to(t0), (do * gloss).reshape(s1).to(t1), (db * gloss).reshape(s2).to(t2),
-                None, None, None, None, None, None)
+        if gloss is None:
+            return (None,) * 9
+        g = dall * gloss
+        return (g[0].reshape(s0).to(t0), g[1].reshape(s1).to(t1), g[2].reshape(s2).to(t2), None, None, None, None, None, None)
 
 
 class ScaleAddPosFn(torch.autograd.Function):

@@ -9,6 +9,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -66,6 +67,8 @@ class Trainer:
         # run the data-parallel exchange even in a one-rank group (a one-GPU box can still push the real RCCL calls of the
         # N-rank step through a 1-rank communicator: tests/test_gpu_dp.py)
         self.force_dp = bool(force_dp)
+        if os.environ.get("DMT_DETERMINISTIC") == "1" and not ops.DETERMINISTIC:
+            ops.set_deterministic(True)
         self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
 
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
@@ -224,8 +227,9 @@ class Trainer:
         out_rows = eng._buf("m_rows", (rows_cap, D), torch.float32)
         if Rn > 0:
             L.call("dmt_zero_rows", ops.p(out_rows), ops.p(plan["n_uniq2"]), 0, rows_cap, D, ops.stream_ptr())
+            ws, wsb = ops.det_ws(Rn, D, recv_r.device, "rows")
             L.call("dmt_rows_reduce_bf16" if recv_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(plan["keys_s"]), ops.p(plan["vals_s"]),
-                   ops.p(plan["seg"]), Rn, st.total_rows, ops.p(recv_r), ops.p(out_rows), D, ops.stream_ptr())
+                   ops.p(plan["seg"]), Rn, st.total_rows, ops.p(recv_r), ops.p(out_rows), D, ws, wsb, ops.stream_ptr())
         if sharded:
             return (plan["uniq2"], plan["n_uniq2"], out_rows, Rn)
         cap_m = plan["cap_m"]
@@ -337,8 +341,9 @@ class Trainer:
         capm = min(N, st.total_rows)
         out_rows = eng._buf("m_rows", (capm, grad_rows.shape[1]), torch.float32)
         L.call("dmt_zero_rows", ops.p(out_rows), ops.p(n_uniq2), 0, capm, int(grad_rows.shape[1]), ops.stream_ptr())
+        ws, wsb = ops.det_ws(N, int(grad_rows.shape[1]), all_r.device, "rows")
         L.call("dmt_rows_reduce_bf16" if all_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(keys_s), ops.p(vals_s), ops.p(seg), N,
-               st.total_rows, ops.p(all_r), ops.p(out_rows), int(grad_rows.shape[1]), ops.stream_ptr())
+               st.total_rows, ops.p(all_r), ops.p(out_rows), int(grad_rows.shape[1]), ws, wsb, ops.stream_ptr())
         return (uniq2, n_uniq2, out_rows, capm)
 
     def train_step(self, batch: DeviceBatch):

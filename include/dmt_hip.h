@@ -155,8 +155,21 @@ int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_k
  * The slices slots[entry_base[f] ...] are the idx / idx_seq columns of dmt_gather_feature in its row-cache form.                  */
 int dmt_entry_slots(const dmt_embgrad_desc* d, const uint32_t* keys_sorted, const uint32_t* vals_sorted, const int32_t* seg,
                     const int32_t* slot_of_row, int64_t n, int32_t* slots, void* stream);
+/* Deterministic mode (process-wide switch).  By default partial sums that meet in one output element are combined with fp32
+ * atomics -- their order, hence the last bits, depends on scheduling.  With the switch on, the segmented reductions
+ * (dmt_embgrad_reduce, dmt_rows_reduce*) route the runs that cross a 64-entry chunk through a workspace and add the pieces in chunk
+ * order, column sums use one ordered pass per column; callers then also avoid split-K GEMMs and dmt_wgrad320 (both refuse).  Results
+ * are bit-reproducible from run to run (tests/test_gpu_deterministic.py); they equal the default mode's to fp32 rounding.
+ * det_ws / det_ws_bytes: workspace of dmt_reduce_det_ws_bytes(n, max_dim) bytes, 16-byte aligned; ignored (may be NULL) when the
+ * switch is off.  The reference's counterpart is TF's own non-deterministic unsorted_segment_sum / atomics on GPU; on CPU (the
+ * reference run: run_dnn.py:45-80) the order is fixed. */
+int dmt_set_deterministic(int32_t on);
+int dmt_get_deterministic(void);
+uint64_t dmt_reduce_det_ws_bytes(int64_t n, int32_t max_dim);
+
 int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
-                       const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* stream);
+                       const int32_t* seg_id, int64_t n, float* grad_rows, int32_t max_dim, void* det_ws, uint64_t det_ws_bytes,
+                       void* stream);
 
 /* rows[0 : min(n_rows[0] + extra, max_rows), 0 : row_elems] = 0 with the row count read ON THE DEVICE (the number of distinct rows
  * of a step is only known there): clears what the reduce kernels will accumulate into instead of the whole capacity. */
@@ -165,10 +178,12 @@ int dmt_zero_rows(float* rows, const int32_t* n_rows, int64_t extra, int64_t max
 /* Same reduction for already-materialised rows (data-parallel merge of per-rank sparse gradients):
  * out_rows[seg_id[e]] += in_rows[sorted_vals[e]].                                                    */
 int dmt_rows_reduce(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
-                    uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* stream);
+                    uint32_t invalid_key, const float* in_rows, float* out_rows, int32_t max_dim, void* det_ws, uint64_t det_ws_bytes,
+                    void* stream);
 /* The same with bf16 in_rows (the transport format of the data-parallel exchange in bf16 mode; the sum stays fp32). */
 int dmt_rows_reduce_bf16(const uint32_t* sorted_keys, const uint32_t* sorted_vals, const int32_t* seg_id, int64_t n,
-                         uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* stream);
+                         uint32_t invalid_key, const void* in_rows_bf16, float* out_rows, int32_t max_dim, void* det_ws,
+                         uint64_t det_ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMM with fused epilogue:  C[m,n] = epi( sum_k A(m,k) * B(k,n) ),  A(m,k) = A[m*a_rs + k*a_cs],

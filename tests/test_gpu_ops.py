@@ -183,7 +183,7 @@ def test_rows_reduce_bf16_matches_fp32_reduce_of_rounded_rows(cuda):
     rows = torch.randn(N, D, device=dev)
     rows_lp = rows.to(torch.bfloat16).contiguous()
     out = torch.zeros(len(uniq), D, device=dev)
-    L.call("dmt_rows_reduce_bf16", ops.p(skeys), ops.p(svals), ops.p(seg), N, R, ops.p(rows_lp), ops.p(out), D, ops.stream_ptr())
+    L.call("dmt_rows_reduce_bf16", ops.p(skeys), ops.p(svals), ops.p(seg), N, R, ops.p(rows_lp), ops.p(out), D, None, 0, ops.stream_ptr())
     ref = torch.zeros(len(uniq), D, device=dev)
     valid = skeys < R
     ref.index_add_(0, inv[valid], rows_lp.float()[order][valid])
