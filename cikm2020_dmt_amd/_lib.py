@@ -64,6 +64,14 @@ class AttnBwdDesc(C.Structure):
                 ("dv_rs", c_i64)]
 
 
+class MmoeDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("E", c_i32), ("T", c_i32), ("u0", c_i32), ("u1", c_i32), ("u2", c_i32), ("g1", c_vp), ("ldg", c_i64),
+                ("w1t", c_vp), ("w1t_expert_stride", c_i64), ("w1t_ld", c_i64), ("w2t", c_vp), ("w2t_expert_stride", c_i64), ("w2t_ld", c_i64),
+                ("w1", c_vp), ("w1_expert_stride", c_i64), ("w2", c_vp), ("w2_expert_stride", c_i64),
+                ("b1", c_vp), ("b1_expert_stride", c_i64), ("b2", c_vp), ("b2_expert_stride", c_i64),
+                ("h1", c_vp), ("h2", c_vp), ("gates", c_vp), ("mix", c_vp), ("dmix", c_vp), ("dh1", c_vp), ("dh2", c_vp), ("dg1", c_vp), ("lddg", c_i64)]
+
+
 class CastJob(C.Structure):
     _fields_ = [("src", c_vp), ("dst_plain", c_vp), ("dst_t", c_vp), ("ld_src", c_i64), ("ld_plain", c_i64), ("ld_t", c_i64),
                 ("rows", c_i32), ("cols", c_i32), ("tile_begin", c_i32), ("tiles_x", c_i32)]
@@ -110,6 +118,8 @@ _SIGS = {
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_attn_long_fwd": [C.POINTER(AttnDesc), c_vp],
+    "dmt_mmoe_experts_fwd": [C.POINTER(MmoeDesc), c_vp],
+    "dmt_mmoe_experts_bwd": [C.POINTER(MmoeDesc), c_vp],
     "dmt_attn_long_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_ln_fwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp],
     "dmt_ln_bwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
@@ -150,7 +160,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported",
-                                                 "dmt_attn_long_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
 
 _lib = None
 
@@ -177,6 +187,8 @@ def load():
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
+    lib.dmt_mmoe_experts_supported.restype = c_i32
+    lib.dmt_mmoe_experts_supported.argtypes = [c_i32] * 5
     lib.dmt_get_deterministic.restype = c_i32
     lib.dmt_get_deterministic.argtypes = []
     lib.dmt_reduce_det_ws_bytes.restype = C.c_uint64

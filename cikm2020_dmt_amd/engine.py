@@ -297,6 +297,7 @@ class DMTEngine:
         # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
 
     def gather_bytes(self, batch, seq_T) -> float:
@@ -489,6 +490,14 @@ class DMTEngine:
         g1 = ops.linear(zin, self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
                         self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0])
         # [B, E * u0]: the four experts' layer-0 outputs side by side | both gates' logits
+        if self.use_mmoe_fused and ops.mmoe_experts_supported(units, E, T, g1.dtype):
+            # fused expert-MLP + gate kernels: layers 1-2 of every expert, the gate softmaxes and the mixtures in one launch
+            names = [["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)] for li in (1, 2)]
+            mix, gates = ops.MmoeExpertsFn.apply(g1, [self._w(n + "weights") for n in names[0]], [self._w(n + "weights") for n in names[1]],
+                                                 [self._lf(n + "weights") for n in names[0]], [self._lf(n + "biases") for n in names[0]],
+                                                 [self._lf(n + "weights") for n in names[1]], [self._lf(n + "biases") for n in names[1]], E, T)
+            self.intermediates["gates"] = gates
+            return list(ops.Unbind0Fn.apply(mix))
         expert, glogit = ops.split_cols(g1, 0, E * units[0], E * units[0], E * units[0] + T * E)
         for li in range(1, len(units)):
             nms = ["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)]

@@ -973,6 +973,77 @@ class MixFn(torch.autograd.Function):
         return dexp, dgl, None, None, None
 
 
+def mmoe_experts_supported(units, E, T, dtype):
+    return dtype == BF16 and len(units) == 3 and bool(L.load().dmt_mmoe_experts_supported(int(units[0]), int(units[1]), int(units[2]), int(E), int(T)))
+
+
+class MmoeExpertsFn(torch.autograd.Function):
+    """(mix [T, B, u2], gates [T, B, E]) from g1 [B, E*u0 + T*E] (the experts' relu'd layer-0 outputs | the gates' logits): expert layers 1
+    and 2, the gate softmaxes and the mixtures in ONE launch (dmt_mmoe_experts_fwd); backward: one launch for the gradient of all of
+    g1 (dmt_mmoe_experts_bwd) + the two batched weight-gradient GEMMs.  expert_gate, mmoe_transformer_unbias.py:63-105."""
+
+    @staticmethod
+    def forward(ctx, g1, ws1, ws2, wl1, bl1, wl2, bl2, E, T):
+        Bn = g1.shape[0]
+        u0, u1 = ws1[0].f32.shape
+        u2 = ws2[0].f32.shape[1]
+        dev = g1.device
+        s1t, s2t = _uniform_stride([w.lp_t for w in ws1]), _uniform_stride([w.lp_t for w in ws2])
+        s1p, s2p = _uniform_stride([w.lp for w in ws1]), _uniform_stride([w.lp for w in ws2])
+        sb1, sb2 = _uniform_stride(list(bl1)), _uniform_stride(list(bl2))
+        if None in (s1t, s2t, s1p, s2p, sb1, sb2):
+            raise RuntimeError("MmoeExpertsFn: the experts' weights must be equally spaced in the arenas")
+        d = L.MmoeDesc()
+        d.B, d.E, d.T, d.u0, d.u1, d.u2 = Bn, E, T, u0, u1, u2
+        d.g1, d.ldg = g1.data_ptr(), _row_major2d(g1, "g1")
+        d.w1t, d.w1t_expert_stride, d.w1t_ld = ws1[0].lp_t.data_ptr(), s1t, ws1[0].lp_t.stride(0)
+        d.w2t, d.w2t_expert_stride, d.w2t_ld = ws2[0].lp_t.data_ptr(), s2t, ws2[0].lp_t.stride(0)
+        d.w1, d.w1_expert_stride = ws1[0].lp.data_ptr(), s1p
+        d.w2, d.w2_expert_stride = ws2[0].lp.data_ptr(), s2p
+        d.b1, d.b1_expert_stride, d.b2, d.b2_expert_stride = bl1[0].data_ptr(), sb1, bl2[0].data_ptr(), sb2
+        h1 = torch.empty((Bn, E * u1), dtype=BF16, device=dev)
+        h2 = torch.empty((Bn, E * u2), dtype=BF16, device=dev)
+        gates = torch.empty((T, Bn, E), dtype=F32, device=dev)
+        mix = torch.empty((T, Bn, u2), dtype=BF16, device=dev)
+        d.h1, d.h2, d.gates, d.mix = h1.data_ptr(), h2.data_ptr(), gates.data_ptr(), mix.data_ptr()
+        with _Timed("mmoe_experts", 2.0 * Bn * E * (u0 * u1 + u1 * u2)):
+            L.call("dmt_mmoe_experts_fwd", C.byref(d), stream_ptr())
+        ctx.desc = d
+        ctx.leaves = (tuple(wl1), tuple(bl1), tuple(wl2), tuple(bl2))
+        ctx.dims = (E, T, u0, u1, u2)
+        ctx.save_for_backward(g1, h1, h2, gates)
+        ctx.mark_non_differentiable(gates)
+        ctx.set_materialize_grads(False)
+        return mix, gates
+
+    @staticmethod
+    def backward(ctx, dmix, _dgates):
+        g1, h1, h2, gates = ctx.saved_tensors
+        E, T, u0, u1, u2 = ctx.dims
+        wl1, bl1, wl2, bl2 = ctx.leaves
+        Bn = g1.shape[0]
+        dmix = dmix.contiguous()
+        d = ctx.desc
+        dh1, dh2 = torch.empty_like(h1), torch.empty_like(h2)
+        dg1 = torch.empty((Bn, g1.shape[1]), dtype=BF16, device=g1.device)
+        d.dmix, d.dh1, d.dh2, d.dg1, d.lddg = dmix.data_ptr(), dh1.data_ptr(), dh2.data_ptr(), dg1.data_ptr(), dg1.stride(0)
+        with _Timed("mmoe_experts", 2.0 * Bn * E * (u0 * u1 + u1 * u2)):
+            L.call("dmt_mmoe_experts_bwd", C.byref(d), stream_ptr())
+        # dW_e += x_e^T dz_e, db_e += colsum(dz_e), straight into the gradient arena: one batched GEMM per layer
+        for (x, ldx, K, dz, N, wls, bls) in ((g1, g1.stride(0), u0, dh1, u1, wl1, bl1), (h1, h1.stride(0), u1, dh2, u2, wl2, bl2)):
+            gws, gbs = [_grad_view(l) for l in wls], [_grad_view(l) for l in bls]
+            if any(g is None for g in gws) or any(g is None for g in gbs):
+                raise RuntimeError("MmoeExpertsFn: parameter leaves without an in-place gradient view are not supported")
+            sg, sgb = _uniform_stride(gws), _uniform_stride(gbs)
+            if sg is None or sgb is None:
+                raise RuntimeError("MmoeExpertsFn: the experts' gradient views must be equally spaced")
+            rows = K + 1
+            tiles = E * ((rows + 127) // 128) * ((N + 127) // 128)
+            gemm(x, 1, ldx, dz, dz.stride(0), 1, rows, N, Bn, gws[0], gws[0].stride(0), ones_row=True, c_last=gbs[0], split_k=_pick_split(tiles, Bn),
+                 accumulate=True, batch=E, a_bs=K, b_bs=N, c_bs=sg, clast_bs=sgb)
+        return dg1, None, None, None, None, None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class LossUnbiasFn(torch.autograd.Function):
     @staticmethod

@@ -517,6 +517,41 @@ int dmt_confusion_counts(int32_t B, const float* pred, const float* label, float
 int dmt_l2_unique_rows(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows, int32_t dim,
                        uint32_t* seen, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused expert-MLP + gate kernels of the MMoE bottom (bf16; expert widths 512 -> 256 -> 128).
+ *   g1 [B, E*512 + T*E]: relu'd layer-0 outputs of the E experts side by side | the T gates' logits (the output of the one
+ *   concatenated layer-0 GEMM).
+ *   forward : h1_e = relu(x_e W1_e + b1_e), h2_e = relu(h1_e W2_e + b2_e), gates[t] = softmax_e(logits[t]),
+ *             mix[t] = sum_e gates[t][:, e] * h2_e                                       (one launch)
+ *   backward: d mix -> dg1 (gradient of ALL columns of g1: expert inputs and gate logits), plus dh1 / dh2, the operands of the
+ *             weight-gradient GEMMs dW1_e = x_e^T dh1_e, dW2_e = h1_e^T dh2_e            (one launch)
+ * Weights are read from their bf16 shadows: transposed [E][N][ld] (k-contiguous) in the forward pass, plain [E][K][N] in the
+ * backward pass; per-expert strides in elements.
+ * Replaces: expert_gate's dense_layer stack for layers >= 1, the gate softmax and the weighted sum
+ *           (mmoe_transformer_unbias.py:63-105; base.dense_layer base.py:58-70).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, E, T;             /* rows, experts, tasks (T <= 4, T*E <= 16) */
+  int32_t u0, u1, u2;          /* 512, 256, 128 */
+  const void* g1; int64_t ldg;
+  const void* w1t; int64_t w1t_expert_stride, w1t_ld;     /* [E][u1][ld >= u0] bf16 */
+  const void* w2t; int64_t w2t_expert_stride, w2t_ld;     /* [E][u2][ld >= u1] bf16 */
+  const void* w1; int64_t w1_expert_stride;               /* [E][u0][u1] bf16 (backward) */
+  const void* w2; int64_t w2_expert_stride;               /* [E][u1][u2] bf16 (backward) */
+  const float* b1; int64_t b1_expert_stride;              /* [E][u1] fp32 */
+  const float* b2; int64_t b2_expert_stride;              /* [E][u2] fp32 */
+  void* h1; void* h2;          /* [B, E*u1], [B, E*u2] bf16: written by forward, read by backward */
+  float* gates;                /* [T, B, E] fp32: written by forward, read by backward */
+  void* mix;                   /* [T, B, u2] bf16 (forward) */
+  const void* dmix;            /* [T, B, u2] bf16 (backward) */
+  void* dh1; void* dh2;        /* [B, E*u1], [B, E*u2] bf16 (backward) */
+  void* dg1; int64_t lddg;     /* [B, >= E*u0 + T*E] bf16 (backward) */
+} dmt_mmoe_desc;
+
+int dmt_mmoe_experts_supported(int32_t u0, int32_t u1, int32_t u2, int32_t E, int32_t T);
+int dmt_mmoe_experts_fwd(const dmt_mmoe_desc* d, void* stream);
+int dmt_mmoe_experts_bwd(const dmt_mmoe_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
