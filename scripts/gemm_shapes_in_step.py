@@ -17,9 +17,21 @@ def spy(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, **kw):
            "split%d" % kw.get("split_k", 1), "bias" if kw.get("bias") is not None else "", "relu" if kw.get("act_ncols") else "", "resid" if kw.get("resid") is not None else "",
            "gate" if kw.get("gate") is not None else "")
     seen[key] += 1
-    return orig(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = orig(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, **kw)
+    e1.record()
+    evs.setdefault(key, []).append((e0, e1))
+    return r
+evs = {}
 ops.gemm = spy
 b._prep = None
 tr.train_step(b)
-for k, n in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[0][3]):
-    print(n, k)
+torch.cuda.synchronize()
+tot = 0.0
+for k, n in sorted(seen.items(), key=lambda kv: -sum(a.elapsed_time(b) for a, b in evs[kv[0]])):
+    t = sum(a.elapsed_time(b) for a, b in evs[k])
+    tot += t
+    fl = 2.0 * k[0] * k[1] * k[2] * k[3] * n
+    print("%2d x %-90s %7.1f us total  %6.1f TF/s" % (n, str(k), t * 1e3, fl / (t * 1e-3) / 1e12 if t > 0 else 0))
+print("all dmt_gemm launches: %.3f ms" % tot)
