@@ -72,6 +72,14 @@ class MmoeDesc(C.Structure):
                 ("h1", c_vp), ("h2", c_vp), ("gates", c_vp), ("mix", c_vp), ("dmix", c_vp), ("dh1", c_vp), ("dh2", c_vp), ("dg1", c_vp), ("lddg", c_i64)]
 
 
+class HeadsDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("u_in", c_i32), ("u_fc", c_i32), ("b_in", c_i32), ("b_h0", c_i32), ("b_h1", c_i32),
+                ("mix", c_vp), ("zb", c_vp), ("ld_zb", c_i64), ("fc_w", c_vp * 2), ("fc_b", c_vp * 2), ("out_w", c_vp * 2), ("out_b", c_vp * 2),
+                ("bias_w", c_vp * 3), ("bias_b", c_vp * 3), ("drop_seed", C.c_uint32 * 2), ("drop_keep", c_f32 * 2),
+                ("logits", c_vp), ("h_fc", c_vp), ("h0", c_vp), ("h1", c_vp), ("dlogits", c_vp), ("dmix", c_vp), ("dzb", c_vp), ("ld_dzb", c_i64),
+                ("dz_fc", c_vp), ("dz0", c_vp), ("dz1", c_vp), ("g_out_w", c_vp * 2), ("g_out_b", c_vp * 2), ("g_bias_w2", c_vp), ("g_bias_b2", c_vp)]
+
+
 class CastJob(C.Structure):
     _fields_ = [("src", c_vp), ("dst_plain", c_vp), ("dst_t", c_vp), ("ld_src", c_i64), ("ld_plain", c_i64), ("ld_t", c_i64),
                 ("rows", c_i32), ("cols", c_i32), ("tile_begin", c_i32), ("tiles_x", c_i32)]
@@ -118,6 +126,8 @@ _SIGS = {
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_attn_long_fwd": [C.POINTER(AttnDesc), c_vp],
+    "dmt_heads_fwd": [C.POINTER(HeadsDesc), c_vp],
+    "dmt_heads_bwd": [C.POINTER(HeadsDesc), c_vp],
     "dmt_mmoe_experts_fwd": [C.POINTER(MmoeDesc), c_vp],
     "dmt_mmoe_experts_bwd": [C.POINTER(MmoeDesc), c_vp],
     "dmt_attn_long_bwd": [C.POINTER(AttnBwdDesc), c_vp],
@@ -160,7 +170,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported",
-                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
 
 _lib = None
 
@@ -187,6 +197,8 @@ def load():
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
+    lib.dmt_heads_supported.restype = c_i32
+    lib.dmt_heads_supported.argtypes = [c_i32] * 6
     lib.dmt_mmoe_experts_supported.restype = c_i32
     lib.dmt_mmoe_experts_supported.argtypes = [c_i32] * 5
     lib.dmt_get_deterministic.restype = c_i32

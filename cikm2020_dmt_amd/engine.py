@@ -282,6 +282,11 @@ class AssembleFn(torch.autograd.Function):
         return (dz, None, None, *[dz[:, off + s * d: off + (s + 1) * d] for s in range(ctx.n)])
 
 
+def sp_units(spec):
+    """(width of a task tower's input = the experts' last layer,)"""
+    return (spec["hidden_units_bottom"][-1],)
+
+
 # ------------------------------------------------------------------------------------------------ engine
 class DMTEngine:
     def __init__(self, spec: dict, store: VariableStore):
@@ -297,6 +302,7 @@ class DMTEngine:
         # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
 
@@ -482,7 +488,8 @@ class DMTEngine:
         self.intermediates["zbuf"] = z
         return z
 
-    def expert_gate(self, z):
+    def expert_gate(self, z, want_mix=False):
+        """Per-task mixtures; want_mix: as ONE [T, B, U] tensor (for heads()), else a list of [B, U] (reference shape)."""
         sp = self.spec
         E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
         K = self.plan.K
@@ -497,7 +504,7 @@ class DMTEngine:
                                                  [self._lf(n + "weights") for n in names[0]], [self._lf(n + "biases") for n in names[0]],
                                                  [self._lf(n + "weights") for n in names[1]], [self._lf(n + "biases") for n in names[1]], E, T)
             self.intermediates["gates"] = gates
-            return list(ops.Unbind0Fn.apply(mix))
+            return mix if want_mix else list(ops.Unbind0Fn.apply(mix))
         expert, glogit = ops.split_cols(g1, 0, E * units[0], E * units[0], E * units[0] + T * E)
         for li in range(1, len(units)):
             nms = ["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)]
@@ -505,7 +512,24 @@ class DMTEngine:
                                       [self._lf(n + "biases") for n in nms])
         mix, gates = ops.MixFn.apply(expert, glogit, E, units[-1], T)
         self.intermediates["gates"] = gates
-        return list(ops.Unbind0Fn.apply(mix))
+        return mix if want_mix else list(ops.Unbind0Fn.apply(mix))
+
+    def heads(self, mix, z_bias):
+        """Task towers + position-bias tower in one launch (dmt_heads_fwd): ((click, order), y_bias), each [B, 1] fp32."""
+        sp = self.spec
+        towers = []
+        for name in ("click", "order")[: sp["num_tasks"]]:
+            f, o = "%s/%s-fc-0/" % (name, name), "%s/%s-output/" % (name, name)
+            towers.append((self._w(f + "weights"), self._lf(f + "weights"), self._lf(f + "biases"),
+                           self._w(o + "weights"), self._lf(o + "weights"), self._lf(o + "biases")))
+        bias = [(self._w("layer_bias%d/kernel" % l), self._lf("layer_bias%d/kernel" % l), self._lf("layer_bias%d/bias" % l)) for l in range(3)]
+        rates = sp.get("dropout_rate_bias", [0.0, 0.0])
+        drops = []
+        for l in range(2):
+            on = self.dropout_step_seed is not None and rates[l]
+            drops.append((ops.site_seed(self.dropout_step_seed, 100 + l), 1.0 - rates[l]) if on else (0, 1.0))
+        outs = ops.HeadsFn.apply(mix, z_bias, towers, bias, tuple(drops))
+        return tuple(outs[:-1]), outs[-1]
 
     def build_tower(self, x, name):
         sp = self.spec
@@ -538,6 +562,10 @@ class DMTEngine:
             z_main, z_bias = z[:, :plan.K], z[:, plan.bias_off: plan.bias_off + plan.bias_width]
         else:
             z_main, z_bias = ops.split_cols(z, 0, plan.K, plan.bias_off, plan.bias_off + plan.bias_width)
+        if self.use_heads_fused and ops.heads_supported(sp_units(self.spec)[0], self.spec["hidden_units_task"], plan.bias_width,
+                                                        self.spec["hidden_units_bias"], self.spec["num_tasks"], z.dtype):
+            mix = self.expert_gate(z_main, want_mix=True)
+            return self.heads(mix, z_bias)
         tasks = self.expert_gate(z_main)
         logits = tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         return logits, self.embedding_mlp_bias(z_bias)

@@ -1044,6 +1044,84 @@ class MmoeExpertsFn(torch.autograd.Function):
         return dg1, None, None, None, None, None, None, None, None
 
 
+def heads_supported(u_in, tower_units, bias_in, bias_units, T, dtype):
+    return (dtype == BF16 and not DETERMINISTIC and len(tower_units) == 1 and len(bias_units) == 2 and
+            bool(L.load().dmt_heads_supported(int(u_in), int(tower_units[0]), int(bias_in), int(bias_units[0]), int(bias_units[1]), int(T))))
+
+
+class HeadsFn(torch.autograd.Function):
+    """(click, order, y_bias) logits [B, 1] fp32 from mix [T, B, 128] and the bias tower's input zb [B, 20]: the T task towers
+    (build_tower, mmoe_transformer_unbias.py:107-126) and the position-bias tower (embedding_mlp_bias, :259-289) in ONE launch
+    (dmt_heads_fwd); backward one launch (dmt_heads_bwd: input gradients + the 1-wide layers' weight gradients) + the hidden layers'
+    weight-gradient GEMMs.  tower = [(fc Weight, fc w leaf, fc b leaf, out Weight, out w leaf, out b leaf)] per task; bias = three
+    (Weight, w leaf, b leaf); drops = ((seed, keep), (seed, keep)) of the bias tower's two dropout sites (keep 1.0: off)."""
+
+    @staticmethod
+    def forward(ctx, mix, zb, towers, bias, drops):
+        T, Bn, u_in = mix.shape
+        dev = mix.device
+        d = L.HeadsDesc()
+        d.B, d.T, d.u_in, d.u_fc = Bn, T, u_in, towers[0][0].f32.shape[1]
+        d.b_in, d.b_h0, d.b_h1 = bias[0][0].f32.shape[0], bias[0][0].f32.shape[1], bias[1][0].f32.shape[1]
+        mix = mix.contiguous()
+        d.mix, d.zb, d.ld_zb = mix.data_ptr(), zb.data_ptr(), _row_major2d(zb, "zb")
+        for t, (fw, _fwl, fbl, ow, _owl, obl) in enumerate(towers):
+            d.fc_w[t], d.fc_b[t], d.out_w[t], d.out_b[t] = fw.lp.data_ptr(), fbl.data_ptr(), ow.lp.data_ptr(), obl.data_ptr()
+        for l, (w, _wl, bl) in enumerate(bias):
+            d.bias_w[l], d.bias_b[l] = w.lp.data_ptr(), bl.data_ptr()
+        for l in range(2):
+            d.drop_seed[l], d.drop_keep[l] = int(drops[l][0]), float(drops[l][1])
+        logits = torch.empty((T + 1, Bn), dtype=F32, device=dev)
+        h_fc = torch.empty((T, Bn, d.u_fc), dtype=BF16, device=dev)
+        h0 = torch.empty((Bn, d.b_h0), dtype=BF16, device=dev)
+        h1 = torch.empty((Bn, d.b_h1), dtype=BF16, device=dev)
+        d.logits, d.h_fc, d.h0, d.h1 = logits.data_ptr(), h_fc.data_ptr(), h0.data_ptr(), h1.data_ptr()
+        L.call("dmt_heads_fwd", C.byref(d), stream_ptr())
+        ctx.desc, ctx.towers, ctx.bias = d, towers, bias
+        ctx.save_for_backward(mix, zb, h_fc, h0, h1)
+        ctx.set_materialize_grads(False)
+        return tuple(logits[i].unsqueeze(1) for i in range(T + 1))
+
+    @staticmethod
+    def backward(ctx, *dls):
+        mix, zb, h_fc, h0, h1 = ctx.saved_tensors
+        d, towers, bias = ctx.desc, ctx.towers, ctx.bias
+        T, Bn, u_in = mix.shape
+        dev = mix.device
+        # the loss hands back three views of ONE [3, B] buffer (LossUnbiasFn.backward): use it in place when that is what arrived
+        if (all(g is not None and g.dtype == F32 and g.is_contiguous() for g in dls) and
+                all(dls[i].data_ptr() == dls[0].data_ptr() + 4 * Bn * i for i in range(T + 1))):
+            dl = dls[0]
+        else:
+            dl = torch.empty((T + 1, Bn), dtype=F32, device=dev)
+            for i, g in enumerate(dls):
+                if g is None:
+                    dl[i].zero_()
+                else:
+                    dl[i].copy_(g.reshape(-1))
+        dmix = torch.empty_like(mix)
+        dzb = torch.empty((Bn, d.b_in), dtype=BF16, device=dev)
+        dz_fc, dz0, dz1 = torch.empty_like(h_fc), torch.empty_like(h0), torch.empty_like(h1)
+        d.dlogits, d.dmix, d.dzb, d.ld_dzb = dl.data_ptr(), dmix.data_ptr(), dzb.data_ptr(), dzb.stride(0)
+        d.dz_fc, d.dz0, d.dz1 = dz_fc.data_ptr(), dz0.data_ptr(), dz1.data_ptr()
+        for t, (_fw, _fwl, _fbl, _ow, owl, obl) in enumerate(towers):
+            gw, gb = _grad_view(owl), _grad_view(obl)
+            if gw is None or gb is None:
+                raise RuntimeError("HeadsFn: parameter leaves without an in-place gradient view are not supported")
+            d.g_out_w[t], d.g_out_b[t] = gw.data_ptr(), gb.data_ptr()
+        gw2, gb2 = _grad_view(bias[2][1]), _grad_view(bias[2][2])
+        if gw2 is None or gb2 is None:
+            raise RuntimeError("HeadsFn: parameter leaves without an in-place gradient view are not supported")
+        d.g_bias_w2, d.g_bias_b2 = gw2.data_ptr(), gb2.data_ptr()
+        L.call("dmt_heads_bwd", C.byref(d), stream_ptr())
+        # hidden layers: dW += x^T dz, db += colsum(dz), accumulated into the gradient arena
+        for t, (_fw, fwl, fbl, _ow, _owl, _obl) in enumerate(towers):
+            linear_backward_weight(mix[t], dz_fc[t], want_bias=True, w_leaf=fwl, b_leaf=fbl)
+        linear_backward_weight(zb, dz0, want_bias=True, w_leaf=bias[0][1], b_leaf=bias[0][2])
+        linear_backward_weight(h0, dz1, want_bias=True, w_leaf=bias[1][1], b_leaf=bias[1][2])
+        return dmix, dzb, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class LossUnbiasFn(torch.autograd.Function):
     @staticmethod

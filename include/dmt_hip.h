@@ -552,6 +552,39 @@ int dmt_mmoe_experts_supported(int32_t u0, int32_t u1, int32_t u2, int32_t E, in
 int dmt_mmoe_experts_fwd(const dmt_mmoe_desc* d, void* stream);
 int dmt_mmoe_experts_bwd(const dmt_mmoe_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The heads in two launches (bf16): T task towers  mix[t] [128] -> relu(fc 32) -> 1 logit  (build_tower,
+ * mmoe_transformer_unbias.py:107-126) and the position-bias tower  20 -> relu(32) -> dropout -> relu(16) -> dropout -> 1
+ * (embedding_mlp_bias, :259-289).
+ *   forward : logits [T+1][B] fp32 (task logits, then y_bias) + saved activations h_fc, h0, h1 (h0 / h1 after dropout).
+ *   backward: dlogits [T+1][B] fp32 -> dmix, dzb, the pre-activation gradients dz_fc / dz0 / dz1 (operands of the weight-gradient
+ *             GEMMs of the hidden layers), and the weight / bias gradients of the three 1-wide output layers ACCUMULATED into
+ *             g_out_w / g_out_b / g_bias_w2 / g_bias_b2 (fp32 atomics; refuses in deterministic mode).
+ * Weights: bf16 plain shadows [K][N] row-major, fp32 biases.  Dropout: counter mask, index row * width + unit.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, T;                /* rows, task towers (<= 2) */
+  int32_t u_in, u_fc;          /* 128, 32 */
+  int32_t b_in, b_h0, b_h1;    /* 20, 32, 16 */
+  const void* mix;             /* [T][B][u_in] bf16 */
+  const void* zb; int64_t ld_zb;   /* [B][>= b_in] bf16 */
+  const void* fc_w[2]; const float* fc_b[2];
+  const void* out_w[2]; const float* out_b[2];
+  const void* bias_w[3]; const float* bias_b[3];
+  uint32_t drop_seed[2]; float drop_keep[2];     /* after bias-tower layers 0 and 1; keep >= 1 (or 0): off */
+  float* logits;               /* [T+1][B] */
+  void* h_fc; void* h0; void* h1;      /* [T][B][u_fc], [B][b_h0], [B][b_h1] bf16 */
+  const float* dlogits;        /* [T+1][B] (backward) */
+  void* dmix;                  /* [T][B][u_in] bf16 */
+  void* dzb; int64_t ld_dzb;   /* [B][>= b_in] bf16 */
+  void* dz_fc; void* dz0; void* dz1;   /* [T][B][u_fc], [B][b_h0], [B][b_h1] bf16 */
+  float* g_out_w[2]; float* g_out_b[2]; float* g_bias_w2; float* g_bias_b2;
+} dmt_heads_desc;
+
+int dmt_heads_supported(int32_t u_in, int32_t u_fc, int32_t b_in, int32_t b_h0, int32_t b_h1, int32_t T);
+int dmt_heads_fwd(const dmt_heads_desc* d, void* stream);
+int dmt_heads_bwd(const dmt_heads_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
