@@ -80,6 +80,12 @@ class HeadsDesc(C.Structure):
                 ("dz_fc", c_vp), ("dz0", c_vp), ("dz1", c_vp), ("g_out_w", c_vp * 2), ("g_out_b", c_vp * 2), ("g_bias_w2", c_vp), ("g_bias_b2", c_vp)]
 
 
+class Q1memDesc(C.Structure):
+    _fields_ = [("B", c_i32), ("T", c_i32), ("H", c_i32), ("d", c_i32), ("dh", c_i32), ("mem", c_vp), ("m_bs", c_i64), ("m_rs", c_i64),
+                ("k_lens", c_vp), ("qp", c_vp), ("ctx", c_vp), ("ctx_hs", c_i64), ("drop_seed", C.c_uint32), ("drop_keep", c_f32),
+                ("dctx", c_vp), ("dout", c_vp), ("do_bs", c_i64), ("bv", c_vp), ("dqp", c_vp), ("dmem", c_vp), ("dm_bs", c_i64), ("dm_rs", c_i64)]
+
+
 class CastJob(C.Structure):
     _fields_ = [("src", c_vp), ("dst_plain", c_vp), ("dst_t", c_vp), ("ld_src", c_i64), ("ld_plain", c_i64), ("ld_t", c_i64),
                 ("rows", c_i32), ("cols", c_i32), ("tile_begin", c_i32), ("tiles_x", c_i32)]
@@ -126,6 +132,8 @@ _SIGS = {
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_attn_long_fwd": [C.POINTER(AttnDesc), c_vp],
+    "dmt_q1mem_fwd": [C.POINTER(Q1memDesc), c_vp],
+    "dmt_q1mem_bwd": [C.POINTER(Q1memDesc), c_vp],
     "dmt_heads_fwd": [C.POINTER(HeadsDesc), c_vp],
     "dmt_heads_bwd": [C.POINTER(HeadsDesc), c_vp],
     "dmt_mmoe_experts_fwd": [C.POINTER(MmoeDesc), c_vp],
@@ -170,7 +178,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported",
-                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
 
 _lib = None
 
@@ -197,6 +205,8 @@ def load():
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
+    lib.dmt_q1mem_supported.restype = c_i32
+    lib.dmt_q1mem_supported.argtypes = [c_i32] * 4
     lib.dmt_heads_supported.restype = c_i32
     lib.dmt_heads_supported.argtypes = [c_i32] * 6
     lib.dmt_mmoe_experts_supported.restype = c_i32

@@ -37,6 +37,7 @@ extern "C" int dmt_struct_size(int which) {
     case 10: return (int)sizeof(dmt_mhsa_desc);
     case 11: return (int)sizeof(dmt_mmoe_desc);
     case 12: return (int)sizeof(dmt_heads_desc);
+    case 13: return (int)sizeof(dmt_q1mem_desc);
     default: return -1;
   }
 }

@@ -1,0 +1,325 @@
+// Target-as-query cross attention WITHOUT the K / V projections of the memory (decoder of every behaviour sequence:
+// TransformerModel.decode -> multihead_attention(queries = target [B, 1, d], keys = values = memory [B, T, d]),
+// TransformerModel_util.py:160-209 with 11-56, 80-108).
+//
+// With ONE query per example the projections re-associate.  Per head h (dh = d / H columns hc of the packed kernels):
+//     score_k = Q_h . K_k,h / sqrt(dh),   K_k,h = mem_k Wk[:, hc] + bk_h      =  (Wk[:, hc] Q_h) . mem_k / sqrt(dh)  + const
+//     out_h   = sum_k P_k V_k,h,          V_k,h = mem_k Wv[:, hc] + bv_h      =  (sum_k P_k mem_k) Wv[:, hc] + (sum_k P_k) bv_h
+// (the constant Q_h . bk_h shifts every unmasked score alike: the softmax does not see it, and masked keys carry the reference's
+// padding value either way).  So instead of projecting T memory rows to K and V (a [B*T, d] x [d, 2d] GEMM forward, its input
+// gradient and its weight gradient -- ~1 ms of the 12 ms step -- plus a kernel that reads the 2d-wide K|V back) the query is
+// projected INTO memory space (q' = Q_h Wk[:, hc]^T, a [B, dh] x [dh, d] GEMM), these kernels attend over the raw memory rows, and
+// the V projection is applied to the d-wide context (ctx_h | sum P) afterwards ([B, d+1] x [d+1, dh]).  Every GEMM left has B rows.
+//
+//   forward   ctx [B][H][d+8]: cols 0..d-1 = sum_k Pd_k mem_k, col d = sum_k Pd_k (Pd = weights after the dropout), rest 0
+//   backward  d ctx, d out (for d (sum P) = d out_h . bv_h) -> d q' [B][H][d], d mem [B][T][d]
+// One workgroup per example, one wavefront per head; the memory rows pass through LDS in chunks of 64 keys (one chunk at T <= 64:
+// read once).  Scores: lane = key, a d-long dot product against the row in LDS; context / d q': lane = 8 columns, walking the keys.
+// Same arithmetic as the single-query kernels of dmt_attn.hip (IEEE division, expf; key mask before the softmax; dropout counter
+// ((b*H + h)*1 + 0)*T + k).  The query is always valid on this path (the decoder passes no query lengths).
+#include "dmt_common.h"
+
+namespace {
+
+constexpr float PADDING_NUM = -4294967295.0f;
+constexpr int D = 320;                 // memory row width
+constexpr int RS = D + 8;              // LDS row stride (elements): 16-byte reads, rows 4 banks apart
+constexpr int CK = 64;                 // keys per chunk
+constexpr int MAXT = 256;
+constexpr int MAXH = 4;
+constexpr int NCH = D / 8;             // 16-byte chunks per row (40)
+
+struct Q1mArgs {
+  int B, T, H;
+  float inv_sc;                        // 1 / sqrt(dh)
+  const bf16_t* mem; long long m_bs, m_rs;
+  const int* k_lens;
+  const float* qp;                     // [B][H][D] fp32
+  bf16_t* ctx; long long ctx_hs;       // [B][H][ctx_hs]
+  unsigned drop_seed, drop_thr;
+  float drop_inv;
+  int drop_on;
+  const float* dctx;                   // [B][H][D] fp32
+  const bf16_t* dout; long long do_bs; // [B][H*dh]
+  const float* bv;                     // [H*dh]
+  int dh;
+  bf16_t* dqp;                         // [B][H][D]
+  bf16_t* dmem; long long dm_bs, dm_rs;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(dmt_pack_bf16(f[0], f[1]), dmt_pack_bf16(f[2], f[3]), dmt_pack_bf16(f[4], f[5]), dmt_pack_bf16(f[6], f[7]));
+}
+
+// rows [k0, k0 + CK) of example b's memory -> LDS (rows past T: zeros)
+__device__ __forceinline__ void stage_chunk(bf16_t* __restrict__ s_mem, const bf16_t* __restrict__ mem_b, long long m_rs, int k0, int T, int tid) {
+  for (int c = tid; c < CK * NCH; c += 256) {
+    const int r = c / NCH, ch = c - r * NCH;
+    const uint4 v = (k0 + r < T) ? *reinterpret_cast<const uint4*>(mem_b + (long long)(k0 + r) * m_rs + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(s_mem + r * RS + ch * 8) = v;
+  }
+}
+
+// dot products of LDS row `lane` with up to two fp32 vectors in LDS (wave-uniform addresses: broadcast reads)
+template <bool TWO>
+__device__ __forceinline__ void row_dots(const bf16_t* __restrict__ row, const float* __restrict__ v0, const float* __restrict__ v1, float& a0, float& a1) {
+  a0 = 0.f; a1 = 0.f;
+#pragma unroll 5
+  for (int ch = 0; ch < NCH; ++ch) {
+    float m[8];
+    unpack8(*reinterpret_cast<const uint4*>(row + ch * 8), m);
+    const float4 x0 = *reinterpret_cast<const float4*>(v0 + ch * 8), x1 = *reinterpret_cast<const float4*>(v0 + ch * 8 + 4);
+    a0 = fmaf(m[0], x0.x, a0); a0 = fmaf(m[1], x0.y, a0); a0 = fmaf(m[2], x0.z, a0); a0 = fmaf(m[3], x0.w, a0);
+    a0 = fmaf(m[4], x1.x, a0); a0 = fmaf(m[5], x1.y, a0); a0 = fmaf(m[6], x1.z, a0); a0 = fmaf(m[7], x1.w, a0);
+    if constexpr (TWO) {
+      const float4 y0 = *reinterpret_cast<const float4*>(v1 + ch * 8), y1 = *reinterpret_cast<const float4*>(v1 + ch * 8 + 4);
+      a1 = fmaf(m[0], y0.x, a1); a1 = fmaf(m[1], y0.y, a1); a1 = fmaf(m[2], y0.z, a1); a1 = fmaf(m[3], y0.w, a1);
+      a1 = fmaf(m[4], y1.x, a1); a1 = fmaf(m[5], y1.y, a1); a1 = fmaf(m[6], y1.z, a1); a1 = fmaf(m[7], y1.w, a1);
+    }
+  }
+}
+
+// masked softmax over the T scores of head h (in s_sc, natural units, already divided by sqrt(dh)); leaves P in s_sc, returns nothing
+__device__ __forceinline__ void softmax_row(float* __restrict__ sc, int T, int klen, int lane) {
+  float m = -3.0e38f;
+  for (int k = lane; k < T; k += 64) {
+    const float x = (k < klen) ? sc[k] : PADDING_NUM;
+    sc[k] = x;
+    m = fmaxf(m, x);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int k = lane; k < T; k += 64) {
+    const float e = expf(sc[k] - m);
+    sc[k] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  for (int k = lane; k < T; k += 64) sc[k] = sc[k] / sum;
+}
+
+// ------------------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_mem[CK * RS];
+  __shared__ __attribute__((aligned(16))) float s_q[MAXH][D];
+  __shared__ float s_sc[MAXH][MAXT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, T = a.T, H = a.H;
+  const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
+  int klen = a.k_lens ? a.k_lens[b] : T;
+  klen = klen < 0 ? 0 : (klen > T ? T : klen);
+  for (int i = tid; i < H * D; i += 256) s_q[i / D][i % D] = a.qp[((long long)b * H) * D + i];
+  const int nchunk = (T + CK - 1) / CK;
+  const int h = wave;                  // one head per wavefront (H <= 4)
+  const bool act = h < H;
+  // ---- scores: lane = key
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+    __syncthreads();
+    if (act) {
+      float s0, s1;
+      row_dots<false>(s_mem + lane * RS, s_q[h], nullptr, s0, s1);
+      if (c * CK + lane < T) s_sc[h][c * CK + lane] = s0 * a.inv_sc;
+    }
+  }
+  __syncthreads();
+  // ---- softmax, dropout
+  if (act) {
+    softmax_row(s_sc[h], T, klen, lane);
+    if (a.drop_on)
+      for (int k = lane; k < T; k += 64)
+        s_sc[h][k] = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? s_sc[h][k] * a.drop_inv : 0.f;
+  }
+  // ---- context: lane = 8 columns
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  float ssum = 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    if (nchunk > 1) {
+      __syncthreads();
+      stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+    }
+    __syncthreads();
+    const int kn = (T - c * CK) < CK ? (T - c * CK) : CK;
+    if (act && lane < NCH) {
+      for (int k = 0; k < kn; ++k) {
+        const float p = s_sc[h][c * CK + k];
+        float m[8];
+        unpack8(*reinterpret_cast<const uint4*>(s_mem + k * RS + lane * 8), m);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, m[i], acc[i]);
+        ssum += p;
+      }
+    }
+  }
+  const float S = __shfl(ssum, 0, 64);
+  if (act) {
+    bf16_t* cp = a.ctx + ((long long)b * H + h) * a.ctx_hs;
+    if (lane < NCH) *reinterpret_cast<uint4*>(cp + lane * 8) = pack8(acc);
+    if (lane == NCH) {
+      const float z[8] = {S, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<uint4*>(cp + D) = pack8(z);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_mem[CK * RS];
+  __shared__ __attribute__((aligned(16))) float s_q[MAXH][D];
+  __shared__ __attribute__((aligned(16))) float s_dc[MAXH][D];
+  __shared__ float s_sc[MAXH][MAXT];      // scores -> P -> dS
+  __shared__ float s_g[MAXH][MAXT];       // d Pd (raw) -> Pd
+  __shared__ float s_dS[MAXH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, T = a.T, H = a.H;
+  const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
+  int klen = a.k_lens ? a.k_lens[b] : T;
+  klen = klen < 0 ? 0 : (klen > T ? T : klen);
+  for (int i = tid; i < H * D; i += 256) {
+    s_q[i / D][i % D] = a.qp[((long long)b * H) * D + i];
+    s_dc[i / D][i % D] = a.dctx[((long long)b * H) * D + i];
+  }
+  const int h = wave;                  // one head per wavefront (H <= 4)
+  const bool act = h < H;
+  // d (sum_k Pd_k) of head h = d out_h . bv_h
+  if (act) {
+    float p = 0.f;
+    for (int n = lane; n < a.dh; n += 64) p = fmaf(bf2f(a.dout[(long long)b * a.do_bs + h * a.dh + n]), a.bv[h * a.dh + n], p);
+    p = wave_sum(p);
+    if (lane == 0) s_dS[h] = p;
+  }
+  const int nchunk = (T + CK - 1) / CK;
+  // ---- scores and d Pd: lane = key
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+    __syncthreads();
+    if (act) {
+      float s0, g0;
+      row_dots<true>(s_mem + lane * RS, s_q[h], s_dc[h], s0, g0);
+      if (c * CK + lane < T) { s_sc[h][c * CK + lane] = s0 * a.inv_sc; s_g[h][c * CK + lane] = g0 + s_dS[h]; }
+    }
+  }
+  __syncthreads();
+  // ---- softmax backward: dS_k = P_k (dP_k - sum P dP) / sqrt(dh) on unmasked keys; Pd for the d mem term
+  if (act) {
+    softmax_row(s_sc[h], T, klen, lane);
+    float dot = 0.f;
+    for (int k = lane; k < T; k += 64) {
+      float keep = 1.f;
+      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
+      const float dp = s_g[h][k] * keep;
+      s_g[h][k] = dp;
+      dot += s_sc[h][k] * dp;
+    }
+    dot = wave_sum(dot);
+    for (int k = lane; k < T; k += 64) {
+      float keep = 1.f;
+      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
+      const float p = s_sc[h][k];
+      const float ds = (k < klen) ? p * (s_g[h][k] - dot) * a.inv_sc : 0.f;
+      s_g[h][k] = p * keep;           // Pd
+      s_sc[h][k] = ds;                // dS (already carries the 1 / sqrt(dh) of the score)
+    }
+  }
+  // ---- d q'_h = sum_k dS_k mem_k: lane = 8 columns
+  {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+      if (nchunk > 1) {
+        __syncthreads();
+        stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+      }
+      __syncthreads();
+      const int kn = (T - c * CK) < CK ? (T - c * CK) : CK;
+      if (act && lane < NCH) {
+        for (int k = 0; k < kn; ++k) {
+          const float ds = s_sc[h][c * CK + k];
+          float m[8];
+          unpack8(*reinterpret_cast<const uint4*>(s_mem + k * RS + lane * 8), m);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = fmaf(ds, m[i], acc[i]);
+        }
+      }
+    }
+    if (act && lane < NCH) *reinterpret_cast<uint4*>(a.dqp + ((long long)b * H + h) * D + lane * 8) = pack8(acc);
+  }
+  __syncthreads();
+  // ---- d mem_k = sum_h Pd_k,h d ctx_h + dS_k,h q'_h: one (key, 8 columns) item per thread
+  bf16_t* dm_b = a.dmem + (long long)b * a.dm_bs;
+  for (int it = tid; it < T * NCH; it += 256) {
+    const int k = it / NCH, ch = it - k * NCH;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int hh = 0; hh < H; ++hh) {
+      const float pd = s_g[hh][k], ds = s_sc[hh][k];
+      const float4 c0 = *reinterpret_cast<const float4*>(&s_dc[hh][ch * 8]), c1 = *reinterpret_cast<const float4*>(&s_dc[hh][ch * 8 + 4]);
+      const float4 q0 = *reinterpret_cast<const float4*>(&s_q[hh][ch * 8]), q1 = *reinterpret_cast<const float4*>(&s_q[hh][ch * 8 + 4]);
+      acc[0] = fmaf(pd, c0.x, fmaf(ds, q0.x, acc[0])); acc[1] = fmaf(pd, c0.y, fmaf(ds, q0.y, acc[1]));
+      acc[2] = fmaf(pd, c0.z, fmaf(ds, q0.z, acc[2])); acc[3] = fmaf(pd, c0.w, fmaf(ds, q0.w, acc[3]));
+      acc[4] = fmaf(pd, c1.x, fmaf(ds, q1.x, acc[4])); acc[5] = fmaf(pd, c1.y, fmaf(ds, q1.y, acc[5]));
+      acc[6] = fmaf(pd, c1.z, fmaf(ds, q1.z, acc[6])); acc[7] = fmaf(pd, c1.w, fmaf(ds, q1.w, acc[7]));
+    }
+    *reinterpret_cast<uint4*>(dm_b + (long long)k * a.dm_rs + ch * 8) = pack8(acc);
+  }
+}
+
+int fill(Q1mArgs& a, const dmt_q1mem_desc* d, const char* who) {
+  DMT_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  DMT_CHECK_ARG(d->B > 0 && d->T > 0 && d->T <= MAXT && d->H > 0 && d->H <= MAXH && d->d == D && d->dh > 0 && d->dh * d->H == D,
+                "%s: built for memory width %d, H <= %d, T <= %d (got d %d, H %d, dh %d, T %d)", who, D, MAXH, MAXT, d->d, d->H, d->dh, d->T);
+  DMT_CHECK_ARG(d->mem && d->qp, "%s: null operand", who);
+  DMT_CHECK_ARG((((uintptr_t)d->mem) & 15) == 0 && d->m_bs % 8 == 0 && d->m_rs % 8 == 0 && (((uintptr_t)d->qp) & 15) == 0,
+                "%s: memory rows and q' must be 16-byte aligned", who);
+  a.B = d->B; a.T = d->T; a.H = d->H; a.dh = d->dh;
+  a.inv_sc = 1.0f / sqrtf((float)d->dh);
+  a.mem = (const bf16_t*)d->mem; a.m_bs = d->m_bs; a.m_rs = d->m_rs;
+  a.k_lens = d->k_lens;
+  a.qp = d->qp;
+  a.ctx = (bf16_t*)d->ctx; a.ctx_hs = d->ctx_hs;
+  a.drop_on = (d->drop_keep > 0.f && d->drop_keep < 1.f) ? 1 : 0;
+  a.drop_seed = d->drop_seed;
+  a.drop_thr = a.drop_on ? (unsigned)(d->drop_keep * 16777216.0f) : 0u;
+  a.drop_inv = a.drop_on ? 1.f / d->drop_keep : 1.f;
+  a.dctx = d->dctx; a.dout = (const bf16_t*)d->dout; a.do_bs = d->do_bs; a.bv = d->bv;
+  a.dqp = (bf16_t*)d->dqp; a.dmem = (bf16_t*)d->dmem; a.dm_bs = d->dm_bs; a.dm_rs = d->dm_rs;
+  return DMT_OK;
+}
+
+}  // namespace
+
+extern "C" int dmt_q1mem_supported(int32_t dtype, int32_t d, int32_t H, int32_t T) {
+  return (dtype == DMT_BF16 && d == D && H >= 1 && H <= MAXH && D % H == 0 && T >= 1 && T <= MAXT) ? 1 : 0;
+}
+
+extern "C" int dmt_q1mem_fwd(const dmt_q1mem_desc* d, void* stream) {
+  Q1mArgs a;
+  if (fill(a, d, "dmt_q1mem_fwd") != DMT_OK) return DMT_ERR_ARG;
+  DMT_CHECK_ARG(d->ctx && d->ctx_hs >= D + 8 && d->ctx_hs % 8 == 0 && (((uintptr_t)d->ctx) & 15) == 0, "dmt_q1mem_fwd: ctx rows need >= d + 8 columns, 16-byte aligned");
+  hipLaunchKernelGGL(q1m_fwd_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, a);
+  DMT_CHECK_LAUNCH("dmt_q1mem_fwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_q1mem_bwd(const dmt_q1mem_desc* d, void* stream) {
+  Q1mArgs a;
+  if (fill(a, d, "dmt_q1mem_bwd") != DMT_OK) return DMT_ERR_ARG;
+  DMT_CHECK_ARG(d->dctx && d->dout && d->bv && d->dqp && d->dmem, "dmt_q1mem_bwd: null argument");
+  DMT_CHECK_ARG((((uintptr_t)d->dctx) & 15) == 0 && (((uintptr_t)d->dqp) & 15) == 0 && (((uintptr_t)d->dmem) & 15) == 0 && d->dm_bs % 8 == 0 && d->dm_rs % 8 == 0,
+                "dmt_q1mem_bwd: rows must be 16-byte aligned");
+  hipLaunchKernelGGL(q1m_bwd_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, a);
+  DMT_CHECK_LAUNCH("dmt_q1mem_bwd");
+  return DMT_OK;
+}

@@ -302,6 +302,7 @@ class DMTEngine:
         # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
@@ -432,6 +433,13 @@ class DMTEngine:
         a = blk + "vanilla_attention/"
         wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
         q = ops.linear(q_in, wl[:, :d], bl[:d], self._wslice(w, 0, d))
+        wv_aug = self.store.q1mem.get(a) if (self.use_q1mem and q_in.dtype == torch.bfloat16) else None
+        if (wv_aug is not None and q_lens is None and q_in.shape[1] == 1 and ops.q1mem_supported(d, H, mem.shape[1]) and
+                mem.stride(2) == 1 and mem.stride(1) % 8 == 0 and mem.stride(0) % 8 == 0 and mem.data_ptr() % 16 == 0):
+            # one query per example: attend over the raw memory rows, no K / V projection of the memory (dmt_q1mem.hip)
+            seed, keep = self._attn_drop(stream)
+            s = ops.CrossQ1Fn.apply(q.reshape(-1, d), mem, q_in.reshape(-1, d), k_lens, w, wl, bl, wv_aug, H, seed, keep).unsqueeze(1)
+            return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
         kv = ops.linear(mem, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d))
         s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False, *self._attn_drop(stream))
         return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))

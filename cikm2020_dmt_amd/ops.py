@@ -774,6 +774,81 @@ class AttnFn(torch.autograd.Function):
         return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None
 
 
+def q1mem_supported(d, H, T, dtype=BF16):
+    return dtype == BF16 and bool(L.load().dmt_q1mem_supported(dt_code(dtype), int(d), int(H), int(T)))
+
+
+class CrossQ1Fn(torch.autograd.Function):
+    """s = multihead_attention(q_in [B, d] (one query per example), mem, mem) + q_in, WITHOUT projecting the memory to K and V
+    (dmt_q1mem.hip: the projections re-associate for a single query).  q [B, d] is the already projected query (Q = q_in Wq + bq);
+    w / w_leaf / b_leaf are the packed (Q|K|V) kernel and bias of the attention scope, wv_aug its [d, d+8] V block (variables.py)."""
+
+    @staticmethod
+    def forward(ctx, q, mem, q_in, k_lens, w: Weight, w_leaf, b_leaf, wv_aug, H, drop_seed, drop_keep):
+        Bn, d = q.shape
+        T = mem.shape[1]
+        dh = d // H
+        dev = q.device
+        lp, ld = w.lp, w.lp.stride(0)                      # plain bf16 shadow [d, 3d]
+        # q'_h = Q_h Wk[:, hc]^T  -> [B, H, d] fp32
+        qp = torch.empty((Bn, H, d), dtype=F32, device=dev)
+        gemm(q, q.stride(0), 1, lp[:, d:2 * d], 1, ld, Bn, d, dh, qp, H * d, batch=H, a_bs=dh, b_bs=dh, c_bs=d)
+        cx = torch.empty((Bn, H, d + 8), dtype=BF16, device=dev)
+        dd = L.Q1memDesc()
+        dd.B, dd.T, dd.H, dd.d, dd.dh = Bn, T, H, d, dh
+        dd.mem, dd.m_bs, dd.m_rs = mem.data_ptr(), mem.stride(0), mem.stride(1)
+        dd.k_lens = k_lens.data_ptr() if k_lens is not None else None
+        dd.qp, dd.ctx, dd.ctx_hs = qp.data_ptr(), cx.data_ptr(), d + 8
+        dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
+        with _Timed("q1mem", 4.0 * Bn * H * T * d):
+            L.call("dmt_q1mem_fwd", C.byref(dd), stream_ptr())
+        # out[:, hc] = (ctx_h | S_h) (Wv[:, hc] ; bv_h) + q_in[:, hc]
+        out = torch.empty((Bn, d), dtype=BF16, device=dev)
+        gemm(cx, H * (d + 8), 1, wv_aug, 1, wv_aug.stride(0), Bn, dh, d + 8, out, d, resid=q_in, ldr=q_in.stride(0), batch=H, a_bs=d + 8,
+             b_bs=dh * wv_aug.stride(0), c_bs=dh, resid_bs=dh)
+        ctx.save_for_backward(q, mem, k_lens, qp, cx)
+        ctx.w, ctx.leaves, ctx.dims, ctx.desc = w, (w_leaf, b_leaf), (H, d, dh, T), dd
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, mem, k_lens, qp, cx = ctx.saved_tensors
+        H, d, dh, T = ctx.dims
+        w, (w_leaf, b_leaf) = ctx.w, ctx.leaves
+        Bn = q.shape[0]
+        dev = q.device
+        dout = dout.contiguous()
+        lp, lpt = w.lp, w.lp_t
+        # d ctx_h = d out_h Wv[:, hc]^T  -> [B, H, d] fp32
+        dctx = torch.empty((Bn, H, d), dtype=F32, device=dev)
+        gemm(dout, d, 1, lp[:, 2 * d:], 1, lp.stride(0), Bn, d, dh, dctx, H * d, batch=H, a_bs=dh, b_bs=dh, c_bs=d)
+        dqp = torch.empty((Bn, H, d), dtype=BF16, device=dev)
+        dmem = torch.empty((Bn, T, d), dtype=BF16, device=dev)
+        dd = ctx.desc
+        dd.dctx, dd.dout, dd.do_bs = dctx.data_ptr(), dout.data_ptr(), d
+        dd.bv = b_leaf.data_ptr() + 4 * 2 * d
+        dd.dqp, dd.dmem, dd.dm_bs, dd.dm_rs = dqp.data_ptr(), dmem.data_ptr(), T * d, d
+        with _Timed("q1mem", 8.0 * Bn * H * T * d):
+            L.call("dmt_q1mem_bwd", C.byref(dd), stream_ptr())
+        # d Q_h = d q'_h Wk[:, hc]  -> [B, d] bf16   (B operand k-contiguous: the transposed shadow rows d + hc)
+        dq = torch.empty((Bn, d), dtype=BF16, device=dev)
+        ldt = lpt.stride(0)
+        gemm(dqp, H * d, 1, lpt[d:2 * d], 1, ldt, Bn, dh, d, dq, d, batch=H, a_bs=d, b_bs=dh * ldt, c_bs=dh)
+        # weight gradients, accumulated into the packed kernel's / bias' gradient views (reductions over the B rows only)
+        gw, gb = _grad_view(w_leaf), _grad_view(b_leaf)
+        if gw is None or gb is None:
+            raise RuntimeError("CrossQ1Fn: parameter leaves without an in-place gradient view are not supported")
+        ldg = gw.stride(0)
+        split = _pick_split(H * 3, Bn)
+        #   dWk[:, hc] += d q'_h^T Q_h        (the K bias gets no gradient: it shifts all scores of a softmax alike)
+        gemm(dqp, 1, H * d, q, q.stride(0), 1, d, dh, Bn, gw[:, d:2 * d], ldg, split_k=split, accumulate=True, batch=H, a_bs=d, b_bs=dh, c_bs=dh)
+        #   dWv[:, hc] += ctx_h^T d out_h ;  dbv_h += S_h^T d out_h
+        gemm(cx, 1, H * (d + 8), dout, d, 1, d, dh, Bn, gw[:, 2 * d:], ldg, split_k=split, accumulate=True, batch=H, a_bs=d + 8, b_bs=dh, c_bs=dh)
+        gemm(cx[:, :, d:], 1, H * (d + 8), dout, d, 1, 1, dh, Bn, gb[2 * d:], dh, split_k=split, accumulate=True, batch=H, a_bs=d + 8, b_bs=dh,
+             c_bs=dh)
+        return dq, dmem, dout, None, None, None, None, None, None, None, None
+
+
 class SelfAttnBlockFn(torch.autograd.Function):
     """s = concat_h softmax(mask(QK^T/sqrt(dh))) V + x  with (Q|K|V) = x Wqkv + b: multihead_attention(x, x, x) before its LayerNorm
     (TransformerModel_util.py:160-207) as ONE autograd node, so that dx = dqkv Wqkv^T + ds leaves the input-gradient GEMM's epilogue

@@ -234,6 +234,15 @@ class VariableStore:
                         self.chain[scope] = dict(geo=(d, dff, d), fwd=torch.empty(nbytes, dtype=torch.uint8, device=dev),
                                                  bwd=torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
+        # decoder cross attention over the raw memory rows (dmt_q1mem_*): per vanilla_attention scope the V projection as a
+        # k-contiguous bf16 block [d_model, d_model + 8]: row n = output column n, cols 0..d-1 = Wv[:, n], col d = bv[n], rest 0
+        self.q1mem: Dict[str, torch.Tensor] = {}
+        if bf and ops.q1mem_supported(self.spec["d_model"], self.spec["num_heads"], 1):
+            dm = self.spec["d_model"]
+            for name in self.leaves:
+                if name.endswith("vanilla_attention/qkv_kernel"):
+                    self.q1mem[name[: -len("qkv_kernel")]] = torch.zeros((dm, dm + 8), dtype=torch.bfloat16, device=dev)
+
         # weight images of the fused self-attention block (dmt_mhsa_block_fwd), one per encoder self-attention scope
         self.mhsa: Dict[str, torch.Tensor] = {}
         if bf and ops.mhsa_supported(self.spec["d_model"], self.spec["num_heads"], 1):
@@ -323,8 +332,13 @@ class VariableStore:
         if self.compute_dtype != torch.bfloat16:
             return
         if getattr(self, "_cast_jobs", None) is None:
-            self._cast_jobs = ops.cast_shadow_jobs([(self.weight[n].f32, self.weight[n].lp, self.weight[n].lp_t) for n in self._w2d],
-                                                   self.device)
+            triples = [(self.weight[n].f32, self.weight[n].lp, self.weight[n].lp_t) for n in self._w2d]
+            dm = self.spec["d_model"]
+            for scope, blk in self.q1mem.items():      # (Wv | bv) transposed into the decoder's V-projection block
+                wqkv, bqkv = self.leaf[scope + "qkv_kernel"].detach(), self.leaf[scope + "qkv_bias"].detach()
+                triples.append((wqkv[:, 2 * dm: 3 * dm], None, blk[:, :dm]))
+                triples.append((bqkv[2 * dm: 3 * dm].view(1, dm), None, blk[:, dm: dm + 1]))
+            self._cast_jobs = ops.cast_shadow_jobs(triples, self.device)
         ops.cast_shadow_batched(self._cast_jobs)
         for scope, img in self.mhsa.items():
             ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)

@@ -585,6 +585,37 @@ int dmt_heads_supported(int32_t u_in, int32_t u_fc, int32_t b_in, int32_t b_h0, 
 int dmt_heads_fwd(const dmt_heads_desc* d, void* stream);
 int dmt_heads_bwd(const dmt_heads_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Target-as-query cross attention over the RAW memory rows (Tq = 1; the decoder of every behaviour sequence).
+ * With one query per example the K / V projections of the memory re-associate (dmt_q1mem.hip):
+ *   q'_h = Q_h Wk[:, hc]^T [d]        score_k = q'_h . mem_k / sqrt(dh)        (the bias term Q_h . bk_h shifts all scores alike)
+ *   ctx_h = sum_k Pd_k mem_k [d], S_h = sum_k Pd_k        out_h = ctx_h Wv[:, hc] + S_h bv_h
+ * so the [B*T, d] x [d, 2d] projection, its input gradient and its weight gradient disappear; what is left are B-row GEMMs
+ * (q', the V projection of (ctx | S), their gradients) around these two kernels.
+ *   forward : ctx [B][H][ctx_hs]: cols 0..d-1 = ctx_h, col d = S_h, cols d+1.. = 0   (bf16)
+ *   backward: dctx [B][H][d] fp32 + dout [B][H*dh] (dS_h = dout_h . bv_h) -> dqp [B][H][d] bf16, dmem [B][T][d] bf16
+ * Masks, softmax, dropout counter as dmt_attn_fwd with Tq = 1 and no query lengths; d = 320, H <= 4, T <= 256, bf16.
+ * Replaces: multihead_attention(target, memory, memory) of TransformerModel.decode (TransformerModel.py:146-160,
+ *           TransformerModel_util.py:160-209) together with the K / V halves of its tf.layers.dense projections.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, T, H, d, dh;
+  const void* mem; int64_t m_bs, m_rs;       /* [B][T][d] bf16 */
+  const int32_t* k_lens;                     /* [B] or NULL */
+  const float* qp;                           /* [B][H][d] fp32 */
+  void* ctx; int64_t ctx_hs;                 /* [B][H][ctx_hs >= d + 8] bf16 */
+  uint32_t drop_seed; float drop_keep;
+  const float* dctx;                         /* [B][H][d] fp32 (backward) */
+  const void* dout; int64_t do_bs;           /* [B][H*dh] bf16 */
+  const float* bv;                           /* [H*dh] fp32 */
+  void* dqp;                                 /* [B][H][d] bf16 */
+  void* dmem; int64_t dm_bs, dm_rs;          /* [B][T][d] bf16 */
+} dmt_q1mem_desc;
+
+int dmt_q1mem_supported(int32_t dtype, int32_t d, int32_t H, int32_t T);
+int dmt_q1mem_fwd(const dmt_q1mem_desc* d, void* stream);
+int dmt_q1mem_bwd(const dmt_q1mem_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

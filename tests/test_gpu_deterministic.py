@@ -45,7 +45,9 @@ def test_deterministic_mode_is_bit_reproducible(cuda, dtype):
         assert np.array_equal(s1[k].view(np.uint32), s2[k].view(np.uint32)), k
     # against the default mode: same sums in another order
     l0, s0 = _run(cuda, dtype, False)
-    assert np.abs(np.array(l0) - np.array(l1)).max() < (1e-4 if dtype == torch.float32 else 2e-2)
+    # (bf16: the fused heads kernels sum their 1-wide layers' gradients with atomics and hand over to the layer path in deterministic
+    #  mode -- another rounding of the same numbers; losses of ~10 after three steps)
+    assert np.abs(np.array(l0) - np.array(l1)).max() < (1e-4 if dtype == torch.float32 else 6e-2)
     worst = max(float(np.abs(s0[k] - s1[k]).max()) for k in s1)
     assert worst < 4e-3, worst          # three Adam steps bound any element's movement
 
