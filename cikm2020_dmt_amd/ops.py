@@ -7,6 +7,7 @@ raises (cikm2020_dmt_amd/_lib.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import ctypes as _ct
 import math
 from typing import Optional, Sequence
@@ -839,7 +840,7 @@ class CrossQ1Fn(torch.autograd.Function):
         if gw is None or gb is None:
             raise RuntimeError("CrossQ1Fn: parameter leaves without an in-place gradient view are not supported")
         ldg = gw.stride(0)
-        split = _pick_split(H * 3, Bn)
+        split = 1 if DETERMINISTIC else max(1, min(int(os.environ.get('DMT_Q1_SPLIT', '8')), Bn // 64))
         #   dWk[:, hc] += d q'_h^T Q_h        (the K bias gets no gradient: it shifts all scores of a softmax alike)
         gemm(dqp, 1, H * d, q, q.stride(0), 1, d, dh, Bn, gw[:, d:2 * d], ldg, split_k=split, accumulate=True, batch=H, a_bs=d, b_bs=dh, c_bs=dh)
         #   dWv[:, hc] += ctx_h^T d out_h ;  dbv_h += S_h^T d out_h
