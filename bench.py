@@ -152,6 +152,8 @@ def main():
         "attn_long": "attn_long_fwd/bwd_kernel + attn_q1_long_kernel (dmt_attn_long.hip): flash-style attention core, 64 < T <= 256",
         "attn": "attn_fwd/bwd_co_kernel + attn_q1v_kernel (dmt_attn.hip): attention core, T <= 64",
         "mhsa_block": "mhsa_fwd_kernel (dmt_mhsa.hip): fused self-attention block",
+        "q1mem": "q1m_fwd/bwd_kernel (dmt_q1mem.hip): decoder cross attention over the raw memory rows (HBM-bound: memory rows read once, d mem written once)",
+        "mmoe_experts": "mmoe_experts_fwd/bwd_kernel (dmt_mmoe.hip): expert layers 1-2 + gates + mixtures",
     }
     fams = []
     for key, desc_ in fam_desc.items():
@@ -183,7 +185,7 @@ def main():
             f["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % t["launches"]
     # `roofline` names ONE kernel (its rocprofv3 row must agree): the single-kernel family with the largest share of the step; the
     # dmt_gemm family spans three kernels and is listed with the others
-    single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long")] or fams
+    single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts")] or fams
     roofline = dict(single[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
     n_ga, t_ga, by_ga = agg("gather_fwd")
     gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",

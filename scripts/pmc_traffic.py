@@ -10,6 +10,9 @@ FAMILIES = {
     "wgrad320": ["wgrad320_kernel"],
     "attn": ["attn_fwd_co_kernel", "attn_bwd_co_kernel", "attn_q1v_kernel"],
     "attn_long": ["attn_long_fwd", "attn_long_bwd", "attn_q1_long"],
+    "q1mem": ["q1m_fwd_kernel", "q1m_bwd_kernel"],
+    "mmoe_experts": ["mmoe_experts_"],
+    "heads": ["heads_fwd_kernel", "heads_bwd_kernel"],
     "gather_fwd": ["gather_group_kernel"],
     "embgrad_reduce": ["embgrad_reduce_kernel"],
     "adam_sparse": ["adam_sparse_kernel"],
