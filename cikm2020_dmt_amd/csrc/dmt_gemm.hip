@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (; iL < g.total_blocks; iL += G) {
       const TileCoord ti = decode_tile(g, iL);
       if (!ti.valid) continue;
-      ira = rsrc_of(Ag, g.a_cs, ti.m0, M_real); irb = rsrc_of(Bg, g.b_rs, ti.n0, g.N);
+      ira = rsrc_of(Ag + (long long)ti.bt * g.a_bs, g.a_cs, ti.m0, M_real); irb = rsrc_of(Bg + (long long)ti.bt * g.b_bs, g.b_rs, ti.n0, g.N);
       ik = ti.k_begin; ik_end = ti.k_end; ivalid = true;
       return;
     }
@@ -1074,7 +1074,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (row >= g.M) continue;
           const float x = acc[i][j][r];
-          float* dst = (row == ones_row) ? (g.c_last + col) : (reinterpret_cast<float*>(g.C) + (long long)row * g.ldc + col);
+          float* dst = (row == ones_row) ? (g.c_last + (long long)t.bt * g.clast_bs + col)
+                                         : (reinterpret_cast<float*>(g.C) + (long long)t.bt * g.c_bs + (long long)row * g.ldc + col);
           if (atomic) atomicAdd(dst, x); else *dst = x;
         }
       }
@@ -1159,7 +1160,7 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   }
   const bool glds = d->in_dtype == DMT_BF16 && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && g.fast_ok && batch == 1 &&
                     (d->K % 64 == 0) && d->N <= GL_MAX_N;
-  const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok && batch == 1 &&
+  const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok &&
                        (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
   if (dw_glds) {
     const dim3 gd((unsigned)(nblk < GL_GRID ? nblk : GL_GRID));

@@ -34,12 +34,12 @@ struct Q1mArgs {
   float inv_sc;                        // 1 / sqrt(dh)
   const bf16_t* mem; long long m_bs, m_rs;
   const int* k_lens;
-  const float* qp;                     // [B][H][D] fp32
+  const bf16_t* qp;                    // [B][H][D] bf16
   bf16_t* ctx; long long ctx_hs;       // [B][H][ctx_hs]
   unsigned drop_seed, drop_thr;
   float drop_inv;
   int drop_on;
-  const float* dctx;                   // [B][H][D] fp32
+  const bf16_t* dctx;                  // [B][H][D] bf16
   const bf16_t* dout; long long do_bs; // [B][H*dh]
   const float* bv;                     // [H*dh]
   int dh;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
   const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
   int klen = a.k_lens ? a.k_lens[b] : T;
   klen = klen < 0 ? 0 : (klen > T ? T : klen);
-  for (int i = tid; i < H * D; i += 256) s_q[i / D][i % D] = a.qp[((long long)b * H) * D + i];
+  for (int i = tid; i < H * D; i += 256) s_q[i / D][i % D] = bf2f(a.qp[((long long)b * H) * D + i]);
   const int nchunk = (T + CK - 1) / CK;
   const int h = wave;                  // one head per wavefront (H <= 4)
   const bool act = h < H;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
   int klen = a.k_lens ? a.k_lens[b] : T;
   klen = klen < 0 ? 0 : (klen > T ? T : klen);
   for (int i = tid; i < H * D; i += 256) {
-    s_q[i / D][i % D] = a.qp[((long long)b * H) * D + i];
-    s_dc[i / D][i % D] = a.dctx[((long long)b * H) * D + i];
+    s_q[i / D][i % D] = bf2f(a.qp[((long long)b * H) * D + i]);
+    s_dc[i / D][i % D] = bf2f(a.dctx[((long long)b * H) * D + i]);
   }
   const int h = wave;                  // one head per wavefront (H <= 4)
   const bool act = h < H;
@@ -287,13 +287,13 @@ int fill(Q1mArgs& a, const dmt_q1mem_desc* d, const char* who) {
   a.inv_sc = 1.0f / sqrtf((float)d->dh);
   a.mem = (const bf16_t*)d->mem; a.m_bs = d->m_bs; a.m_rs = d->m_rs;
   a.k_lens = d->k_lens;
-  a.qp = d->qp;
+  a.qp = (const bf16_t*)d->qp;
   a.ctx = (bf16_t*)d->ctx; a.ctx_hs = d->ctx_hs;
   a.drop_on = (d->drop_keep > 0.f && d->drop_keep < 1.f) ? 1 : 0;
   a.drop_seed = d->drop_seed;
   a.drop_thr = a.drop_on ? (unsigned)(d->drop_keep * 16777216.0f) : 0u;
   a.drop_inv = a.drop_on ? 1.f / d->drop_keep : 1.f;
-  a.dctx = d->dctx; a.dout = (const bf16_t*)d->dout; a.do_bs = d->do_bs; a.bv = d->bv;
+  a.dctx = (const bf16_t*)d->dctx; a.dout = (const bf16_t*)d->dout; a.do_bs = d->do_bs; a.bv = d->bv;
   a.dqp = (bf16_t*)d->dqp; a.dmem = (bf16_t*)d->dmem; a.dm_bs = d->dm_bs; a.dm_rs = d->dm_rs;
   return DMT_OK;
 }

@@ -791,8 +791,8 @@ class CrossQ1Fn(torch.autograd.Function):
         dh = d // H
         dev = q.device
         lp, ld = w.lp, w.lp.stride(0)                      # plain bf16 shadow [d, 3d]
-        # q'_h = Q_h Wk[:, hc]^T  -> [B, H, d] fp32
-        qp = torch.empty((Bn, H, d), dtype=F32, device=dev)
+        # q'_h = Q_h Wk[:, hc]^T  -> [B, H, d]
+        qp = torch.empty((Bn, H, d), dtype=BF16, device=dev)
         gemm(q, q.stride(0), 1, lp[:, d:2 * d], 1, ld, Bn, d, dh, qp, H * d, batch=H, a_bs=dh, b_bs=dh, c_bs=d)
         cx = torch.empty((Bn, H, d + 8), dtype=BF16, device=dev)
         dd = L.Q1memDesc()
@@ -820,8 +820,8 @@ class CrossQ1Fn(torch.autograd.Function):
         dev = q.device
         dout = dout.contiguous()
         lp, lpt = w.lp, w.lp_t
-        # d ctx_h = d out_h Wv[:, hc]^T  -> [B, H, d] fp32
-        dctx = torch.empty((Bn, H, d), dtype=F32, device=dev)
+        # d ctx_h = d out_h Wv[:, hc]^T  -> [B, H, d]
+        dctx = torch.empty((Bn, H, d), dtype=BF16, device=dev)
         gemm(dout, d, 1, lp[:, 2 * d:], 1, lp.stride(0), Bn, d, dh, dctx, H * d, batch=H, a_bs=dh, b_bs=dh, c_bs=d)
         dqp = torch.empty((Bn, H, d), dtype=BF16, device=dev)
         dmem = torch.empty((Bn, T, d), dtype=BF16, device=dev)

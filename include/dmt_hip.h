@@ -593,7 +593,7 @@ int dmt_heads_bwd(const dmt_heads_desc* d, void* stream);
  * so the [B*T, d] x [d, 2d] projection, its input gradient and its weight gradient disappear; what is left are B-row GEMMs
  * (q', the V projection of (ctx | S), their gradients) around these two kernels.
  *   forward : ctx [B][H][ctx_hs]: cols 0..d-1 = ctx_h, col d = S_h, cols d+1.. = 0   (bf16)
- *   backward: dctx [B][H][d] fp32 + dout [B][H*dh] (dS_h = dout_h . bv_h) -> dqp [B][H][d] bf16, dmem [B][T][d] bf16
+ *   backward: dctx [B][H][d] bf16 + dout [B][H*dh] (dS_h = dout_h . bv_h) -> dqp [B][H][d] bf16, dmem [B][T][d] bf16
  * Masks, softmax, dropout counter as dmt_attn_fwd with Tq = 1 and no query lengths; d = 320, H <= 4, T <= 256, bf16.
  * Replaces: multihead_attention(target, memory, memory) of TransformerModel.decode (TransformerModel.py:146-160,
  *           TransformerModel_util.py:160-209) together with the K / V halves of its tf.layers.dense projections.
@@ -602,10 +602,10 @@ typedef struct {
   int32_t B, T, H, d, dh;
   const void* mem; int64_t m_bs, m_rs;       /* [B][T][d] bf16 */
   const int32_t* k_lens;                     /* [B] or NULL */
-  const float* qp;                           /* [B][H][d] fp32 */
+  const void* qp;                            /* [B][H][d] bf16 */
   void* ctx; int64_t ctx_hs;                 /* [B][H][ctx_hs >= d + 8] bf16 */
   uint32_t drop_seed; float drop_keep;
-  const float* dctx;                         /* [B][H][d] fp32 (backward) */
+  const void* dctx;                          /* [B][H][d] bf16 (backward) */
   const void* dout; int64_t do_bs;           /* [B][H*dh] bf16 */
   const float* bv;                           /* [H*dh] fp32 */
   void* dqp;                                 /* [B][H][d] bf16 */
