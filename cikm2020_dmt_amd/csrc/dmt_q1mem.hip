@@ -57,35 +57,37 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(dmt_pack_bf16(f[0], f[1]), dmt_pack_bf16(f[2], f[3]), dmt_pack_bf16(f[4], f[5]), dmt_pack_bf16(f[6], f[7]));
 }
 
-// rows [k0, k0 + CK) of example b's memory -> LDS (rows past T: zeros)
-__device__ __forceinline__ void stage_chunk(bf16_t* __restrict__ s_mem, const bf16_t* __restrict__ mem_b, long long m_rs, int k0, int T, int tid) {
-  for (int c = tid; c < CK * NCH; c += 256) {
-    const int r = c / NCH, ch = c - r * NCH;
-    const uint4 v = (k0 + r < T) ? *reinterpret_cast<const uint4*>(mem_b + (long long)(k0 + r) * m_rs + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(s_mem + r * RS + ch * 8) = v;
-  }
+// packed bf16 dot product with fp32 accumulate: acc + a.lo * b.lo + a.hi * b.hi   (v_dot2c_f32_bf16)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+__device__ __forceinline__ float dot8(const uint4& m, const uint4& v, float acc) {
+  acc = dot2(m.x, v.x, acc); acc = dot2(m.y, v.y, acc); acc = dot2(m.z, v.z, acc); acc = dot2(m.w, v.w, acc);
+  return acc;
+}
+// acc[0..7] += s * (the 8 bf16 of m), s given as bf16 bits: two dot2 per dword against (s, 0) and (0, s) -- no unpacking
+__device__ __forceinline__ void axpy8(float (&acc)[8], const uint4& m, unsigned sb) {
+  const unsigned lo = sb & 0xFFFFu, hi = sb << 16;
+  acc[0] = dot2(m.x, lo, acc[0]); acc[1] = dot2(m.x, hi, acc[1]);
+  acc[2] = dot2(m.y, lo, acc[2]); acc[3] = dot2(m.y, hi, acc[3]);
+  acc[4] = dot2(m.z, lo, acc[4]); acc[5] = dot2(m.z, hi, acc[5]);
+  acc[6] = dot2(m.w, lo, acc[6]); acc[7] = dot2(m.w, hi, acc[7]);
 }
 
-// dot products of LDS row `lane` with up to two fp32 vectors in LDS (wave-uniform addresses: broadcast reads)
+// dot products of LDS row `row` (bf16) with one or two bf16 vectors in LDS (wave-uniform addresses: broadcast reads)
 template <bool TWO>
-__device__ __forceinline__ void row_dots(const bf16_t* __restrict__ row, const float* __restrict__ v0, const float* __restrict__ v1, float& a0, float& a1) {
+__device__ __forceinline__ void row_dots(const bf16_t* __restrict__ row, const bf16_t* __restrict__ v0, const bf16_t* __restrict__ v1, float& a0, float& a1) {
   a0 = 0.f; a1 = 0.f;
-#pragma unroll 5
+#pragma unroll 8
   for (int ch = 0; ch < NCH; ++ch) {
-    float m[8];
-    unpack8(*reinterpret_cast<const uint4*>(row + ch * 8), m);
-    const float4 x0 = *reinterpret_cast<const float4*>(v0 + ch * 8), x1 = *reinterpret_cast<const float4*>(v0 + ch * 8 + 4);
-    a0 = fmaf(m[0], x0.x, a0); a0 = fmaf(m[1], x0.y, a0); a0 = fmaf(m[2], x0.z, a0); a0 = fmaf(m[3], x0.w, a0);
-    a0 = fmaf(m[4], x1.x, a0); a0 = fmaf(m[5], x1.y, a0); a0 = fmaf(m[6], x1.z, a0); a0 = fmaf(m[7], x1.w, a0);
-    if constexpr (TWO) {
-      const float4 y0 = *reinterpret_cast<const float4*>(v1 + ch * 8), y1 = *reinterpret_cast<const float4*>(v1 + ch * 8 + 4);
-      a1 = fmaf(m[0], y0.x, a1); a1 = fmaf(m[1], y0.y, a1); a1 = fmaf(m[2], y0.z, a1); a1 = fmaf(m[3], y0.w, a1);
-      a1 = fmaf(m[4], y1.x, a1); a1 = fmaf(m[5], y1.y, a1); a1 = fmaf(m[6], y1.z, a1); a1 = fmaf(m[7], y1.w, a1);
-    }
+    const uint4 m = *reinterpret_cast<const uint4*>(row + ch * 8);
+    a0 = dot8(m, *reinterpret_cast<const uint4*>(v0 + ch * 8), a0);
+    if constexpr (TWO) a1 = dot8(m, *reinterpret_cast<const uint4*>(v1 + ch * 8), a1);
   }
 }
 
-// masked softmax over the T scores of head h (in s_sc, natural units, already divided by sqrt(dh)); leaves P in s_sc, returns nothing
+// masked softmax over the T scores of one head (in sc, natural units, already divided by sqrt(dh)); leaves P in sc
 __device__ __forceinline__ void softmax_row(float* __restrict__ sc, int T, int klen, int lane) {
   float m = -3.0e38f;
   for (int k = lane; k < T; k += 64) {
@@ -104,68 +106,101 @@ __device__ __forceinline__ void softmax_row(float* __restrict__ sc, int T, int k
   for (int k = lane; k < T; k += 64) sc[k] = sc[k] / sum;
 }
 
+// LDS carve-up (dynamic; the host sizes it from T so that short histories leave room for four workgroups per CU):
+//   s_mem [MR][RS] bf16 | s_q [H][D] bf16 | (bwd) s_dc [H][D] bf16 | s_sc [H][TP] f32 | s_g [H][TP] f32 | (bwd) s_cq, s_pds
+struct Q1mLds {
+  bf16_t* mem; bf16_t* q; bf16_t* dc; float* sc; float* g; unsigned* pb; unsigned* cq; unsigned* pds; float* dS;
+};
+__host__ __device__ inline int q1m_mem_rows(int T) { const int r = T < CK ? T : CK; return (r + 1) & ~1; }
+__host__ __device__ inline int q1m_tp(int T) { return (T + 63) & ~63; }
+__host__ __device__ inline size_t q1m_lds_bytes(int T, int H, bool bwd) {
+  size_t b = (size_t)q1m_mem_rows(T) * RS * 2 + (size_t)H * D * 2 + (size_t)H * q1m_tp(T) * 4 * 2 + 64;
+  if (bwd) b += (size_t)H * D * 2 + (size_t)H * D * 4 + (size_t)H * q1m_tp(T) * 4;
+  return (b + 255) & ~(size_t)255;
+}
+__device__ __forceinline__ Q1mLds q1m_carve(unsigned char* base, int T, int H, bool bwd) {
+  Q1mLds L;
+  unsigned char* p = base;
+  L.mem = (bf16_t*)p; p += (size_t)q1m_mem_rows(T) * RS * 2;
+  L.q = (bf16_t*)p; p += (size_t)H * D * 2;
+  L.dc = (bf16_t*)p; if (bwd) p += (size_t)H * D * 2;
+  L.sc = (float*)p; p += (size_t)H * q1m_tp(T) * 4;
+  L.g = (float*)p; L.pb = (unsigned*)p; p += (size_t)H * q1m_tp(T) * 4;
+  L.cq = (unsigned*)p; if (bwd) p += (size_t)H * D * 4;
+  L.pds = (unsigned*)p; if (bwd) p += (size_t)H * q1m_tp(T) * 4;
+  L.dS = (float*)p;
+  return L;
+}
+
+// rows [k0, k0 + rows) of example b's memory -> LDS (rows past T: zeros)
+__device__ __forceinline__ void stage_rows(bf16_t* __restrict__ s_mem, const bf16_t* __restrict__ mem_b, long long m_rs, int k0, int rows, int T, int tid) {
+  for (int c = tid; c < rows * NCH; c += 256) {
+    const int r = c / NCH, ch = c - r * NCH;
+    const uint4 v = (k0 + r < T) ? *reinterpret_cast<const uint4*>(mem_b + (long long)(k0 + r) * m_rs + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(s_mem + r * RS + ch * 8) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_mem[CK * RS];
-  __shared__ __attribute__((aligned(16))) float s_q[MAXH][D];
-  __shared__ float s_sc[MAXH][MAXT];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, T = a.T, H = a.H;
+  const Q1mLds L = q1m_carve(smem, T, H, false);
+  const int MR = q1m_mem_rows(T), TP = q1m_tp(T);
   const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
   int klen = a.k_lens ? a.k_lens[b] : T;
   klen = klen < 0 ? 0 : (klen > T ? T : klen);
-  for (int i = tid; i < H * D; i += 256) s_q[i / D][i % D] = bf2f(a.qp[((long long)b * H) * D + i]);
+  for (int i = tid; i < H * D / 8; i += 256) reinterpret_cast<uint4*>(L.q)[i] = reinterpret_cast<const uint4*>(a.qp + (long long)b * H * D)[i];
   const int nchunk = (T + CK - 1) / CK;
   const int h = wave;                  // one head per wavefront (H <= 4)
   const bool act = h < H;
   // ---- scores: lane = key
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();
-    stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+    stage_rows(L.mem, mem_b, a.m_rs, c * CK, MR, T, tid);
     __syncthreads();
-    if (act) {
+    if (act && lane < MR) {
       float s0, s1;
-      row_dots<false>(s_mem + lane * RS, s_q[h], nullptr, s0, s1);
-      if (c * CK + lane < T) s_sc[h][c * CK + lane] = s0 * a.inv_sc;
+      row_dots<false>(L.mem + lane * RS, L.q + h * D, nullptr, s0, s1);
+      if (c * CK + lane < T) L.sc[h * TP + c * CK + lane] = s0 * a.inv_sc;
     }
   }
   __syncthreads();
-  // ---- softmax, dropout
+  // ---- softmax, dropout; the weights as bf16 bits for the context sums, their sum S from the same rounded values
+  float ssum = 0.f;
   if (act) {
-    softmax_row(s_sc[h], T, klen, lane);
-    if (a.drop_on)
-      for (int k = lane; k < T; k += 64)
-        s_sc[h][k] = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? s_sc[h][k] * a.drop_inv : 0.f;
+    softmax_row(L.sc + h * TP, T, klen, lane);
+    for (int k = lane; k < T; k += 64) {
+      float p = L.sc[h * TP + k];
+      if (a.drop_on) p = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? p * a.drop_inv : 0.f;
+      const bf16_t pb = f2bf(p);
+      L.pb[h * TP + k] = (unsigned)pb;
+      ssum += bf2f(pb);
+    }
+    ssum = wave_sum(ssum);
   }
   // ---- context: lane = 8 columns
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  float ssum = 0.f;
   for (int c = 0; c < nchunk; ++c) {
     if (nchunk > 1) {
       __syncthreads();
-      stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+      stage_rows(L.mem, mem_b, a.m_rs, c * CK, MR, T, tid);
     }
     __syncthreads();
     const int kn = (T - c * CK) < CK ? (T - c * CK) : CK;
     if (act && lane < NCH) {
-      for (int k = 0; k < kn; ++k) {
-        const float p = s_sc[h][c * CK + k];
-        float m[8];
-        unpack8(*reinterpret_cast<const uint4*>(s_mem + k * RS + lane * 8), m);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, m[i], acc[i]);
-        ssum += p;
-      }
+#pragma unroll 4
+      for (int k = 0; k < kn; ++k) axpy8(acc, *reinterpret_cast<const uint4*>(L.mem + k * RS + lane * 8), L.pb[h * TP + c * CK + k]);
     }
   }
-  const float S = __shfl(ssum, 0, 64);
   if (act) {
     bf16_t* cp = a.ctx + ((long long)b * H + h) * a.ctx_hs;
     if (lane < NCH) *reinterpret_cast<uint4*>(cp + lane * 8) = pack8(acc);
     if (lane == NCH) {
-      const float z[8] = {S, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float z[8] = {ssum, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<uint4*>(cp + D) = pack8(z);
     }
   }
@@ -173,20 +208,22 @@ __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
 
 // ----------------------------------------------------------------------------------------------------------- backward
 __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t s_mem[CK * RS];
-  __shared__ __attribute__((aligned(16))) float s_q[MAXH][D];
-  __shared__ __attribute__((aligned(16))) float s_dc[MAXH][D];
-  __shared__ float s_sc[MAXH][MAXT];      // scores -> P -> dS
-  __shared__ float s_g[MAXH][MAXT];       // d Pd (raw) -> Pd
-  __shared__ float s_dS[MAXH];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, T = a.T, H = a.H;
+  const Q1mLds L = q1m_carve(smem, T, H, true);
+  const int MR = q1m_mem_rows(T), TP = q1m_tp(T);
   const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
   int klen = a.k_lens ? a.k_lens[b] : T;
   klen = klen < 0 ? 0 : (klen > T ? T : klen);
+  for (int i = tid; i < H * D / 8; i += 256) {
+    reinterpret_cast<uint4*>(L.q)[i] = reinterpret_cast<const uint4*>(a.qp + (long long)b * H * D)[i];
+    reinterpret_cast<uint4*>(L.dc)[i] = reinterpret_cast<const uint4*>(a.dctx + (long long)b * H * D)[i];
+  }
+  // (d ctx_h[i], q'_h[i]) interleaved as bf16 pairs: the d mem sums take them as one dot2 operand
   for (int i = tid; i < H * D; i += 256) {
-    s_q[i / D][i % D] = bf2f(a.qp[((long long)b * H) * D + i]);
-    s_dc[i / D][i % D] = bf2f(a.dctx[((long long)b * H) * D + i]);
+    const unsigned c = a.dctx[(long long)b * H * D + i], q = a.qp[(long long)b * H * D + i];
+    L.cq[i] = c | (q << 16);
   }
   const int h = wave;                  // one head per wavefront (H <= 4)
   const bool act = h < H;
@@ -195,40 +232,41 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
     float p = 0.f;
     for (int n = lane; n < a.dh; n += 64) p = fmaf(bf2f(a.dout[(long long)b * a.do_bs + h * a.dh + n]), a.bv[h * a.dh + n], p);
     p = wave_sum(p);
-    if (lane == 0) s_dS[h] = p;
+    if (lane == 0) L.dS[h] = p;
   }
   const int nchunk = (T + CK - 1) / CK;
   // ---- scores and d Pd: lane = key
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();
-    stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+    stage_rows(L.mem, mem_b, a.m_rs, c * CK, MR, T, tid);
     __syncthreads();
-    if (act) {
+    if (act && lane < MR) {
       float s0, g0;
-      row_dots<true>(s_mem + lane * RS, s_q[h], s_dc[h], s0, g0);
-      if (c * CK + lane < T) { s_sc[h][c * CK + lane] = s0 * a.inv_sc; s_g[h][c * CK + lane] = g0 + s_dS[h]; }
+      row_dots<true>(L.mem + lane * RS, L.q + h * D, L.dc + h * D, s0, g0);
+      if (c * CK + lane < T) { L.sc[h * TP + c * CK + lane] = s0 * a.inv_sc; L.g[h * TP + c * CK + lane] = g0 + L.dS[h]; }
     }
   }
   __syncthreads();
-  // ---- softmax backward: dS_k = P_k (dP_k - sum P dP) / sqrt(dh) on unmasked keys; Pd for the d mem term
+  // ---- softmax backward: dS_k = P_k (dP_k - sum P dP) / sqrt(dh) on unmasked keys; (Pd_k, dS_k) as a bf16 pair per (head, key)
   if (act) {
-    softmax_row(s_sc[h], T, klen, lane);
+    float* sc = L.sc + h * TP;
+    float* g = L.g + h * TP;
+    softmax_row(sc, T, klen, lane);
     float dot = 0.f;
     for (int k = lane; k < T; k += 64) {
       float keep = 1.f;
       if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
-      const float dp = s_g[h][k] * keep;
-      s_g[h][k] = dp;
-      dot += s_sc[h][k] * dp;
+      const float dp = g[k] * keep;
+      g[k] = dp;
+      dot += sc[k] * dp;
     }
     dot = wave_sum(dot);
     for (int k = lane; k < T; k += 64) {
       float keep = 1.f;
       if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
-      const float p = s_sc[h][k];
-      const float ds = (k < klen) ? p * (s_g[h][k] - dot) * a.inv_sc : 0.f;
-      s_g[h][k] = p * keep;           // Pd
-      s_sc[h][k] = ds;                // dS (already carries the 1 / sqrt(dh) of the score)
+      const float p = sc[k];
+      const float ds = (k < klen) ? p * (g[k] - dot) * a.inv_sc : 0.f;     // (carries the 1 / sqrt(dh) of the score)
+      L.pds[h * TP + k] = (unsigned)f2bf(p * keep) | ((unsigned)f2bf(ds) << 16);
     }
   }
   // ---- d q'_h = sum_k dS_k mem_k: lane = 8 columns
@@ -239,24 +277,19 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
     for (int c = 0; c < nchunk; ++c) {
       if (nchunk > 1) {
         __syncthreads();
-        stage_chunk(s_mem, mem_b, a.m_rs, c * CK, T, tid);
+        stage_rows(L.mem, mem_b, a.m_rs, c * CK, MR, T, tid);
       }
       __syncthreads();
       const int kn = (T - c * CK) < CK ? (T - c * CK) : CK;
       if (act && lane < NCH) {
-        for (int k = 0; k < kn; ++k) {
-          const float ds = s_sc[h][c * CK + k];
-          float m[8];
-          unpack8(*reinterpret_cast<const uint4*>(s_mem + k * RS + lane * 8), m);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] = fmaf(ds, m[i], acc[i]);
-        }
+#pragma unroll 4
+        for (int k = 0; k < kn; ++k) axpy8(acc, *reinterpret_cast<const uint4*>(L.mem + k * RS + lane * 8), L.pds[h * TP + c * CK + k] >> 16);
       }
     }
     if (act && lane < NCH) *reinterpret_cast<uint4*>(a.dqp + ((long long)b * H + h) * D + lane * 8) = pack8(acc);
   }
   __syncthreads();
-  // ---- d mem_k = sum_h Pd_k,h d ctx_h + dS_k,h q'_h: one (key, 8 columns) item per thread
+  // ---- d mem_k = sum_h Pd_k,h d ctx_h + dS_k,h q'_h: one (key, 8 columns) item per thread, one dot2 per (head, column)
   bf16_t* dm_b = a.dmem + (long long)b * a.dm_bs;
   for (int it = tid; it < T * NCH; it += 256) {
     const int k = it / NCH, ch = it - k * NCH;
@@ -264,13 +297,10 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     for (int hh = 0; hh < H; ++hh) {
-      const float pd = s_g[hh][k], ds = s_sc[hh][k];
-      const float4 c0 = *reinterpret_cast<const float4*>(&s_dc[hh][ch * 8]), c1 = *reinterpret_cast<const float4*>(&s_dc[hh][ch * 8 + 4]);
-      const float4 q0 = *reinterpret_cast<const float4*>(&s_q[hh][ch * 8]), q1 = *reinterpret_cast<const float4*>(&s_q[hh][ch * 8 + 4]);
-      acc[0] = fmaf(pd, c0.x, fmaf(ds, q0.x, acc[0])); acc[1] = fmaf(pd, c0.y, fmaf(ds, q0.y, acc[1]));
-      acc[2] = fmaf(pd, c0.z, fmaf(ds, q0.z, acc[2])); acc[3] = fmaf(pd, c0.w, fmaf(ds, q0.w, acc[3]));
-      acc[4] = fmaf(pd, c1.x, fmaf(ds, q1.x, acc[4])); acc[5] = fmaf(pd, c1.y, fmaf(ds, q1.y, acc[5]));
-      acc[6] = fmaf(pd, c1.z, fmaf(ds, q1.z, acc[6])); acc[7] = fmaf(pd, c1.w, fmaf(ds, q1.w, acc[7]));
+      const unsigned pd = L.pds[hh * TP + k];
+      const uint4 c0 = *reinterpret_cast<const uint4*>(L.cq + hh * D + ch * 8), c1 = *reinterpret_cast<const uint4*>(L.cq + hh * D + ch * 8 + 4);
+      acc[0] = dot2(c0.x, pd, acc[0]); acc[1] = dot2(c0.y, pd, acc[1]); acc[2] = dot2(c0.z, pd, acc[2]); acc[3] = dot2(c0.w, pd, acc[3]);
+      acc[4] = dot2(c1.x, pd, acc[4]); acc[5] = dot2(c1.y, pd, acc[5]); acc[6] = dot2(c1.z, pd, acc[6]); acc[7] = dot2(c1.w, pd, acc[7]);
     }
     *reinterpret_cast<uint4*>(dm_b + (long long)k * a.dm_rs + ch * 8) = pack8(acc);
   }
@@ -308,7 +338,7 @@ extern "C" int dmt_q1mem_fwd(const dmt_q1mem_desc* d, void* stream) {
   Q1mArgs a;
   if (fill(a, d, "dmt_q1mem_fwd") != DMT_OK) return DMT_ERR_ARG;
   DMT_CHECK_ARG(d->ctx && d->ctx_hs >= D + 8 && d->ctx_hs % 8 == 0 && (((uintptr_t)d->ctx) & 15) == 0, "dmt_q1mem_fwd: ctx rows need >= d + 8 columns, 16-byte aligned");
-  hipLaunchKernelGGL(q1m_fwd_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(q1m_fwd_kernel, dim3((unsigned)d->B), dim3(256), q1m_lds_bytes(d->T, d->H, false), (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_q1mem_fwd");
   return DMT_OK;
 }
@@ -319,7 +349,7 @@ extern "C" int dmt_q1mem_bwd(const dmt_q1mem_desc* d, void* stream) {
   DMT_CHECK_ARG(d->dctx && d->dout && d->bv && d->dqp && d->dmem, "dmt_q1mem_bwd: null argument");
   DMT_CHECK_ARG((((uintptr_t)d->dctx) & 15) == 0 && (((uintptr_t)d->dqp) & 15) == 0 && (((uintptr_t)d->dmem) & 15) == 0 && d->dm_bs % 8 == 0 && d->dm_rs % 8 == 0,
                 "dmt_q1mem_bwd: rows must be 16-byte aligned");
-  hipLaunchKernelGGL(q1m_bwd_kernel, dim3((unsigned)d->B), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(q1m_bwd_kernel, dim3((unsigned)d->B), dim3(256), q1m_lds_bytes(d->T, d->H, true), (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_q1mem_bwd");
   return DMT_OK;
 }
