@@ -301,11 +301,24 @@ class DMTEngine:
         self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
         # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
+        self._use_mhsa = False
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
+
+    @property
+    def use_mhsa(self):
+        return self._use_mhsa
+
+    @use_mhsa.setter
+    def use_mhsa(self, on):
+        """The store rebuilds the block's weight images after every optimizer step only while the block is in use."""
+        self._use_mhsa = bool(on)
+        if self._use_mhsa and not self.store.mhsa_in_use:
+            self.store.mhsa_in_use = True
+            self.store.refresh_shadows()
 
     def gather_bytes(self, batch, seq_T) -> float:
         """Algorithmic HBM bytes of one gather launch: int32 indices read once, fp32 table rows for

@@ -65,6 +65,7 @@ class VariableStore:
         self.spec = spec
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
+        self.mhsa_in_use = False          # set by the engine when the fused self-attention block is selected
         self.shard = (int(table_shard[0]), int(table_shard[1])) if table_shard is not None else None
         if self.shard is not None and not (0 <= self.shard[0] < self.shard[1]):
             raise ValueError("table_shard = (rank, world) with 0 <= rank < world")
@@ -340,8 +341,9 @@ class VariableStore:
                 triples.append((bqkv[2 * dm: 3 * dm].view(1, dm), None, blk[:, dm: dm + 1]))
             self._cast_jobs = ops.cast_shadow_jobs(triples, self.device)
         ops.cast_shadow_batched(self._cast_jobs)
-        for scope, img in self.mhsa.items():
-            ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
+        if self.mhsa_in_use:              # (the one-launch self-attention block is optional: DMTEngine.use_mhsa)
+            for scope, img in self.mhsa.items():
+                ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
         for scope, ch in self.chain.items():
             w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
             # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]
