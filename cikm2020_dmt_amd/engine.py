@@ -303,6 +303,7 @@ class DMTEngine:
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
         self._use_mhsa = False
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") == "1"        # one stream per behaviour sequence
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
@@ -499,15 +500,41 @@ class DMTEngine:
     def embedding_trans(self, batch: DeviceBatch):
         X, tar, zbuf = self.gather(batch)
         us = []
+        n_seq = len(self.spec["attention_embed_pairs"])
+        # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
+        # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
+        # of one sequence's decoder fill the tails of another's big kernels.
+        main = torch.cuda.current_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
+        side = self._seq_stream_pool(n_seq) if main is not None else None
         for i, pairs in enumerate(self.spec["attention_embed_pairs"]):
             lens = batch.feats[pairs[-1][0]].lens          # mask / lens come from the LAST pair (mmoe_transformer.py:137-142)
-            mem = self.encode_prepared(X[i], lens, i)
-            y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
+            if side is not None and side[i] is not None:
+                side[i].wait_stream(main)
+                X[i].record_stream(side[i])            # (allocated on the compute stream, read on this one)
+                tar.record_stream(side[i])
+                with torch.cuda.stream(side[i]):
+                    mem = self.encode_prepared(X[i], lens, i)
+                    y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
+                    y.record_stream(main)
+                    mem.record_stream(main)
+            else:
+                mem = self.encode_prepared(X[i], lens, i)
+                y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
             us.append(y.squeeze(1))
             self.intermediates["memory_%d" % i] = mem
+        if side is not None:
+            for st in side:
+                if st is not None:
+                    main.wait_stream(st)
         z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *us)
         self.intermediates["zbuf"] = z
         return z
+
+    def _seq_stream_pool(self, n):
+        if getattr(self, "_seq_streams", None) is None or len(self._seq_streams) != n:
+            # sequence 0 stays on the compute stream
+            self._seq_streams = [None] + [torch.cuda.Stream(self.store.device) for _ in range(n - 1)]
+        return self._seq_streams
 
     def expert_gate(self, z, want_mix=False):
         """Per-task mixtures; want_mix: as ONE [T, B, U] tensor (for heads()), else a list of [B, U] (reference shape)."""
