@@ -243,7 +243,9 @@ class Trainer:
             all_r.copy_(r_loc)
         return (plan["all_k"], plan["n_dev"], all_r, W * cap_m)
 
-    def forward_backward(self, batch: DeviceBatch):
+    def forward_backward(self, batch: DeviceBatch, join: bool = True):
+        """join=False leaves the side-stream weight gradients (ops._wgrad_defer) open: the caller must ops.join_wgrad() before it
+        reads the dense gradient arena."""
         self.sync_rows(batch)
         self.store.zero_grad()
         rank, _W = parallel.world()
@@ -264,6 +266,8 @@ class Trainer:
                     return g
                 z.register_hook(_hook)
         loss.backward()
+        if join:
+            ops.join_wgrad(self.device)           # weight gradients issued on side streams (ops._wgrad_defer)
         self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
         return loss.detach()
@@ -347,10 +351,20 @@ class Trainer:
         return (uniq2, n_uniq2, out_rows, capm)
 
     def train_step(self, batch: DeviceBatch):
-        loss = self.forward_backward(batch)
         rank, W = parallel.world()
+        dp = W > 1 or (self.force_dp and parallel.dist.is_initialized())
+        loss = self.forward_backward(batch, join=dp)
         sparse = self.engine.sparse
-        if W > 1 or (self.force_dp and parallel.dist.is_initialized()):
+        if not dp:
+            # the embedding rows first: the last weight gradients are still accumulating on their side streams meanwhile
+            self.opt.begin()
+            self.opt.apply_sparse(sparse, 1.0)
+            ops.join_wgrad(self.device)
+            self.opt.apply_dense(1.0)
+            self.opt.end()
+            self.store.refresh_shadows()
+            return loss
+        if dp:
             early, self._early = getattr(self, "_early", None), None
             self.early_allreduce_used = early is not None
             if early is not None:
