@@ -111,9 +111,9 @@ def main():
         torch.cuda.synchronize()
 
     def step(i):
-        b = batches[i % nb]
-        b._prep = None          # every step re-sorts its indices, as a fresh batch would
-        return tr.train_step(b)
+        b, nxt = batches[i % nb], batches[(i + 1) % nb]
+        nxt._prep = None        # every step sorts the ids of one batch, as fresh batches would need: the NEXT one's, while this step runs
+        return tr.train_step(b, prefetch=nxt)
 
     for i in range(args.warmup):
         step(i)

@@ -201,7 +201,7 @@ WGRAD320_MIN_ROWS = 16384
 # arena with fp32 atomics there.  The dX chain of the next layer starts at once, and the tail of the weight-gradient work runs
 # beside the id-bound end of the step (embedding-gradient reduction, sparse Adam, next gather).  join_wgrad() -- called by the
 # Trainer, and queued as an end-of-backward callback for everybody else -- orders the consumer behind them.
-WGRAD_STREAMS = os.environ.get("DMT_WGRAD_STREAMS", "1") == "1"
+WGRAD_STREAMS = os.environ.get("DMT_WGRAD_STREAMS", "0") == "1"
 _wgrad_pool, _wgrad_open, _wgrad_cb = {}, {}, [False]
 
 

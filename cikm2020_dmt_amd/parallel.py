@@ -26,6 +26,23 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+_index_group = {"world": None, "group": None}
+
+
+def index_group():
+    """The communicator of the INDEX PLANE (row ids, counts: Trainer.plan_exchange).  RCCL: a second communicator, hence its own
+    stream -- the id exchange of batch i + 1 is not ordered behind the gradient collectives of batch i, so it can run (and its two
+    host syncs can return) while step i computes.  Created collectively on first use (every rank reaches its first plan_exchange at
+    the same point of the program); other backends share the default group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+        return None
+    world_pg = dist.distributed_c10d._get_default_group()
+    if _index_group["world"] is not world_pg:          # (a new default group after destroy_process_group + init_process_group)
+        _index_group["world"] = world_pg
+        _index_group["group"] = dist.new_group(backend="nccl")
+    return _index_group["group"]
+
+
 def allreduce_dense_(flat_grads: torch.Tensor, async_op: bool = False, force: bool = False):
     """Sum the flat gradient arena over ranks in place (the mean is applied by the optimizer's grad_scale).
     `force`: issue the collective even in a one-rank group (exercises the real RCCL call on a one-GPU box)."""
@@ -34,12 +51,12 @@ def allreduce_dense_(flat_grads: torch.Tensor, async_op: bool = False, force: bo
     return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
-def _all_gather_cat(dst: torch.Tensor, loc: torch.Tensor, W: int, cap: int):
+def _all_gather_cat(dst: torch.Tensor, loc: torch.Tensor, W: int, cap: int, group=None):
     if dist.get_backend() == "nccl" and hasattr(dist, "all_gather_into_tensor"):
-        dist.all_gather_into_tensor(dst, loc)      # one RCCL all-gather straight into the rank-major buffer
+        dist.all_gather_into_tensor(dst, loc, group=group)      # one RCCL all-gather straight into the rank-major buffer
         return
     parts = [torch.empty_like(loc) for _ in range(W)]
-    dist.all_gather(parts, loc)
+    dist.all_gather(parts, loc, group=group)
     for r in range(W):
         dst[r * cap:(r + 1) * cap] = parts[r]
 
@@ -81,15 +98,15 @@ def allgather_sparse(keys: torch.Tensor, rows: torch.Tensor, n: int, invalid_key
     return all_k, all_r, cap
 
 
-def _a2a(dst: torch.Tensor, src: torch.Tensor, recv_splits, send_splits):
+def _a2a(dst: torch.Tensor, src: torch.Tensor, recv_splits, send_splits, group=None):
     """all_to_all_single along dim 0 with uneven splits.  RCCL moves device tensors directly (one send/recv per peer: on the
     xGMI full mesh every pair has its own link); gloo (tests) only implements the CPU form, so device tensors are staged."""
     if dist.get_backend() != "nccl" and src.is_cuda:
         d_cpu = torch.empty(dst.shape, dtype=dst.dtype)
-        dist.all_to_all_single(d_cpu, src.cpu(), recv_splits, send_splits)
+        dist.all_to_all_single(d_cpu, src.cpu(), recv_splits, send_splits, group=group)
         dst.copy_(d_cpu)
         return
-    dist.all_to_all_single(dst, src, recv_splits, send_splits)
+    dist.all_to_all_single(dst, src, recv_splits, send_splits, group=group)
 
 
 def owner_of(keys: torch.Tensor, W: int) -> torch.Tensor:

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib as L
-from . import ops, parallel
+from . import ops, parallel, streams
 from .engine import DeviceBatch, DMTEngine
 from .optim import TFAdam
 from .variables import VariableStore
@@ -70,36 +70,60 @@ class Trainer:
         if os.environ.get("DMT_DETERMINISTIC") == "1" and not ops.DETERMINISTIC:
             ops.set_deterministic(True)
         self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
+        if self.device.type == "cuda":
+            streams.lanes(self.device)                     # bind the step's lanes to hardware queues before anything else (streams.py)
+            if self._dp_active():
+                streams.warm_communicators(self.device)
 
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
 
-    def sync_rows(self, batch: DeviceBatch, for_training: bool = True):
-        """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them; in a data-parallel
-        training step also the index plane of the gradient exchange (plan_exchange)."""
-        need_plan = (for_training or self.table_layout == "sharded") and self._dp_active() and self.dp_exchange == "owner"
+    def _needs_plan(self, for_training):
+        return (for_training or self.table_layout == "sharded") and self._dp_active() and self.dp_exchange == "owner"
+
+    def _index_plane(self, batch: DeviceBatch, need_plan: bool):
+        """engine.prepare (+ plan_exchange) for a batch.  Everything here depends on the batch's ids only -- not on any step's results --
+        so it runs on its own stream, next to whatever the compute stream has queued, and its host syncs wait for THIS stream only:
+        the compute stream never drains.  prep["_ready"] is the event the compute stream waits for before it touches the result."""
+        side = self._index_stream()
+        if side is None:
+            prep = self.engine.prepare(batch)
+            if need_plan and "xplan" not in prep:
+                prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
+            return prep
+        main = torch.cuda.current_stream(self.device)
+        if batch.ready is not None:
+            side.wait_event(batch.ready)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            prep = self.engine.prepare(batch)
+            if need_plan and "xplan" not in prep:
+                prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
+            _record_stream(prep, main)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        prep["_ready"] = ev
+        return prep
+
+    def prefetch(self, batch: DeviceBatch, for_training: bool = True):
+        """Start the index plane of a LATER batch now (call it with batch i + 1 while step i is being issued: train_step(prefetch=)).
+        In a data-parallel step the id exchange and its host syncs then overlap step i instead of opening step i + 1."""
+        need_plan = self._needs_plan(for_training)
         prep = getattr(batch, "_prep", None)
         if prep is None or (need_plan and "xplan" not in prep):
-            # Everything here depends on the batch's ids only -- not on the previous step's results -- so it runs on its own stream,
-            # next to whatever the compute stream still has queued (the tail of the previous step), and its host syncs wait for THIS
-            # stream only: the compute stream never drains.
-            side = self._index_stream()
-            if side is None:
-                prep = self.engine.prepare(batch)
-                if need_plan and "xplan" not in prep:
-                    prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
-            else:
-                main = torch.cuda.current_stream(self.device)
-                if batch.ready is not None:
-                    side.wait_event(batch.ready)
-                else:
-                    side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    prep = self.engine.prepare(batch)
-                    if need_plan and "xplan" not in prep:
-                        prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
-                    _record_stream(prep, main)
-                main.wait_stream(side)
+            self._index_plane(batch, need_plan)
+
+    def sync_rows(self, batch: DeviceBatch, for_training: bool = True):
+        """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them; in a data-parallel
+        training step also the index plane of the gradient exchange (plan_exchange), unless prefetch() already ran it."""
+        need_plan = self._needs_plan(for_training)
+        prep = getattr(batch, "_prep", None)
+        if prep is None or (need_plan and "xplan" not in prep):
+            prep = self._index_plane(batch, need_plan)
+        ev = prep.pop("_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
         if self.table_layout == "sharded":
             self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
             return prep
@@ -111,7 +135,7 @@ class Trainer:
         if self.device.type != "cuda" or not self.index_stream:
             return None
         if self._ix_stream is None:
-            self._ix_stream = torch.cuda.Stream(self.device)
+            self._ix_stream = streams.lanes(self.device)["index"]
         return self._ix_stream
 
     def _dp_active(self):
@@ -142,9 +166,10 @@ class Trainer:
         L.call("dmt_sort_pairs", ops.p(owner), ops.p(own_s), ops.p(iota), ops.p(perm32), cap, end_bit, ops.p(ws), C.byref(have), ops.stream_ptr())
         edges = torch.searchsorted(own_s, torch.arange(W + 1, dtype=torch.int32, device=dev))
         counts = edges[1:] - edges[:-1]
+        grp = parallel.index_group() if parallel.dist.is_initialized() else None
         if parallel.dist.is_initialized():
             mat = [torch.zeros_like(counts) for _ in range(W)]
-            parallel.dist.all_gather(mat, counts)
+            parallel.dist.all_gather(mat, counts, group=grp)
             M = torch.stack(mat).cpu()                                    # host sync 1 of 2 (before the forward pass)
         else:
             M = counts.cpu().reshape(1, 1)
@@ -154,7 +179,7 @@ class Trainer:
         send_k = uniq.index_select(0, perm)
         recv_k = torch.empty((Rn,), dtype=uniq.dtype, device=dev)
         if parallel.dist.is_initialized():
-            parallel._a2a(recv_k, send_k, recv_splits, send_splits)
+            parallel._a2a(recv_k, send_k, recv_splits, send_splits, group=grp)
         else:
             recv_k.copy_(send_k)
         plan = dict(n=n, R=Rn, perm=perm, send_splits=send_splits, recv_splits=recv_splits, recv_k=recv_k)
@@ -172,7 +197,7 @@ class Trainer:
         cnt = plan["n_uniq2"].to(torch.int64)
         if parallel.dist.is_initialized():
             cnts = [torch.zeros_like(cnt) for _ in range(W)]
-            parallel.dist.all_gather(cnts, cnt)
+            parallel.dist.all_gather(cnts, cnt, group=grp)
             c_host = torch.stack(cnts).reshape(-1).cpu()                  # host sync 2 of 2 (still before the forward pass)
         else:
             c_host = cnt.cpu()
@@ -182,7 +207,7 @@ class Trainer:
         k_loc[:m] = plan["uniq2"][:m]
         all_k = torch.empty((W * cap_m,), dtype=uniq.dtype, device=dev)
         if parallel.dist.is_initialized():
-            parallel._all_gather_cat(all_k, k_loc, W, cap_m)
+            parallel._all_gather_cat(all_k, k_loc, W, cap_m, group=grp)
         else:
             all_k.copy_(k_loc)
         plan.update(m=m, cap_m=cap_m, all_k=all_k, n_dev=torch.full((1,), W * cap_m, dtype=torch.int32, device=dev))
@@ -243,15 +268,17 @@ class Trainer:
             all_r.copy_(r_loc)
         return (plan["all_k"], plan["n_dev"], all_r, W * cap_m)
 
-    def forward_backward(self, batch: DeviceBatch, join: bool = True):
+    def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None):
         """join=False leaves the side-stream weight gradients (ops._wgrad_defer) open: the caller must ops.join_wgrad() before it
-        reads the dense gradient arena."""
+        reads the dense gradient arena.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
         self.sync_rows(batch)
         self.store.zero_grad()
         rank, _W = parallel.world()
         self.engine.dropout_step_seed = (self.dropout_seed + self.opt.global_step + 7919 * rank) if self.dropout else None
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
+        if prefetch is not None and prefetch is not batch:
+            self.prefetch(prefetch)
         self._early = None
         if _W > 1 or (self.force_dp and parallel.dist.is_initialized()):
             # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
@@ -350,10 +377,10 @@ class Trainer:
                st.total_rows, ops.p(all_r), ops.p(out_rows), int(grad_rows.shape[1]), ws, wsb, ops.stream_ptr())
         return (uniq2, n_uniq2, out_rows, capm)
 
-    def train_step(self, batch: DeviceBatch):
+    def train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):
         rank, W = parallel.world()
         dp = W > 1 or (self.force_dp and parallel.dist.is_initialized())
-        loss = self.forward_backward(batch, join=dp)
+        loss = self.forward_backward(batch, join=dp, prefetch=prefetch)
         sparse = self.engine.sparse
         if not dp:
             # the embedding rows first: the last weight gradients are still accumulating on their side streams meanwhile

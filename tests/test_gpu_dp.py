@@ -189,12 +189,18 @@ def _nccl_world1_step(q, bf16):
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
     states = []
-    for force in (False, True):
+    for force, ahead in ((False, False), (True, False), (True, True)):
         tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, force_dp=force, dropout=False)
         tr.store.load_state(P)
+        bs = []
         for s_ in range(3):
             inputs, mask, _ = make_batch(sp, 9, seed=300 + s_, lengths="ragged", weights="random")
-            tr.train_step(tr.make_batch(inputs, mask))
+            bs.append(tr.make_batch(inputs, mask))
+        for s_ in range(3):
+            # ahead: the id exchange of batch s + 1 (second communicator, index stream) is issued inside step s
+            tr.train_step(bs[s_], prefetch=bs[s_ + 1] if (ahead and s_ < 2) else None)
+            if ahead and s_ < 2:
+                assert "xplan" in bs[s_ + 1]._prep
         if force:
             assert tr.early_allreduce_used
         tr.opt.flush_tables()
@@ -202,6 +208,9 @@ def _nccl_world1_step(q, bf16):
         states.append(tr.store.state_dict())
     worst = max(float(np.abs(states[0][k] - states[1][k]).max()) for k in states[0])
     same = all(np.array_equal(states[0][k], states[1][k]) for k in states[0])
+    same = same and all(np.array_equal(states[1][k], states[2][k]) for k in states[0]) if not bf16 else same
+    if bf16:
+        worst = max(worst, max(float(np.abs(states[1][k] - states[2][k]).max()) for k in states[0]))
     q.put((same, worst))
     dist.destroy_process_group()
 

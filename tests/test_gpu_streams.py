@@ -61,3 +61,39 @@ def test_sequence_streams_full_size_default_mode(cuda):
         assert ((g1 - g0).norm() / g0.norm()).item() < 2e-3
         assert (g1 - g0).abs().max().item() < 2e-2 * g0.abs().max().item()
         assert ((r1 - r0).norm() / r0.norm()).item() < 2e-3
+
+
+def _lanes_worker(q, rccl):
+    import os
+    import torch
+    from cikm2020_dmt_amd import spec as S
+    from cikm2020_dmt_amd import streams
+    from cikm2020_dmt_amd.train import Trainer
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if rccl:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29577"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # (communicator set-up uses streams of its own)
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120})
+    Trainer(sp, device=dev, compute_dtype=torch.bfloat16, seed=1, force_dp=rccl)
+    ln = streams.lanes(dev)
+    groups = streams.queue_groups([torch.cuda.default_stream(dev), ln["index"], ln["seq"][0], ln["seq"][1]], ["compute", "index", "seq1", "seq2"])
+    q.put((groups, ln["distinct"]))
+    if rccl:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_lanes_are_bound_to_four_hardware_queues(cuda, rccl):
+    """streams.py: the compute / index / sequence-1 / sequence-2 streams of a process each sit on their own hardware queue -- also
+    after an RCCL communicator was set up first --, measured with the head-of-line probe."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_lanes_worker, args=(q, rccl))
+    p_.start()
+    groups, distinct = q.get(timeout=300)
+    p_.join(60)
+    assert p_.exitcode == 0
+    assert distinct == 4 and len(groups) == 4, (groups, distinct)
