@@ -237,6 +237,17 @@ class GatherFn(torch.autograd.Function):
         engine, batch = ctx.engine, ctx.batch
         spec = engine.spec
         n_seq = len(spec["attention_embed_pairs"])
+        if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None for pl in ctx.pos_leaves):
+            # Trainer.train_step finishes this node itself (finish_sparse_backward), on the index lane, beside the deferred weight gradients
+            engine._pending_sparse = (ctx, grads)
+            return (None, None) + (None,) * n_seq
+        return GatherFn._finish(ctx, grads)
+
+    @staticmethod
+    def _finish(ctx, grads):
+        engine, batch = ctx.engine, ctx.batch
+        spec = engine.spec
+        n_seq = len(spec["attention_embed_pairs"])
         dX = [g.contiguous() if g is not None else None for g in grads[:n_seq]]
         dtar, dz = grads[n_seq], grads[n_seq + 1]
         B, d = batch.B, spec["d_model"]
@@ -303,6 +314,7 @@ class DMTEngine:
         # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
         self._use_mhsa = False
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.defer_sparse, self._pending_sparse = False, None     # GatherFn.backward leaves its work to finish_sparse_backward()
         self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") != "0"        # side streams for the behaviour sequences
         self.seq_stream_mode = "dec" if os.environ.get("DMT_SEQ_STREAMS", "1") == "dec" else "seq"
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
@@ -764,6 +776,21 @@ class DMTEngine:
         if self.dropout_step_seed is None or not rate:
             return [0] * n_seq, 0.0
         return [ops.site_seed(self.dropout_step_seed, 10 * s + 0) for s in range(n_seq)], 1.0 - rate
+
+    def finish_sparse_backward(self):
+        """The deferred tail of backward (GatherFn.backward with defer_sparse): position-table gradients, zero + segment-reduce of the
+        embedding-gradient rows -> self.sparse.  Runs on the CURRENT stream; the caller orders it behind backward."""
+        pend, self._pending_sparse = self._pending_sparse, None
+        if pend is None:
+            return False
+        ctx, grads = pend
+        cur = torch.cuda.current_stream(self.store.device)
+        for g in grads:
+            if g is not None and g.is_cuda:
+                g.record_stream(cur)
+        out = GatherFn._finish(ctx, grads)
+        assert all(o is None for o in out)        # (position gradients went straight into the arena)
+        return True
 
     def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz, drop=None):
         plan = self.plan

@@ -205,6 +205,24 @@ WGRAD_STREAMS = os.environ.get("DMT_WGRAD_STREAMS", "0") == "1"
 _wgrad_pool, _wgrad_open, _wgrad_cb = {}, {}, [False]
 
 
+_deferred = [None]      # list of closures while a Trainer step collects its long-row weight gradients (begin_deferred_wgrads)
+
+
+def begin_deferred_wgrads():
+    """From now on the long-row weight gradients of backward are COLLECTED instead of launched: nothing in backward reads them, so
+    the dX chain -- the critical path to the embedding gradients -- runs through first; run_deferred_wgrads() launches them afterwards
+    (Trainer.train_step: beside the id-bound tail of the step, which runs on the index lane meanwhile)."""
+    _deferred[0] = []
+
+
+def run_deferred_wgrads():
+    """Launch what begin_deferred_wgrads() collected, on the current stream, in backward order; -> how many."""
+    todo, _deferred[0] = _deferred[0], None
+    for fn in todo or ():
+        fn()
+    return len(todo or ())
+
+
 def _wgrad_defer(x, dz):
     """-> (event-ordered side stream) for this weight gradient, or None: same stream."""
     if not (WGRAD_STREAMS and not DETERMINISTIC and x.is_cuda and x.shape[0] >= WGRAD320_MIN_ROWS):
@@ -225,6 +243,16 @@ def _wgrad_defer(x, dz):
         except RuntimeError:       # not inside a backward pass: the caller joins
             pass
     return ws
+
+
+def _deferred_wgrad320(x, dz, gw, gb, k_is_320):
+    cur = torch.cuda.current_stream(x.device)
+    x.record_stream(cur)          # (operands of the side-lane sequences were allocated on their streams)
+    dz.record_stream(cur)
+    if k_is_320:
+        wgrad320(x, dz, gw, False, gb, 1)
+    else:
+        wgrad320(dz, x, gw, True, gb, 2)
 
 
 def _wgrad_end_of_backward():
@@ -278,6 +306,9 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
             and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
             and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
         # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block
+        if _deferred[0] is not None:
+            _deferred[0].append(lambda: _deferred_wgrad320(x, dz, gw, gb if want_bias else None, K == 320))
+            return None, None
         ws = _wgrad_defer(x, dz)
         with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
             if K == 320:

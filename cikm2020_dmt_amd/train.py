@@ -69,6 +69,7 @@ class Trainer:
         self.force_dp = bool(force_dp)
         if os.environ.get("DMT_DETERMINISTIC") == "1" and not ops.DETERMINISTIC:
             ops.set_deterministic(True)
+        self.sparse_lane = os.environ.get("DMT_SPARSE_LANE", "0") == "1"     # one-GPU step: id-bound tail beside the deferred weight gradients (off: even at L=50, -3 % at L=200)
         self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
         if self.device.type == "cuda":
             streams.lanes(self.device)                     # bind the step's lanes to hardware queues before anything else (streams.py)
@@ -279,6 +280,10 @@ class Trainer:
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
         if prefetch is not None and prefetch is not batch:
             self.prefetch(prefetch)
+        defer = (not join) and self.sparse_lane and self.device.type == "cuda" and self._index_stream() is not None
+        if defer:
+            ops.begin_deferred_wgrads()
+            self.engine.defer_sparse = True
         self._early = None
         if _W > 1 or (self.force_dp and parallel.dist.is_initialized()):
             # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
@@ -292,7 +297,14 @@ class Trainer:
                         self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True, force=self.force_dp))
                     return g
                 z.register_hook(_hook)
-        loss.backward()
+        try:
+            loss.backward()
+        except BaseException:
+            ops._deferred[0] = None
+            self.engine._pending_sparse = None
+            raise
+        finally:
+            self.engine.defer_sparse = False
         if join:
             ops.join_wgrad(self.device)           # weight gradients issued on side streams (ops._wgrad_defer)
         self.engine.dropout_step_seed = None
@@ -383,6 +395,25 @@ class Trainer:
         loss = self.forward_backward(batch, join=dp, prefetch=prefetch)
         sparse = self.engine.sparse
         if not dp:
+            lane = self._index_stream() if self.engine._pending_sparse is not None else None
+            if lane is not None:
+                # TWO LANES from here: the id-bound tail of the step (position / embedding-row gradients, sparse Adam: HBM-latency
+                # work on few wavefronts) on the index lane, the long-row weight gradients backward skipped (MFMA work) on the compute
+                # stream; they meet at the dense Adam.
+                main = torch.cuda.current_stream(self.device)
+                lane.wait_stream(main)
+                with torch.cuda.stream(lane):
+                    self.engine.finish_sparse_backward()
+                    self.opt.begin()
+                    self.opt.apply_sparse(self.engine.sparse, 1.0)
+                ops.run_deferred_wgrads()
+                ops.join_wgrad(self.device)
+                main.wait_stream(lane)
+                self.opt.apply_dense(1.0)
+                self.opt.end()
+                self.store.refresh_shadows()
+                return loss
+            ops.run_deferred_wgrads()
             # the embedding rows first: the last weight gradients are still accumulating on their side streams meanwhile
             self.opt.begin()
             self.opt.apply_sparse(sparse, 1.0)

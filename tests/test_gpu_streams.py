@@ -19,9 +19,10 @@ def test_sequence_streams_change_nothing_but_the_schedule(cuda, dtype, B):
     try:
         sp = S.scaled_spec(S.e64_spec(), {"Sku": 20000, "Brand": 3000, "Shopid": 3000, "Cid3": 1200})
         ref = None
-        for streams in (False, True, True, True):
+        for streams, lane in ((False, False), (True, False), (True, False), (True, True), (False, True)):
             tr = Trainer(sp, device=cuda, compute_dtype=dtype, seed=5, dropout=True)
             tr.engine.seq_streams = streams
+            tr.sparse_lane = lane          # id-bound tail of the step on the index lane (Trainer.train_step)
             losses = []
             for s in range(3):
                 inputs, mask, _ = make_batch(sp, B, seed=80 + s, lengths="ragged", weights="random")
@@ -37,6 +38,34 @@ def test_sequence_streams_change_nothing_but_the_schedule(cuda, dtype, B):
                 assert np.array_equal(state[k].view(np.uint32), ref[1][k].view(np.uint32)), k
     finally:
         ops.set_deterministic(False)
+
+
+def test_sparse_lane_with_deferred_weight_gradients_default_mode(cuda):
+    """Default mode, bf16: the long-row weight gradients collected during backward and launched afterwards, the embedding-gradient tail
+    and the sparse Adam on the index lane -- three steps end in the same state as the plain schedule up to atomic-order rounding."""
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 20000, "Brand": 3000, "Shopid": 3000, "Cid3": 1200})
+    states = []
+    for lane in (False, False, True):
+        tr = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=5, dropout=True)
+        tr.sparse_lane = lane
+        for s in range(3):
+            inputs, mask, _ = make_batch(sp, 2048, seed=80 + s, lengths="full")     # 2048 x 50 rows: the wgrad320 path, deferred
+            tr.train_step(tr.make_batch(inputs, mask))
+        assert ops._deferred[0] is None and tr.engine._pending_sparse is None
+        tr.opt.flush_tables()
+        torch.cuda.synchronize()
+        states.append(tr.store.state_dict())
+    # the yardstick is the plain schedule against ITSELF: fp32 atomics make two runs differ, and the first Adam steps turn the sign of
+    # a rounding-level gradient into a full +-lr move
+    tot_noise = tot_lane = 0.0
+    for k in states[0]:
+        a, b, c = (st[k].astype(np.float64) for st in states)
+        noise, lane_d = np.abs(a - b).mean(), np.abs(a - c).mean()
+        tot_noise += noise
+        tot_lane += lane_d
+        assert lane_d <= 4.0 * noise + 2e-5, (k, lane_d, noise)
+        assert np.abs(a - c).max() <= 6.5e-3, k           # three steps at lr 1e-3: +-2 lr per step at most
+    assert tot_lane <= 2.0 * tot_noise + 1e-6, (tot_lane, tot_noise)
 
 
 def test_sequence_streams_full_size_default_mode(cuda):
