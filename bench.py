@@ -125,6 +125,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    # the same kernels with the chip to themselves: a few extra steps (outside the timed region) with the sequences' streams serialised
+    prof_x, steps_x = None, 4
+    if tr.engine.seq_streams:
+        tr.engine.seq_streams = False
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ops.PROFILE = {}
+        for i in range(steps_x):
+            step(args.warmup + args.steps + 1 + i)
+        torch.cuda.synchronize()
+        prof_x, ops.PROFILE = ops.PROFILE, None
+        tr.engine.seq_streams = True
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -156,16 +168,33 @@ def main():
         "mmoe_experts": "mmoe_experts_fwd/bwd_kernel (dmt_mmoe.hip): expert layers 1-2 + gates + mixtures",
     }
     fams = []
+
+    def agg_x(key):
+        ent = (prof_x or {}).get(key, [])
+        return len(ent), sum(e0.elapsed_time(e1) for (e0, e1, _w) in ent) * 1e-3, sum(w for (_a, _b, w) in ent)
+
     for key, desc_ in fam_desc.items():
         n_k, t_k, fl_k = agg(key)
         if n_k == 0 or t_k <= 0:
             continue
         byts = prof.get(key + "_bytes", prof.get("gemm_bytes", []) if key.startswith("gemm") else [])
-        fams.append({"key": key, "kernel": desc_, "bound": "mfma", "achieved": round(fl_k / t_k / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(fl_k / t_k / 1e12 / peak, 4), "traffic": None, "launches_per_step": round(n_k / max(args.steps, 1), 1),
-                     "avg_launch_us": round(t_k / n_k * 1e6, 2), "time_share": round(t_k / dt, 3),
+        in_step = {"avg_launch_us": round(t_k / n_k * 1e6, 2), "achieved": round(fl_k / t_k / 1e12, 2), "frac": round(fl_k / t_k / 1e12 / peak, 4),
+                   "note": "HIP events around the launch INSIDE the timed region: with three sequence lanes in flight this includes the time the "
+                           "launch queues behind, and shares the chip with, kernels of the other lanes"}
+        n_x, t_x, fl_x = agg_x(key)
+        if n_x > 0 and t_x > 0:
+            # the kernel's own duration: the same launches, same process, lanes serialised (steps_x extra steps right after the timed region)
+            n_m, t_m, fl_m, how = n_x, t_x, fl_x, ("HIP events on the launch stream, %d steps of the same workload run right after the timed region with "
+                                                   "the sequence lanes serialised (one kernel on the chip at a time)" % steps_x)
+        else:
+            n_m, t_m, fl_m, how = n_k, t_k, fl_k, "HIP events on the launch stream over the timed region"
+        fams.append({"key": key, "kernel": desc_, "bound": "mfma", "achieved": round(fl_m / t_m / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(fl_m / t_m / 1e12 / peak, 4), "traffic": None, "launches_per_step": round(n_k / max(args.steps, 1), 1),
+                     "avg_launch_us": round(t_m / n_m * 1e6, 2), "measured": how,
+                     "time_share": round((t_m / n_m) * (n_k / max(args.steps, 1)) / (dt / args.steps), 3),
                      "algorithmic_flop_per_launch": int(fl_k / n_k),
-                     "algorithmic_bytes_per_launch": int(sum(byts) / n_k) if byts else None})
+                     "algorithmic_bytes_per_launch": int(sum(byts) / n_k) if byts else None,
+                     "in_step": in_step})
     fams.sort(key=lambda f: -f["time_share"])
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process (rocprofv3 wraps it); the committed
     # measurement of the same command is quoted (profiles/r02_traffic.json, made by scripts/pmc_traffic.sh: separate --pmc passes,
@@ -187,14 +216,16 @@ def main():
     # dmt_gemm family spans three kernels and is listed with the others
     single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts")] or fams
     roofline = dict(single[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
-    n_ga, t_ga, by_ga = agg("gather_fwd")
+    ga_x = bool((prof_x or {}).get("gather_fwd"))
+    n_ga, t_ga, by_ga = agg_x("gather_fwd") if ga_x else agg("gather_fwd")
+    ga_per_step = n_ga / max(steps_x if ga_x else args.steps, 1)
     gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",
               "achieved": round(by_ga / t_ga / 1e9, 1) if t_ga > 0 else None, "peak": 8000.0, "unit": "GB/s",
               "frac": round(by_ga / t_ga / 8e12, 4) if t_ga > 0 else None, "avg_launch_us": round(t_ga / max(n_ga, 1) * 1e6, 2),
               "bytes_per_launch": int(by_ga / max(n_ga, 1)), "traffic": None}
     tg = tj.get("gather_fwd")
     if tg:
-        gather["traffic"] = int(tg["hbm_bytes_per_step"] / max(n_ga / max(args.steps, 1), 1e-9))   # one dmt_gather_fwd call = its group kernels
+        gather["traffic"] = int(tg["hbm_bytes_per_step"] / max(ga_per_step, 1e-9))   # one dmt_gather_fwd call = its group kernels
         gather["traffic_source"] = "profiles/r02_traffic.json (same method; the Zipf head is served by L2 / Infinity Cache, uniform ids are not)"
 
     out = {
