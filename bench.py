@@ -160,6 +160,7 @@ def main():
         "chain2": "chain2_kernel<Geo<320,1280,320>> (dmt_chain.hip): fused feed-forward + residual + LayerNorm forward (mode 0) and its input-gradient pass (mode 1)",
         "gemm_bf16": "gemm_glds_kernel / gemm_dw_glds_kernel / gemm_kernel<bf16> (dmt_gemm.hip): QKV / decoder / MMoE / tower GEMMs and their gradients",
         "gemm_f32": "gemm_kernel<float> (dmt_gemm.hip)",
+        "proj": "proj_kernel<PGeo<320,960>> (dmt_chain.hip): packed Q | K | V projection, input rows stationary in registers, weights streamed as an LDS image",
         "wgrad320": "wgrad320_kernel (dmt_dw.hip): K=320 / N=320 weight gradients over the long row dimension",
         "attn_long": "attn_long_fwd/bwd_kernel + attn_q1_long_kernel (dmt_attn_long.hip): flash-style attention core, 64 < T <= 256",
         "attn": "attn_fwd/bwd_co_kernel + attn_q1v_kernel (dmt_attn.hip): attention core, T <= 64",
@@ -214,7 +215,7 @@ def main():
             f["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % t["launches"]
     # `roofline` names ONE kernel (its rocprofv3 row must agree): the single-kernel family with the largest share of the step; the
     # dmt_gemm family spans three kernels and is listed with the others
-    single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts")] or fams
+    single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts", "proj")] or fams
     roofline = dict(single[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
     ga_x = bool((prof_x or {}).get("gather_fwd"))
     n_ga, t_ga, by_ga = agg_x("gather_fwd") if ga_x else agg("gather_fwd")

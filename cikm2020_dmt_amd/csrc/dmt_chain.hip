@@ -139,6 +139,7 @@ struct ChainArgs {
   bf16_t* mid_out; long long ld_mid;
   unsigned short* mask;
   int tiles;
+  int relax;      // side-output stores per mid tile a producer may leave open across the stage wait (see top())
 };
 
 // LDS fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) while an LDS-DMA is in
@@ -220,8 +221,13 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
     const long long blk = row0 >> 5;
 
     // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
+    // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
+    // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
+    // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
     auto top = [&](int u) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");   // (only the pieces of stage gs + 1 / younger stores may be open)
+      if (producer && g.relax == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE + 3) : "memory");
+      else if (producer && g.relax == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       (void)u;
@@ -529,6 +535,14 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
   a.mid_out = (bf16_t*)d->mid_out; a.ld_mid = d->ld_mid;
   a.mask = (unsigned short*)d->mask;
   a.tiles = (int)cdiv64(d->M, 128);
+  a.relax = 0;
+  {
+    const char* rl = getenv("DMT_CHAIN_RELAX");
+    if (!(rl && atoi(rl) == 0)) {
+      if (d->mode == DMT_CHAIN_FFN_LN && a.mid_out != nullptr && a.mask != nullptr) a.relax = 3;
+      if (d->mode == DMT_CHAIN_FFN_BWD && a.mid_out != nullptr) a.relax = 2;
+    }
+  }
   const int grid = a.tiles < 256 ? a.tiles : 256;
   if constexpr (G::KIN == 320) {
     const char* dbg = getenv("DMT_CHAIN_DEBUG");   // timing experiments (see DBG above); never set in production
@@ -546,6 +560,170 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
     hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_BWD>), dim3(grid), dim3(CH_NT), 0, st, a);
   DMT_CHECK_LAUNCH("dmt_chain2");
   return DMT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- projection
+// GEMM 1 of the chain alone:  out[m, :] = in[m, :] . W + b  for long-row activations (the packed Q | K | V projection).  The plain
+// tiled GEMM re-reads a 128-row activation tile once per 128 output columns and synchronises every 64 k; here the wavefront's 32 input
+// rows are loaded ONCE into registers (KIN / 16 MFMA B fragments) and the weights stream through the LDS ring as 32-column slices of a
+// prebuilt image -- one barrier per 32 x KIN slice, output tiles stored straight from the accumulators.  256 threads = 4 wavefronts =
+// 128 rows per workgroup, TWO workgroups per CU (72 KB of LDS each): the pair hides each other's barriers, and a 128-row unit keeps the
+// tail of the launch short (1600 units over 512 slots).
+template <int KIN_, int N_>
+struct PGeo {
+  static constexpr int KIN = KIN_, N = N_;
+  static constexpr int KC = KIN / 16, NJT = N / 32;
+  static constexpr int A1_STRIDE = KIN * 2 + 16, A1_BYTES = 32 * A1_STRIDE, BIAS_OFF = A1_BYTES;
+  static constexpr int RAW = BIAS_OFF + 128;
+  static constexpr int STAGE = (RAW + 4095) / 4096 * 4096;
+  static constexpr int PER_WAVE = STAGE / 4096;          // 4 wavefronts x 1 KB per DMA instruction
+  static constexpr long long IMAGE_BYTES = (long long)NJT * STAGE;
+  static_assert(KIN % 16 == 0 && N % 32 == 0, "projection geometry");
+  static_assert(2 * CH_NS * STAGE <= 160 * 1024, "two workgroups per CU");
+};
+
+constexpr int PJ_NT = 320;   // 4 compute wavefronts (32 rows each) + the loader
+
+struct ProjArgs {
+  long long M;
+  const bf16_t* in; long long ld_in;
+  const unsigned char* image;
+  bf16_t* out; long long ld_out;
+  int tiles;
+};
+
+// DBG (timing experiments only, results are garbage): 1 no DMA, 2 no output stores, 4 no LDS fragment reads, 8 no MFMA
+template <typename G, int DBG = 0>
+__global__ __launch_bounds__(PJ_NT, 2) void proj_kernel(const ProjArgs g) {
+  constexpr int KC = G::KC, NJT = G::NJT, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_NS * STAGE];   // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ml = lane & 31, hi = lane >> 5;
+  const unsigned lds0 = (unsigned)(unsigned long long)((lds_vp)smem);
+  const unsigned a1_lane = lds0 + ml * G::A1_STRIDE + 16 * hi;
+  const unsigned bias_lane = lds0 + G::BIAS_OFF + 16 * hi;
+  const __amdgpu_buffer_rsrc_t rimg =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.image), 0, (int)G::IMAGE_BYTES, 0x00020000);
+  // The weight stream belongs to ONE extra wavefront (wave 4, the loader): vmcnt counts loads AND stores, and a store leaves it only
+  // when the L2 has taken the data -- a compute wavefront that waited for "my DMA pieces have landed" also sat out its own output
+  // stores of the previous slice (measured: 78 of 220 us).  The loader has only DMA in flight, so "at most one stage open" is exact;
+  // the compute wavefronts never wait on vmcnt inside the slice loop.
+  auto issue_stage = [&](int buf, int u) {
+    if constexpr ((DBG & 1) != 0) return;
+#pragma unroll
+    for (int p = 0; p < STAGE / 1024; ++p) {
+      unsigned char* sb = smem + buf * STAGE + p * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + p * 1024, 0, 0);
+    }
+  };
+  const bool loader = wave == 4;
+  const int G_ = (int)gridDim.x;
+  if ((int)blockIdx.x >= g.tiles) return;
+  if (loader) {
+    issue_stage(0, 0);
+    issue_stage(1, 1 % NJT);
+    int gs = 0;
+    for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
+#pragma unroll 1
+      for (int u = 0; u < NJT; ++u, ++gs) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(STAGE / 1024) : "memory");   // stage gs has landed (stage gs + 1 may be open)
+        __builtin_amdgcn_s_barrier();                                          // everybody has left stage gs - 1 = ring slot gs + 2
+        issue_stage((gs + 2) % CH_NS, (u + 2) % NJT);
+      }
+    }
+    return;
+  }
+  int gs = 0;
+  for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
+    const long long m = (long long)tile * 128 + wave * 32 + ml;
+    const bool mvalid = m < g.M;
+    const long long mc = mvalid ? m : (g.M - 1);
+    bf16x8_t X[KC];
+    {
+      const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
+        uint4 v = make_uint4(vl[0], vl[1], vl[2], vl[3]);
+        swap_lo(v.x, v.z);
+        swap_lo(v.y, v.w);
+        X[c] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    }
+#pragma unroll 1
+    for (int u = 0; u < NJT; ++u, ++gs) {
+      const int buf = gs % CH_NS;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                      // the loader has seen stage gs land; everybody has left stage gs - 1
+      const unsigned so = (unsigned)buf * STAGE;
+      const unsigned a1a = a1_lane + so;
+      constexpr int PB = (KC % 5 == 0) ? 5 : 4, NBAT = KC / PB;
+      static_assert(KC % PB == 0, "KIN / 16 must be a multiple of 4 or 5");
+      bf16x8_t R0[5], R1[5];
+      f32x4_t b4[4];
+      f32x16_t Ha;
+      auto rd = [&](bf16x8_t (&R)[5], auto bic) {
+        constexpr int b = decltype(bic)::value;
+        sfor<5>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int c = b * PB + (i < PB ? i : 0);
+          if constexpr ((DBG & 4) != 0) ch_fake(R[i]); else ch_read128<c * 32>(R[i], a1a);
+        });
+      };
+      auto mm = [&](bf16x8_t (&R)[5], auto bic) {
+        constexpr int b = decltype(bic)::value;
+        sfor<PB>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int c = b * PB + i;
+          if constexpr ((DBG & 8) != 0) { Ha[i] += __builtin_bit_cast(f32x4_t, R[i])[0] + __builtin_bit_cast(f32x4_t, X[c])[1]; }
+          else Ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[c], Ha, 0, 0, 0);
+        });
+      };
+      sfor<4>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        ch_read128f<q * 32>(b4[q], bias_lane + so);
+      });
+      rd(R0, std::integral_constant<int, 0>{});
+      sfor<NBAT>([&](auto bic) {
+        constexpr int b = decltype(bic)::value;
+        if constexpr (b + 1 < NBAT) {
+          if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
+          else rd(R0, std::integral_constant<int, b + 1>{});
+        }
+        if constexpr (b == 0) {
+          ch_wait4f<(NBAT > 1 ? 10 : 5)>(b4[0], b4[1], b4[2], b4[3]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Ha[r] = b4[r >> 2][r & 3];   // the bias is the accumulator's initial value
+        }
+        if constexpr (b + 1 < NBAT) {
+          if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+          else { ch_wait<5>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+        } else {
+          if constexpr ((b & 1) == 0) { ch_wait<0>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
+          else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
+        }
+      });
+      // lane (m, hi) holds column 32 u + 8 q + 4 hi + i in register 4 q + i: pair q = 2p (lower lane keeps) with q = 2p + 1 (upper lane)
+      unsigned ho[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) ho[p] = dmt_pack_bf16(Ha[2 * p], Ha[2 * p + 1]);
+      swap_lo(ho[0], ho[2]); swap_lo(ho[1], ho[3]);
+      swap_lo(ho[4], ho[6]); swap_lo(ho[5], ho[7]);
+      if (mvalid && ((DBG & 2) == 0 || ho[0] == 0x12345678u)) {
+        bf16_t* dst = g.out + m * g.ld_out + u * 32 + 8 * hi;
+        *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{ho[0], ho[1], ho[2], ho[3]};
+        *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{ho[4], ho[5], ho[6], ho[7]};
+      }
+    }
+  }
+}
+
+template <typename F>
+int proj_dispatch(int kin, int n, F&& f) {
+  if (kin == 320 && n == 960) return f(PGeo<320, 960>{});
+  dmt_set_error("dmt_proj: unsupported geometry kin=%d n=%d (built: 320/960)", kin, n);
+  return DMT_ERR_UNSUPPORTED;
 }
 
 template <typename F>
@@ -608,3 +786,66 @@ extern "C" int dmt_chain2(const dmt_chain_desc* d, void* stream) {
   DMT_CHECK_ARG(d->mid_out == nullptr || (d->ld_mid % 8 == 0 && ((uintptr_t)d->mid_out & 15) == 0), "dmt_chain2: mid rows must be 16-byte aligned");
   return chain_dispatch(d->kin, d->nmid, d->nout, [&](auto geo) { return launch_chain<decltype(geo)>(d, (hipStream_t)stream); });
 }
+
+extern "C" int dmt_proj_supported(int32_t kin, int32_t n) { return kin == 320 && n == 960; }
+
+extern "C" int dmt_proj_image_bytes(int32_t kin, int32_t n, int64_t* bytes) {
+  DMT_CHECK_ARG(bytes != nullptr, "dmt_proj_image_bytes: null output");
+  return proj_dispatch(kin, n, [&](auto geo) {
+    *bytes = decltype(geo)::IMAGE_BYTES;
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_proj_image_build(int32_t kin, int32_t n, const float* w, int64_t w_rs, int64_t w_cs, const float* bias, void* image,
+                                    void* stream) {
+  DMT_CHECK_ARG(w && image, "dmt_proj_image_build: null pointer");
+  return proj_dispatch(kin, n, [&](auto geo) {
+    typedef decltype(geo) G;
+    ImgArgs g;
+    g.a1 = w; g.a1_rs = w_cs; g.a1_cs = w_rs;      // A1[j, k] = W[k, j]
+    g.a2 = nullptr; g.a2_rs = 0; g.a2_cs = 0;
+    g.bias1 = bias;
+    g.img = (unsigned char*)image;
+    g.kin = kin; g.nmid = n; g.nout = 0;
+    g.a1_stride = G::A1_STRIDE; g.a1_bytes = G::A1_BYTES; g.a2_bytes = 0; g.bias_off = G::BIAS_OFF; g.stage = G::STAGE;
+    g.slots = G::IMAGE_BYTES / 16;
+    long long nb = cdiv64(g.slots, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(chain_image_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g);
+    DMT_CHECK_LAUNCH("dmt_proj_image_build");
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64_t ld_in, const void* image, void* out, int64_t ld_out,
+                        void* stream) {
+  DMT_CHECK_ARG(M > 0 && in && image && out, "dmt_proj: bad argument");
+  DMT_CHECK_ARG(ld_in % 8 == 0 && ((uintptr_t)in & 15) == 0, "dmt_proj: input rows must be 16-byte aligned");
+  DMT_CHECK_ARG(ld_out % 8 == 0 && ((uintptr_t)out & 15) == 0, "dmt_proj: output rows must be 16-byte aligned");
+  DMT_CHECK_ARG(M < (1ll << 31) - 256, "dmt_proj: too many rows");
+  return proj_dispatch(kin, n, [&](auto geo) {
+    typedef decltype(geo) G;
+    ProjArgs a;
+    a.M = M;
+    a.in = (const bf16_t*)in; a.ld_in = ld_in;
+    a.image = (const unsigned char*)image;
+    a.out = (bf16_t*)out; a.ld_out = ld_out;
+    a.tiles = (int)cdiv64(M, 128);
+    const int grid = a.tiles < 512 ? a.tiles : 512;
+    const char* dbg = getenv("DMT_PROJ_DEBUG");   // timing experiments (see DBG above); never set in production
+    switch (dbg ? atoi(dbg) : 0) {
+      case 1: hipLaunchKernelGGL((proj_kernel<G, 1>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 2: hipLaunchKernelGGL((proj_kernel<G, 2>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 4: hipLaunchKernelGGL((proj_kernel<G, 4>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 5: hipLaunchKernelGGL((proj_kernel<G, 5>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 7: hipLaunchKernelGGL((proj_kernel<G, 7>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 8: hipLaunchKernelGGL((proj_kernel<G, 8>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 15: hipLaunchKernelGGL((proj_kernel<G, 15>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      default: hipLaunchKernelGGL((proj_kernel<G>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a);
+    }
+    DMT_CHECK_LAUNCH("dmt_proj");
+    return DMT_OK;
+  });
+}
+

@@ -137,10 +137,11 @@ def _pick_split(tiles: int, red: int) -> int:
 
 class Weight:
     """A 2-D dense weight as the kernels see it: fp32 master view + (bf16 mode) plain and transposed shadows."""
-    __slots__ = ("f32", "lp", "lp_t")
+    __slots__ = ("f32", "lp", "lp_t", "proj")
 
     def __init__(self, f32, lp=None, lp_t=None):
         self.f32, self.lp, self.lp_t = f32, lp, lp_t
+        self.proj = None          # streamed-weight image of dmt_proj (VariableStore.proj), when the geometry has a kernel
 
 
 def linear_forward(x, w: Weight, bias, act_ncols=0, resid=None, out=None, out_dtype=None):
@@ -497,6 +498,43 @@ class FFNFn(torch.autograd.Function):
         dx = linear_backward_input(dh, ctx.w1, resid=ds2)        # dh W1^T + ds (residual branch)
         dW1, db1 = linear_backward_weight(x2, dh, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
         return dx.reshape(ctx.xshape), dW1, db1, dW2, db2, None, None
+
+
+# ------------------------------------------------------------------------------------------------ streamed-weight projection
+def proj_image_bytes(kin, n):
+    """Size of a dmt_proj weight image for out = in[., kin] W[kin, n] + b, or None when no kernel is built for the geometry."""
+    if not L.load().dmt_proj_supported(kin, n):
+        return None
+    nb = C.c_int64(0)
+    L.call("dmt_proj_image_bytes", kin, n, C.byref(nb))
+    return int(nb.value)
+
+
+def proj_image_build(w_f32, bias_f32, image):
+    """w_f32 [kin, n] fp32 (any strides), bias [n] or None -> image (bf16, LDS byte order)."""
+    L.call("dmt_proj_image_build", int(w_f32.shape[0]), int(w_f32.shape[1]), p(w_f32), w_f32.stride(0), w_f32.stride(1), p(bias_f32), p(image),
+           stream_ptr())
+
+
+def proj_ok(x2, w):
+    img = getattr(w, "proj", None)
+    return (USE_PROJ and img is not None and x2.dtype == BF16 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and x2.shape[0] >= PROJ_MIN_ROWS)
+
+
+def proj_forward(x2, w, n):
+    """x2 [M, kin] bf16 -> [M, n] bf16 = x2 W + b by dmt_proj (the bias lives in the image: w.proj is rebuilt by the store with it)."""
+    M, kin = x2.shape
+    out = torch.empty((M, n), dtype=BF16, device=x2.device)
+    if PROFILE is not None:
+        PROFILE.setdefault("proj_bytes", []).append(float((M * kin + M * n + kin * n) * 2))
+    with _Timed("proj", 2.0 * M * kin * n):
+        L.call("dmt_proj", kin, n, M, p(x2), x2.stride(0), p(w.proj), p(out), n, stream_ptr())
+    return out
+
+
+USE_PROJ = os.environ.get("DMT_PROJ", "1") == "1"
+PROJ_MIN_ROWS = 1
 
 
 # ------------------------------------------------------------------------------------------------ fused ff + ln
@@ -942,7 +980,10 @@ class SelfAttnBlockFn(torch.autograd.Function):
         _chk3(x, "x")
         B, T, d = x.shape
         x2 = x.reshape(-1, d)
-        qkv = linear_forward(x2, w, b_leaf).reshape(B, T, 3 * d)
+        if b_leaf is not None and proj_ok(x2, w):
+            qkv = proj_forward(x2, w, 3 * d).reshape(B, T, 3 * d)        # streamed-weight projection (dmt_proj)
+        else:
+            qkv = linear_forward(x2, w, b_leaf).reshape(B, T, 3 * d)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         out = torch.empty((B, T, d), dtype=x.dtype, device=x.device)
         ctx.P = attn_core_fwd(q, k, v, lens, lens, x, out, H, drop_seed, drop_keep)

@@ -235,6 +235,17 @@ class VariableStore:
                         self.chain[scope] = dict(geo=(d, dff, d), fwd=torch.empty(nbytes, dtype=torch.uint8, device=dev),
                                                  bwd=torch.empty(nbytes, dtype=torch.uint8, device=dev))
 
+        # streamed-weight images of the self-attention QKV projections (dmt_proj): Weight.proj, rebuilt with the shadows
+        self.proj: Dict[str, torch.Tensor] = {}
+        if bf:
+            for name in self.leaves:
+                if name.endswith("self-attention/qkv_kernel") and name in self.weight:
+                    kin, n = self.leaf[name].shape
+                    nbytes = ops.proj_image_bytes(int(kin), int(n))
+                    if nbytes is not None:
+                        self.proj[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                        self.weight[name].proj = self.proj[name]
+
         # decoder cross attention over the raw memory rows (dmt_q1mem_*): per vanilla_attention scope the V projection as a
         # k-contiguous bf16 block [d_model, d_model + 8]: row n = output column n, cols 0..d-1 = Wv[:, n], col d = bv[n], rest 0
         self.q1mem: Dict[str, torch.Tensor] = {}
@@ -344,6 +355,8 @@ class VariableStore:
         if self.mhsa_in_use:              # (the one-launch self-attention block is optional: DMTEngine.use_mhsa)
             for scope, img in self.mhsa.items():
                 ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
+        for name, img in self.proj.items():
+            ops.proj_image_build(self.leaf[name].detach(), self.leaf[name[: -len("qkv_kernel")] + "qkv_bias"].detach(), img)
         for scope, ch in self.chain.items():
             w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
             # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]

@@ -445,6 +445,19 @@ int dmt_chain_image_build(int32_t kin, int32_t nmid, int32_t nout, const float* 
 int dmt_chain2(const dmt_chain_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense projection of long-row activations with the weights streamed as an LDS image (bf16 in / out, fp32 accumulation):
+ *     out[m, :] = in[m, :] W + b        in [M, kin], W [kin, n], b [n] or NULL (then 0)
+ * The input rows of a wavefront stay in registers, W passes through LDS once per 128 rows (GEMM 1 of dmt_chain2 alone).
+ * Replaces: tf.layers.dense producing the packed Q | K | V of the self-attention block,
+ *           model/net/TransformerModel_util.py:188-190 (kin = d_model = 320, n = 3 d_model = 960).
+ * dmt_proj_image_build takes W[k, j] = w[k * w_rs + j * w_cs] (fp32) and must be re-run after every change of W or b.
+ * ------------------------------------------------------------------------------------------------ */
+int dmt_proj_supported(int32_t kin, int32_t n);
+int dmt_proj_image_bytes(int32_t kin, int32_t n, int64_t* bytes);
+int dmt_proj_image_build(int32_t kin, int32_t n, const float* w, int64_t w_rs, int64_t w_cs, const float* bias, void* image, void* stream);
+int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64_t ld_in, const void* image, void* out, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight gradient of a dense layer whose input OR output is 320 (= d_model of the E64 configuration) wide, as one wide-block
  * reduction over the batch x sequence rows (bf16 operands, fp32 ACCUMULATED into C by atomics -- C is the gradient arena):
  *     transposed == 0:  C[i * ldc + j] += sum_m A[m, i] B[m, j]      (dW = X^T dY with X 320 wide:  A = X, B = dY)
