@@ -8,6 +8,7 @@ FAMILIES = {
     "chain2": ["chain2_kernel"],
     "gemm_bf16": ["gemm_glds_kernel", "gemm_dw_glds_kernel", "gemm_kernel<"],
     "wgrad320": ["wgrad320_kernel"],
+    "proj": ["proj_kernel"],
     "attn": ["attn_fwd_co_kernel", "attn_bwd_co_kernel", "attn_q1v_kernel"],
     "attn_long": ["attn_long_fwd", "attn_long_bwd", "attn_q1_long"],
     "q1mem": ["q1m_fwd_kernel", "q1m_bwd_kernel"],
