@@ -14,6 +14,7 @@ with RCCL.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -34,8 +35,8 @@ def index_group():
     stream -- the id exchange of batch i + 1 is not ordered behind the gradient collectives of batch i, so it can run (and its two
     host syncs can return) while step i computes.  Created collectively on first use (every rank reaches its first plan_exchange at
     the same point of the program); other backends share the default group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
-        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or os.environ.get("DMT_INDEX_GROUP", "1") != "1":
+        return None          # (DMT_INDEX_GROUP=0: everything on the default communicator -- the id exchange then queues behind gradient collectives)
     world_pg = dist.distributed_c10d._get_default_group()
     if _index_group["world"] is not world_pg:          # (a new default group after destroy_process_group + init_process_group)
         _index_group["world"] = world_pg
