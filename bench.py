@@ -30,8 +30,8 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--dims", default="e64", choices=["e64", "ref"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])

@@ -1,7 +1,7 @@
 """Per-kernel summary of a rocprofv3 --kernel-trace csv of `python bench.py ...`, split into the two phases of a bench run:
 the TIMED steps (three sequence lanes in flight: kernels of different lanes overlap) and the EXCLUSIVE steps bench.py runs right
 after them with the lanes serialised (the durations its `roofline` quotes).  Steps are delimited by embgrad_keys_kernel (one per step).
-usage: python scripts/kernel_summary.py <kernel_trace.csv> [exclusive steps at the end, default 4] [warmup+steps, default 25]"""
+usage: python scripts/kernel_summary.py <kernel_trace.csv> [exclusive steps at the end, default 4] [warmup+steps, default: all but the last 5]"""
 import csv
 import sys
 from collections import defaultdict
@@ -9,7 +9,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n_x = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-n_t = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+n_t = int(sys.argv[3]) if len(sys.argv) > 3 else None
 # a kernel belongs to the step whose first forward kernel (gather_group_kernel, first of a burst) precedes it
 starts = []
 last = -10**18
@@ -20,6 +20,8 @@ for r in rows:
             starts.append(t)
         last = t
 steps = len(starts)
+if n_t is None:
+    n_t = steps - n_x - 1
 print("steps in the trace: %d (last %d exclusive; first %d = warm-up + timed)" % (steps, n_x + 1, n_t))
 bounds_t = (starts[2], starts[n_t])                      # skip the first two warm-up steps
 bounds_x = (starts[steps - n_x], int(rows[-1]["End_Timestamp"]) + 1) if steps > n_t else None
