@@ -174,13 +174,16 @@ _SIGS = {
     "dmt_proj_image_bytes": [c_i32, c_i32, C.POINTER(c_i64)],
     "dmt_proj_image_build": [c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "dmt_proj": [c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp],
+    "dmt_chain_image_job": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "dmt_proj_image_job": [c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "dmt_image_build_batched": [c_i32, c_vp, c_vp],
     "dmt_wgrad320": [C.POINTER(WgradDesc), c_vp],
     "dmt_mhsa_image_bytes": [C.POINTER(c_i64)],
     "dmt_mhsa_image_build": [c_vp, c_i64, c_vp, c_vp],
     "dmt_mhsa_block_fwd": [C.POINTER(MhsaDesc), c_vp],
 }
 
-EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported", "dmt_proj_supported",
+EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported", "dmt_proj_supported", "dmt_image_job_bytes",
                                                  "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
 
 _lib = None
@@ -210,6 +213,8 @@ def load():
     lib.dmt_chain_supported.argtypes = [c_i32, c_i32, c_i32]
     lib.dmt_proj_supported.restype = c_i32
     lib.dmt_proj_supported.argtypes = [c_i32, c_i32]
+    lib.dmt_image_job_bytes.restype = c_i32
+    lib.dmt_image_job_bytes.argtypes = []
     lib.dmt_q1mem_supported.restype = c_i32
     lib.dmt_q1mem_supported.argtypes = [c_i32] * 4
     lib.dmt_heads_supported.restype = c_i32

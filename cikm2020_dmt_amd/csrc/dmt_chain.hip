@@ -81,7 +81,7 @@ struct ImgArgs {
   long long slots;
 };
 
-__global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) {
+__device__ __forceinline__ void chain_image_body(const ImgArgs& g) {
   for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < g.slots; s += (long long)gridDim.x * 256) {
     const long long byte = s * 16;
     const int u = (int)(byte / g.stage), off = (int)(byte % g.stage);   // stage u: A1 / bias1 of mid tile u, A2 of mid tile u - 1
@@ -126,6 +126,14 @@ __global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) {
     }
     *reinterpret_cast<u32x4_t*>(g.img + byte) = o;
   }
+}
+
+__global__ __launch_bounds__(256) void chain_image_kernel(const ImgArgs g) { chain_image_body(g); }
+
+// every weight image of a model in ONE launch: blockIdx.y = job (a table of ImgArgs in device memory, built once)
+__global__ __launch_bounds__(256) void chain_image_batched_kernel(const ImgArgs* __restrict__ jobs) {
+  const ImgArgs g = jobs[blockIdx.y];
+  chain_image_body(g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- chain
@@ -847,5 +855,53 @@ extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64
     DMT_CHECK_LAUNCH("dmt_proj");
     return DMT_OK;
   });
+}
+
+// ---- batched image rebuild: the caller keeps a device table of jobs (dmt_image_job_bytes() each), filled on the host by
+//      dmt_chain_image_job / dmt_proj_image_job with the same arguments as the one-image builders
+extern "C" int32_t dmt_image_job_bytes(void) { return (int32_t)sizeof(ImgArgs); }
+
+extern "C" int dmt_chain_image_job(int32_t kin, int32_t nmid, int32_t nout, const float* a1, int64_t a1_rs, int64_t a1_cs, const float* a2,
+                                   int64_t a2_rs, int64_t a2_cs, const float* bias1, void* image, void* job_out) {
+  DMT_CHECK_ARG(a1 && a2 && image && job_out, "dmt_chain_image_job: null pointer");
+  return chain_dispatch(kin, nmid, nout, [&](auto geo) {
+    typedef decltype(geo) G;
+    ImgArgs g;
+    g.a1 = a1; g.a1_rs = a1_rs; g.a1_cs = a1_cs;
+    g.a2 = a2; g.a2_rs = a2_rs; g.a2_cs = a2_cs;
+    g.bias1 = bias1;
+    g.img = (unsigned char*)image;
+    g.kin = kin; g.nmid = nmid; g.nout = nout;
+    g.a1_stride = G::A1_STRIDE; g.a1_bytes = G::A1_BYTES; g.a2_bytes = G::A2_BYTES; g.bias_off = G::BIAS_OFF; g.stage = G::STAGE;
+    g.slots = G::IMAGE_BYTES / 16;
+    *reinterpret_cast<ImgArgs*>(job_out) = g;
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_proj_image_job(int32_t kin, int32_t n, const float* w, int64_t w_rs, int64_t w_cs, const float* bias, void* image,
+                                  void* job_out) {
+  DMT_CHECK_ARG(w && image && job_out, "dmt_proj_image_job: null pointer");
+  return proj_dispatch(kin, n, [&](auto geo) {
+    typedef decltype(geo) G;
+    ImgArgs g;
+    g.a1 = w; g.a1_rs = w_cs; g.a1_cs = w_rs;
+    g.a2 = nullptr; g.a2_rs = 0; g.a2_cs = 0;
+    g.bias1 = bias;
+    g.img = (unsigned char*)image;
+    g.kin = kin; g.nmid = n; g.nout = 0;
+    g.a1_stride = G::A1_STRIDE; g.a1_bytes = G::A1_BYTES; g.a2_bytes = 0; g.bias_off = G::BIAS_OFF; g.stage = G::STAGE;
+    g.slots = G::IMAGE_BYTES / 16;
+    *reinterpret_cast<ImgArgs*>(job_out) = g;
+    return DMT_OK;
+  });
+}
+
+extern "C" int dmt_image_build_batched(int32_t n_jobs, const void* jobs_dev, void* stream) {
+  DMT_CHECK_ARG(n_jobs > 0 && jobs_dev, "dmt_image_build_batched: bad argument");
+  DMT_CHECK_ARG(n_jobs <= 65535, "dmt_image_build_batched: too many jobs");
+  hipLaunchKernelGGL(chain_image_batched_kernel, dim3(256, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, (const ImgArgs*)jobs_dev);
+  DMT_CHECK_LAUNCH("dmt_image_build_batched");
+  return DMT_OK;
 }
 

@@ -318,6 +318,15 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
                 wgrad320(dz, x, gw, True, gb if want_bias else None, 2)
         return None, None
     if gw is not None and (gb is not None or not want_bias):
+        if _deferred[0] is not None and M >= WGRAD320_MIN_ROWS:
+            def _later(x=x, dz=dz, gw=gw, gb=gb):
+                cur = torch.cuda.current_stream(x.device)
+                x.record_stream(cur)
+                dz.record_stream(cur)
+                gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
+                     split_k=split, accumulate=True)
+            _deferred[0].append(_later)
+            return None, None
         ws = _wgrad_defer(x, dz)
         with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
             gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
@@ -549,6 +558,39 @@ def chain_image_bytes(kin, nmid, nout):
 
 def chain_image_build(geo, a1, a1_rs, a1_cs, a2, a2_rs, a2_cs, bias1, image):
     L.call("dmt_chain_image_build", geo[0], geo[1], geo[2], p(a1), a1_rs, a1_cs, p(a2), a2_rs, a2_cs, p(bias1), p(image), stream_ptr())
+
+
+class ImageJobs:
+    """Every weight image of a store rebuilt by ONE launch: add_chain / add_proj take what chain_image_build / proj_image_build
+    take; finish() uploads the job table; run() is the launch.  The source tensors must stay where they are (parameter arena)."""
+
+    def __init__(self, device):
+        self.device, self.nb = device, int(L.load().dmt_image_job_bytes())
+        self.host, self.dev, self.n = [], None, 0
+
+    def _slot(self):
+        buf = (C.c_uint8 * self.nb)()
+        self.host.append(buf)
+        return buf
+
+    def add_chain(self, geo, a1, a1_rs, a1_cs, a2, a2_rs, a2_cs, bias1, image):
+        L.call("dmt_chain_image_job", geo[0], geo[1], geo[2], p(a1), a1_rs, a1_cs, p(a2), a2_rs, a2_cs, p(bias1), p(image), C.byref(self._slot()))
+
+    def add_proj(self, w_f32, bias_f32, image):
+        L.call("dmt_proj_image_job", int(w_f32.shape[0]), int(w_f32.shape[1]), p(w_f32), w_f32.stride(0), w_f32.stride(1), p(bias_f32), p(image),
+               C.byref(self._slot()))
+
+    def finish(self):
+        self.n = len(self.host)
+        if self.n:
+            import numpy as np
+            flat = np.concatenate([np.frombuffer(b, dtype=np.uint8) for b in self.host])
+            self.dev = torch.from_numpy(flat.copy()).to(self.device)
+        return self
+
+    def run(self):
+        if self.n:
+            L.call("dmt_image_build_batched", self.n, p(self.dev), stream_ptr())
 
 
 def _chain_call(mode, geo, x2, image, M, *, bias2=None, gamma=None, beta=None, eps=0.0, s_out=None, y_out=None, stats=None, mid_out=None, mask=None):

@@ -406,7 +406,7 @@ class Trainer:
                     self.engine.finish_sparse_backward()
                     self.opt.begin()
                     self.opt.apply_sparse(self.engine.sparse, 1.0)
-                ops.run_deferred_wgrads()
+                self.n_deferred = ops.run_deferred_wgrads()
                 ops.join_wgrad(self.device)
                 main.wait_stream(lane)
                 self.opt.apply_dense(1.0)

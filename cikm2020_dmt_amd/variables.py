@@ -355,13 +355,17 @@ class VariableStore:
         if self.mhsa_in_use:              # (the one-launch self-attention block is optional: DMTEngine.use_mhsa)
             for scope, img in self.mhsa.items():
                 ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
-        for name, img in self.proj.items():
-            ops.proj_image_build(self.leaf[name].detach(), self.leaf[name[: -len("qkv_kernel")] + "qkv_bias"].detach(), img)
-        for scope, ch in self.chain.items():
-            w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
-            # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]
-            ops.chain_image_build(ch["geo"], w1, 1, w1.stride(0), w2, 1, w2.stride(0), b1, ch["fwd"])
-            ops.chain_image_build(ch["geo"], w2, w2.stride(0), 1, w1, w1.stride(0), 1, None, ch["bwd"])
+        if getattr(self, "_image_jobs", None) is None:
+            jobs = ops.ImageJobs(self.device)
+            for name, img in self.proj.items():
+                jobs.add_proj(self.leaf[name].detach(), self.leaf[name[: -len("qkv_kernel")] + "qkv_bias"].detach(), img)
+            for scope, ch in self.chain.items():
+                w1, b1, w2 = self.leaf[scope + "dense/kernel"].detach(), self.leaf[scope + "dense/bias"].detach(), self.leaf[scope + "dense_1/kernel"].detach()
+                # forward: A1[j, k] = W1[k, j], A2[n, j] = W2[j, n];  backward: A1[j, n] = W2[j, n], A2[k, j] = W1[k, j]
+                jobs.add_chain(ch["geo"], w1, 1, w1.stride(0), w2, 1, w2.stride(0), b1, ch["fwd"])
+                jobs.add_chain(ch["geo"], w2, w2.stride(0), 1, w1, w1.stride(0), 1, None, ch["bwd"])
+            self._image_jobs = jobs.finish()
+        self._image_jobs.run()          # every streamed-weight image (dmt_proj, dmt_chain2) in one launch
 
     def zero_grad(self):
         self.grads.zero_()

@@ -456,6 +456,14 @@ int dmt_proj_supported(int32_t kin, int32_t n);
 int dmt_proj_image_bytes(int32_t kin, int32_t n, int64_t* bytes);
 int dmt_proj_image_build(int32_t kin, int32_t n, const float* w, int64_t w_rs, int64_t w_cs, const float* bias, void* image, void* stream);
 int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64_t ld_in, const void* image, void* out, int64_t ld_out, void* stream);
+/* All weight images of a model rebuilt in ONE launch (after every optimizer step): a table of jobs in DEVICE memory, each
+ * dmt_image_job_bytes() long, filled on the host by dmt_chain_image_job / dmt_proj_image_job (same arguments as the builders above,
+ * job_out = host pointer to one slot) and uploaded once; the pointers in a job must stay valid. */
+int32_t dmt_image_job_bytes(void);
+int dmt_chain_image_job(int32_t kin, int32_t nmid, int32_t nout, const float* a1, int64_t a1_rs, int64_t a1_cs, const float* a2,
+                        int64_t a2_rs, int64_t a2_cs, const float* bias1, void* image, void* job_out);
+int dmt_proj_image_job(int32_t kin, int32_t n, const float* w, int64_t w_rs, int64_t w_cs, const float* bias, void* image, void* job_out);
+int dmt_image_build_batched(int32_t n_jobs, const void* jobs_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight gradient of a dense layer whose input OR output is 320 (= d_model of the E64 configuration) wide, as one wide-block
