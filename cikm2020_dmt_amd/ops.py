@@ -216,12 +216,23 @@ def begin_deferred_wgrads():
     _deferred[0] = []
 
 
-def run_deferred_wgrads():
-    """Launch what begin_deferred_wgrads() collected, on the current stream, in backward order; -> how many."""
-    todo, _deferred[0] = _deferred[0], None
-    for fn in todo or ():
+def run_deferred_wgrads(upto=None):
+    """Launch what begin_deferred_wgrads() collected, on the current stream, in backward order; -> how many.  upto: only the first
+    `upto` of them now (the rest stays collected for the next call)."""
+    todo = _deferred[0]
+    if todo is None:
+        return 0
+    if upto is not None and upto < len(todo):
+        now, _deferred[0] = todo[:upto], todo[upto:]
+    else:
+        now, _deferred[0] = todo, None
+    for fn in now:
         fn()
-    return len(todo or ())
+    return len(now)
+
+
+def deferred_wgrads_pending():
+    return len(_deferred[0]) if _deferred[0] is not None else 0
 
 
 def _wgrad_defer(x, dz):

@@ -69,6 +69,11 @@ class Trainer:
         self.force_dp = bool(force_dp)
         if os.environ.get("DMT_DETERMINISTIC") == "1" and not ops.DETERMINISTIC:
             ops.set_deterministic(True)
+        # data-parallel step: long-row weight gradients collected in backward and launched beside the row exchange (train_step).  On
+        # by default with more than one rank; in a ONE-rank group (no wire time to hide) it only costs the overlap the lanes give
+        # those kernels inside backward (10.8 against 10.4 ms), so there it is off unless asked for
+        ov = os.environ.get("DMT_DP_OVERLAP_WGRADS", "auto")
+        self.overlap_wgrads = (parallel.world()[1] > 1) if ov == "auto" else (ov == "1")
         self.sparse_lane = os.environ.get("DMT_SPARSE_LANE", "0") == "1"     # one-GPU step: id-bound tail beside the deferred weight gradients (off: even at L=50, -3 % at L=200)
         self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
         if self.device.type == "cuda":
@@ -238,10 +243,11 @@ class Trainer:
             parallel._a2a(recv_r, send_r, plan["recv_splits"], plan["send_splits"])
         return (work, send_r, recv_r)
 
-    def exchange_rows_finish(self, handle, plan):
-        """DATA PLANE, second half: the owner sums what it received per row, in rank order, with the segments prepared by
+    def exchange_rows_reduce(self, handle, plan):
+        """DATA PLANE, second part: the owner sums what it received per row, in rank order, with the segments prepared by
         plan_exchange (dmt_rows_reduce).  Sharded layout: done -- the owner applies Adam to its rows.  Replicated layout: the reduced
-        shards are all-gathered (padded to the largest shard; padding slots carry an invalid key the optimizer kernels skip)."""
+        shards leave in an all-gather (padded to the largest shard; padding slots carry an invalid key the optimizer kernels skip),
+        asynchronous with RCCL: exchange_rows_collect waits for it."""
         work, _send_r, recv_r = handle
         if work is not None:
             work.wait()
@@ -257,19 +263,34 @@ class Trainer:
             L.call("dmt_rows_reduce_bf16" if recv_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(plan["keys_s"]), ops.p(plan["vals_s"]),
                    ops.p(plan["seg"]), Rn, st.total_rows, ops.p(recv_r), ops.p(out_rows), D, ws, wsb, ops.stream_ptr())
         if sharded:
-            return (plan["uniq2"], plan["n_uniq2"], out_rows, Rn)
+            return (None, (plan["uniq2"], plan["n_uniq2"], out_rows, Rn), None)
         cap_m = plan["cap_m"]
         r_loc = out_rows[:cap_m]
         if recv_r.dtype == torch.bfloat16:
             r_loc = r_loc.to(torch.bfloat16)          # (rows past this shard's m are never read: their keys are invalid)
+        r_loc = r_loc.contiguous()
         all_r = torch.empty((W * cap_m, D), dtype=r_loc.dtype, device=r_loc.device)
-        if parallel.dist.is_initialized():
-            parallel._all_gather_cat(all_r, r_loc.contiguous(), W, cap_m)
-        else:
+        work2 = None
+        if not parallel.dist.is_initialized():
             all_r.copy_(r_loc)
-        return (plan["all_k"], plan["n_dev"], all_r, W * cap_m)
+        elif parallel.dist.get_backend() == "nccl" and hasattr(parallel.dist, "all_gather_into_tensor"):
+            work2 = parallel.dist.all_gather_into_tensor(all_r, r_loc, async_op=True)
+        else:
+            parallel._all_gather_cat(all_r, r_loc, W, cap_m)
+        return (work2, (plan["all_k"], plan["n_dev"], all_r, W * cap_m), r_loc)
 
-    def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None):
+    @staticmethod
+    def exchange_rows_collect(handle2):
+        work2, sparse, _keep = handle2
+        if work2 is not None:
+            work2.wait()
+        return sparse
+
+    def exchange_rows_finish(self, handle, plan):
+        """exchange_rows_reduce + exchange_rows_collect in one go."""
+        return self.exchange_rows_collect(self.exchange_rows_reduce(handle, plan))
+
+    def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False):
         """join=False leaves the side-stream weight gradients (ops._wgrad_defer) open: the caller must ops.join_wgrad() before it
         reads the dense gradient arena.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
         self.sync_rows(batch)
@@ -284,6 +305,9 @@ class Trainer:
         if defer:
             ops.begin_deferred_wgrads()
             self.engine.defer_sparse = True
+        elif defer_wgrads:
+            # (data-parallel step: the caller launches them while the gradient rows are on the links -- train_step)
+            ops.begin_deferred_wgrads()
         self._early = None
         if _W > 1 or (self.force_dp and parallel.dist.is_initialized()):
             # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
@@ -392,7 +416,8 @@ class Trainer:
     def train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):
         rank, W = parallel.world()
         dp = W > 1 or (self.force_dp and parallel.dist.is_initialized())
-        loss = self.forward_backward(batch, join=dp, prefetch=prefetch)
+        plan_dp = dp and self.dp_exchange == "owner" and self.overlap_wgrads
+        loss = self.forward_backward(batch, join=dp, prefetch=prefetch, defer_wgrads=plan_dp)
         sparse = self.engine.sparse
         if not dp:
             lane = self._index_stream() if self.engine._pending_sparse is not None else None
@@ -425,11 +450,35 @@ class Trainer:
         if dp:
             early, self._early = getattr(self, "_early", None), None
             self.early_allreduce_used = early is not None
+            plan = (getattr(batch, "_prep", None) or {}).get("xplan")
+            if plan is not None and ops.deferred_wgrads_pending():
+                # Backward ran its dX chain only (the long-row weight gradients were collected): the embedding-gradient rows are ready
+                # EARLY and go on the links at once; the collected weight gradients -- MFMA work nothing else waits for -- run while
+                # the rows travel (first half beside the all_to_all, second half beside the all-gather of the reduced shards).
+                n_w = ops.deferred_wgrads_pending()
+                handle = self.exchange_rows_begin(sparse, plan)
+                ops.run_deferred_wgrads(upto=(n_w + 1) // 2)
+                handle2 = self.exchange_rows_reduce(handle, plan)
+                ops.run_deferred_wgrads()
+                self.n_deferred = n_w
+                works = [early[1] if early is not None else None,
+                         parallel.allreduce_dense_(self.store.grads[: early[0]] if early is not None else self.store.grads, async_op=True, force=self.force_dp)]
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                loss = parallel.mean_scalar(loss)
+                self.opt.begin()
+                self.opt.apply_dense(1.0 / W)
+                sparse = self.exchange_rows_collect(handle2)
+                self.opt.apply_sparse(sparse, 1.0 / W)
+                self.opt.end()
+                self.store.refresh_shadows()
+                return loss
+            ops.run_deferred_wgrads()          # (no exchange plan: nothing to overlap them with)
             if early is not None:
                 works = [early[1], parallel.allreduce_dense_(self.store.grads[: early[0]], async_op=True, force=self.force_dp)]
             else:
                 works = [parallel.allreduce_dense_(self.store.grads, async_op=True, force=self.force_dp)]
-            plan = (getattr(batch, "_prep", None) or {}).get("xplan")
             if plan is not None:
                 # no host sync between backward and the optimizer: sizes were fixed by plan_exchange before the forward pass
                 handle = self.exchange_rows_begin(sparse, plan)

@@ -215,6 +215,53 @@ def _nccl_world1_step(q, bf16):
     dist.destroy_process_group()
 
 
+def _nccl_world1_overlap(q):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd import ops
+    from cikm2020_dmt_amd import spec as S
+    from cikm2020_dmt_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ops.set_deterministic(True)
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 20000, "Brand": 3000, "Shopid": 3000, "Cid3": 1200})
+    states, deferred = [], []
+    for force, overlap, layout in ((False, False, "replicated"), (True, True, "replicated"), (True, False, "replicated"), (True, True, "sharded")):
+        tr = Trainer(sp, device="cuda:0", compute_dtype=torch.float32, seed=3, force_dp=force, dropout=True, table_layout=layout)
+        tr.overlap_wgrads = overlap
+        tr.n_deferred = 0
+        bs = []
+        for s_ in range(3):
+            inputs, mask, _ = make_batch(sp, 512, seed=400 + s_, lengths="ragged", weights="random")     # 512 x 50 rows >= 16384: deferred
+            bs.append(tr.make_batch(inputs, mask))
+        for s_ in range(3):
+            tr.train_step(bs[s_], prefetch=bs[s_ + 1] if (force and s_ < 2) else None)
+        deferred.append(tr.n_deferred)
+        tr.opt.flush_tables()
+        torch.cuda.synchronize()
+        states.append(tr.store.state_dict())
+    same = [all(np.array_equal(states[0][k], st[k]) for k in states[0]) for st in states[1:]]
+    q.put((same, deferred))
+    dist.destroy_process_group()
+
+
+def test_weight_gradients_beside_the_row_exchange_change_nothing(cuda):
+    """Data-parallel step with the long-row weight gradients collected during backward and launched while the gradient rows are on
+    the links (first half beside the all_to_all, second half beside the all-gather): in deterministic fp32 mode three steps through a
+    one-rank RCCL group end BIT-IDENTICAL to the plain one-GPU step -- with the overlap, without it, and with row-sharded tables."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_nccl_world1_overlap, args=(q,))
+    p_.start()
+    same, deferred = q.get(timeout=600)
+    p_.join(60)
+    assert p_.exitcode == 0
+    assert same == [True, True, True], same
+    assert deferred[1] >= 6 and deferred[3] >= 6 and deferred[2] == 0, deferred
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_full_train_step_through_one_rank_rccl_group(cuda, bf16):
     """The N-rank train step (early + late all-reduce, all_to_all to the owners, shard all-gather, bf16-row Adam with padding
