@@ -574,9 +574,9 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
 // GEMM 1 of the chain alone:  out[m, :] = in[m, :] . W + b  for long-row activations (the packed Q | K | V projection).  The plain
 // tiled GEMM re-reads a 128-row activation tile once per 128 output columns and synchronises every 64 k; here the wavefront's 32 input
 // rows are loaded ONCE into registers (KIN / 16 MFMA B fragments) and the weights stream through the LDS ring as 32-column slices of a
-// prebuilt image -- one barrier per 32 x KIN slice, output tiles stored straight from the accumulators.  256 threads = 4 wavefronts =
-// 128 rows per workgroup, TWO workgroups per CU (72 KB of LDS each): the pair hides each other's barriers, and a 128-row unit keeps the
-// tail of the launch short (1600 units over 512 slots).
+// prebuilt image -- one barrier per 32 x KIN slice, output tiles stored straight from the accumulators.  4 compute wavefronts =
+// 128 rows per workgroup + a loader wavefront (320 threads), one workgroup per CU (72 KB of LDS: kernels of the other lanes fit beside it); the rows
+// of the next 128-row unit are requested before the slice loop of the current one.
 template <int KIN_, int N_>
 struct PGeo {
   static constexpr int KIN = KIN_, N = N_;
@@ -587,7 +587,7 @@ struct PGeo {
   static constexpr int PER_WAVE = STAGE / 4096;          // 4 wavefronts x 1 KB per DMA instruction
   static constexpr long long IMAGE_BYTES = (long long)NJT * STAGE;
   static_assert(KIN % 16 == 0 && N % 32 == 0, "projection geometry");
-  static_assert(2 * CH_NS * STAGE <= 160 * 1024, "two workgroups per CU");
+  static_assert(CH_NS * STAGE <= 160 * 1024, "LDS ring");
 };
 
 constexpr int PJ_NT = 320;   // 4 compute wavefronts (32 rows each) + the loader
@@ -602,7 +602,7 @@ struct ProjArgs {
 
 // DBG (timing experiments only, results are garbage): 1 no DMA, 2 no output stores, 4 no LDS fragment reads, 8 no MFMA
 template <typename G, int DBG = 0>
-__global__ __launch_bounds__(PJ_NT, 2) void proj_kernel(const ProjArgs g) {
+__global__ __launch_bounds__(PJ_NT, 1) void proj_kernel(const ProjArgs g) {
   constexpr int KC = G::KC, NJT = G::NJT, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_NS * STAGE];   // the ONLY LDS object
   const int tid = threadIdx.x, lane = tid & 63;
@@ -634,36 +634,43 @@ __global__ __launch_bounds__(PJ_NT, 2) void proj_kernel(const ProjArgs g) {
     int gs = 0;
     for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
 #pragma unroll 1
-      for (int u = 0; u < NJT; ++u, ++gs) {
+      for (int u = 0; u < ((DBG & 32) != 0 ? 1 : NJT); ++u, ++gs) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(STAGE / 1024) : "memory");   // stage gs has landed (stage gs + 1 may be open)
-        __builtin_amdgcn_s_barrier();                                          // everybody has left stage gs - 1 = ring slot gs + 2
+        if constexpr ((DBG & 64) == 0) __builtin_amdgcn_s_barrier();           // everybody has left stage gs - 1 = ring slot gs + 2
         issue_stage((gs + 2) % CH_NS, (u + 2) % NJT);
       }
     }
     return;
   }
   int gs = 0;
+  // The rows of the NEXT tile are requested before this tile's slice loop and turned into fragments after it: their round trip (a
+  // lane reads its own row in 16-byte pieces: 32 rows x 32 bytes per instruction, 63 us per launch when it was waited for at the
+  // top of every tile) runs under the 30 slices.  160 registers of rows -> one workgroup per CU (two wavefronts per SIMD).
+  u32x4_t XR[KC];
+  auto load_rows = [&](int tile, u32x4_t (&R)[KC]) {
+    const long long mm = (long long)tile * 128 + wave * 32 + ml;
+    const bf16_t* xr = g.in + (mm < g.M ? mm : g.M - 1) * g.ld_in + 8 * hi;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) R[c] = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
+  };
+  load_rows((int)blockIdx.x, XR);
   for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
     const long long m = (long long)tile * 128 + wave * 32 + ml;
     const bool mvalid = m < g.M;
-    const long long mc = mvalid ? m : (g.M - 1);
     bf16x8_t X[KC];
-    {
-      const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
-        uint4 v = make_uint4(vl[0], vl[1], vl[2], vl[3]);
-        swap_lo(v.x, v.z);
-        swap_lo(v.y, v.w);
-        X[c] = __builtin_bit_cast(bf16x8_t, v);
-      }
+    for (int c = 0; c < KC; ++c) {
+      uint4 v = make_uint4(XR[c][0], XR[c][1], XR[c][2], XR[c][3]);
+      swap_lo(v.x, v.z);
+      swap_lo(v.y, v.w);
+      X[c] = __builtin_bit_cast(bf16x8_t, v);
     }
+    if (tile + G_ < g.tiles) load_rows(tile + G_, XR);
 #pragma unroll 1
-    for (int u = 0; u < NJT; ++u, ++gs) {
+    for (int u = 0; u < ((DBG & 32) != 0 ? 1 : NJT); ++u, ++gs) {
       const int buf = gs % CH_NS;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                      // the loader has seen stage gs land; everybody has left stage gs - 1
+      if constexpr ((DBG & 64) == 0) __builtin_amdgcn_s_barrier();       // the loader has seen stage gs land; everybody has left stage gs - 1
       const unsigned so = (unsigned)buf * STAGE;
       const unsigned a1a = a1_lane + so;
       constexpr int PB = (KC % 5 == 0) ? 5 : 4, NBAT = KC / PB;
@@ -840,7 +847,8 @@ extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64
     a.image = (const unsigned char*)image;
     a.out = (bf16_t*)out; a.ld_out = ld_out;
     a.tiles = (int)cdiv64(M, 128);
-    const int grid = a.tiles < 512 ? a.tiles : 512;
+    int grid = a.tiles < 256 ? a.tiles : 256;
+    if (const char* gq = getenv("DMT_PROJ_GRID")) { const int v = atoi(gq); if (v > 0 && v < grid) grid = v; }   // (timing experiments)
     const char* dbg = getenv("DMT_PROJ_DEBUG");   // timing experiments (see DBG above); never set in production
     switch (dbg ? atoi(dbg) : 0) {
       case 1: hipLaunchKernelGGL((proj_kernel<G, 1>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
@@ -849,6 +857,9 @@ extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64
       case 5: hipLaunchKernelGGL((proj_kernel<G, 5>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       case 7: hipLaunchKernelGGL((proj_kernel<G, 7>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       case 8: hipLaunchKernelGGL((proj_kernel<G, 8>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 79: hipLaunchKernelGGL((proj_kernel<G, 79>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 64: hipLaunchKernelGGL((proj_kernel<G, 64>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
+      case 47: hipLaunchKernelGGL((proj_kernel<G, 47>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       case 15: hipLaunchKernelGGL((proj_kernel<G, 15>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       default: hipLaunchKernelGGL((proj_kernel<G>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a);
     }
