@@ -316,7 +316,6 @@ class DMTEngine:
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
         self.defer_sparse, self._pending_sparse = False, None     # GatherFn.backward leaves its work to finish_sparse_backward()
         self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") != "0"        # side streams for the behaviour sequences
-        self.seq_stream_mode = "dec" if os.environ.get("DMT_SEQ_STREAMS", "1") == "dec" else "seq"
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
@@ -519,25 +518,6 @@ class DMTEngine:
         main = torch.cuda.current_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
         pairs_all = self.spec["attention_embed_pairs"]
         us, order = [None] * n_seq, list(range(n_seq))
-        if main is not None and self.seq_stream_mode == "dec":
-            # DECODER LANE: the encoders (big kernels) stay back to back on the compute stream; every decoder (a chain of small B-row
-            # kernels) runs on ONE side stream beside the next sequence's encoder -- and, in backward, beside the previous one's.
-            lane = self._seq_stream_pool(2)[1]
-            tar.record_stream(lane)
-            for i in order:
-                lens = batch.feats[pairs_all[i][-1][0]].lens
-                mem = self.encode_prepared(X[i], lens, i)
-                lane.wait_stream(main)
-                mem.record_stream(lane)
-                with torch.cuda.stream(lane):
-                    y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
-                    y.record_stream(main)
-                us[i] = y.squeeze(1)
-                self.intermediates["memory_%d" % i] = mem
-            main.wait_stream(lane)
-            z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *us)
-            self.intermediates["zbuf"] = z
-            return z
         if main is not None:
             # Sequence 0 stays on the compute stream; the others start from ONE event (the gathered inputs), not behind sequence 0.
             # (Measured: issue order -- by length, either way -- moves the step by < 1 %; putting the compute stream's sequence

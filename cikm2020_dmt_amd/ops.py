@@ -7,7 +7,6 @@ raises (cikm2020_dmt_amd/_lib.py).
 from __future__ import annotations
 
 import ctypes as C
-import contextlib
 import os
 import ctypes as _ct
 import math
@@ -197,15 +196,10 @@ def _grad_view(leaf):
 
 WGRAD320_MIN_ROWS = 16384
 
-# Weight gradients of the long (B x T)-row GEMMs leave the backward critical path: nothing in backward reads them (only the
-# optimizer does), so they are issued on a side stream of the stream that produced their operands and accumulate into the gradient
-# arena with fp32 atomics there.  The dX chain of the next layer starts at once, and the tail of the weight-gradient work runs
-# beside the id-bound end of the step (embedding-gradient reduction, sparse Adam, next gather).  join_wgrad() -- called by the
-# Trainer, and queued as an end-of-backward callback for everybody else -- orders the consumer behind them.
-WGRAD_STREAMS = os.environ.get("DMT_WGRAD_STREAMS", "0") == "1"
-_wgrad_pool, _wgrad_open, _wgrad_cb = {}, {}, [False]
-
-
+# Weight gradients of the long (B x T)-row GEMMs can leave the backward critical path: nothing in backward reads them (only the
+# optimizer does).  begin_deferred_wgrads() makes backward COLLECT them; the Trainer launches them where they hide something -- beside
+# the gradient-row exchange of a data-parallel step (train_step), or beside the id-bound tail of a one-GPU step (DMT_SPARSE_LANE).
+# (Tried and dropped: side streams per compute stream for them -- 1 %, and their queues collide with the lanes, streams.py.)
 _deferred = [None]      # list of closures while a Trainer step collects its long-row weight gradients (begin_deferred_wgrads)
 
 
@@ -235,28 +229,6 @@ def deferred_wgrads_pending():
     return len(_deferred[0]) if _deferred[0] is not None else 0
 
 
-def _wgrad_defer(x, dz):
-    """-> (event-ordered side stream) for this weight gradient, or None: same stream."""
-    if not (WGRAD_STREAMS and not DETERMINISTIC and x.is_cuda and x.shape[0] >= WGRAD320_MIN_ROWS):
-        return None
-    cur = torch.cuda.current_stream(x.device)
-    key = (x.device.index, cur.cuda_stream)
-    ws = _wgrad_pool.get(key)
-    if ws is None:
-        ws = _wgrad_pool[key] = torch.cuda.Stream(x.device)
-    _wgrad_open[key] = ws
-    ws.wait_stream(cur)
-    x.record_stream(ws)
-    dz.record_stream(ws)
-    if not _wgrad_cb[0]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_end_of_backward)
-            _wgrad_cb[0] = True
-        except RuntimeError:       # not inside a backward pass: the caller joins
-            pass
-    return ws
-
-
 def _deferred_wgrad320(x, dz, gw, gb, k_is_320):
     cur = torch.cuda.current_stream(x.device)
     x.record_stream(cur)          # (operands of the side-lane sequences were allocated on their streams)
@@ -265,22 +237,6 @@ def _deferred_wgrad320(x, dz, gw, gb, k_is_320):
         wgrad320(x, dz, gw, False, gb, 1)
     else:
         wgrad320(dz, x, gw, True, gb, 2)
-
-
-def _wgrad_end_of_backward():
-    _wgrad_cb[0] = False
-    for (dev, _k), ws in list(_wgrad_open.items()):
-        torch.cuda.default_stream(dev).wait_stream(ws)
-
-
-def join_wgrad(device=None):
-    """The current stream waits for every weight gradient issued on a side stream since the last join."""
-    if not _wgrad_open:
-        return
-    cur = torch.cuda.current_stream(device)
-    for ws in _wgrad_open.values():
-        cur.wait_stream(ws)
-    _wgrad_open.clear()
 
 
 def wgrad320(A, B, C, transposed, bias=None, bias_of=0):
@@ -321,12 +277,10 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
         if _deferred[0] is not None:
             _deferred[0].append(lambda: _deferred_wgrad320(x, dz, gw, gb if want_bias else None, K == 320))
             return None, None
-        ws = _wgrad_defer(x, dz)
-        with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
-            if K == 320:
-                wgrad320(x, dz, gw, False, gb if want_bias else None, 1)
-            else:
-                wgrad320(dz, x, gw, True, gb if want_bias else None, 2)
+        if K == 320:
+            wgrad320(x, dz, gw, False, gb if want_bias else None, 1)
+        else:
+            wgrad320(dz, x, gw, True, gb if want_bias else None, 2)
         return None, None
     if gw is not None and (gb is not None or not want_bias):
         if _deferred[0] is not None and M >= WGRAD320_MIN_ROWS:
@@ -338,10 +292,8 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
                      split_k=split, accumulate=True)
             _deferred[0].append(_later)
             return None, None
-        ws = _wgrad_defer(x, dz)
-        with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
-            gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
-                 split_k=split, accumulate=True)
+        gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
+             split_k=split, accumulate=True)
         return None, None
     dW = torch.zeros((K, N), dtype=F32, device=x.device)
     db = torch.zeros((N,), dtype=F32, device=x.device) if want_bias else None

@@ -291,8 +291,8 @@ class Trainer:
         return self.exchange_rows_collect(self.exchange_rows_reduce(handle, plan))
 
     def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False):
-        """join=False leaves the side-stream weight gradients (ops._wgrad_defer) open: the caller must ops.join_wgrad() before it
-        reads the dense gradient arena.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
+        """join=False (one-GPU train_step with the sparse lane): backward only collects the long-row weight gradients and leaves the
+        embedding-gradient tail to the caller.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
         self.sync_rows(batch)
         self.store.zero_grad()
         rank, _W = parallel.world()
@@ -329,8 +329,6 @@ class Trainer:
             raise
         finally:
             self.engine.defer_sparse = False
-        if join:
-            ops.join_wgrad(self.device)           # weight gradients issued on side streams (ops._wgrad_defer)
         self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
         return loss.detach()
@@ -432,17 +430,14 @@ class Trainer:
                     self.opt.begin()
                     self.opt.apply_sparse(self.engine.sparse, 1.0)
                 self.n_deferred = ops.run_deferred_wgrads()
-                ops.join_wgrad(self.device)
                 main.wait_stream(lane)
                 self.opt.apply_dense(1.0)
                 self.opt.end()
                 self.store.refresh_shadows()
                 return loss
             ops.run_deferred_wgrads()
-            # the embedding rows first: the last weight gradients are still accumulating on their side streams meanwhile
             self.opt.begin()
             self.opt.apply_sparse(sparse, 1.0)
-            ops.join_wgrad(self.device)
             self.opt.apply_dense(1.0)
             self.opt.end()
             self.store.refresh_shadows()

@@ -49,7 +49,9 @@ def test_deterministic_mode_is_bit_reproducible(cuda, dtype):
     #  mode -- another rounding of the same numbers; losses of ~10 after three steps)
     assert np.abs(np.array(l0) - np.array(l1)).max() < (1e-4 if dtype == torch.float32 else 6e-2)
     worst = max(float(np.abs(s0[k] - s1[k]).max()) for k in s1)
-    assert worst < 4e-3, worst          # three Adam steps bound any element's movement
+    # three Adam steps at lr 1e-3 bound any element's movement by 3e-3 each way: an element whose true gradient is 0 (the key bias of
+    # an attention block: the softmax does not see it) moves on rounding noise alone and can end 6e-3 apart
+    assert worst < 6.5e-3, worst
 
 
 def test_atomic_kernels_refuse_in_deterministic_mode(cuda):
