@@ -29,6 +29,9 @@ def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
+    if not bf16:
+        from cikm2020_dmt_amd import ops
+        ops.set_deterministic(True)     # (bit-for-bit comparisons BETWEEN runs: the default mode's fp32 atomics follow kernel timing)
     tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dp_exchange=dp_exchange, dropout=False)
     tr.store.load_state(P)
     losses = []
@@ -188,6 +191,9 @@ def _nccl_world1_step(q, bf16):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
+    if not bf16:
+        from cikm2020_dmt_amd import ops
+        ops.set_deterministic(True)     # (bit-for-bit comparisons BETWEEN runs: the default mode's fp32 atomics follow kernel timing)
     states = []
     for force, ahead in ((False, False), (True, False), (True, True)):
         tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, force_dp=force, dropout=False)

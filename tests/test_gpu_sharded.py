@@ -22,6 +22,7 @@ def _free_port():
 
 def _worker(rank, world, port, q, steps, layout, bf16, backend="gloo"):
     import torch.distributed as dist
+    from cikm2020_dmt_amd import ops
     from cikm2020_dmt_amd.train import Trainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,6 +34,10 @@ def _worker(rank, world, port, q, steps, layout, bf16, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
+    if not bf16:
+        # bit-for-bit claims hold in deterministic mode: in the default mode partial sums that meet in one element are combined with
+        # fp32 atomics, and their order follows the timing of the kernels (two processes and three stream lanes share the GPU here)
+        ops.set_deterministic(True)
     tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dropout=False,
                  table_layout=layout, force_dp=(backend == "nccl"))
     tr.store.load_state(P)
