@@ -161,6 +161,28 @@ class _GatherPlan:
             it["row_base"] = store.table_rows[it["table"]][0]
 
 
+class FanOutFn(torch.autograd.Function):
+    """x -> n aliases of x, ONE backward node that sums their gradients.  The target item's embedding feeds all three decoders: left
+    to autograd, the three gradients meet in the input buffer of the gather node, and the engine queues "wait for lane C's decoder
+    backward, add" on the compute stream BEFORE it gets to issue sequence 0's backward there (it issues nodes newest-first): the
+    lanes then start one after the other's decoder instead of together.  This node is older than every sequence, so its waits are
+    queued after all three backward pipelines (measured: 9.75 -> 9.61 ms/step)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = acc + g
+        return acc, None
+
+
 class GatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, batch, *pos_leaves):
@@ -518,6 +540,7 @@ class DMTEngine:
         main = torch.cuda.current_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
         pairs_all = self.spec["attention_embed_pairs"]
         us, order = [None] * n_seq, list(range(n_seq))
+        tars = FanOutFn.apply(tar, n_seq) if (tar.requires_grad and n_seq > 1) else (tar,) * n_seq
         if main is not None:
             # Sequence 0 stays on the compute stream; the others start from ONE event (the gathered inputs), not behind sequence 0.
             # (Measured: issue order -- by length, either way -- moves the step by < 1 %; putting the compute stream's sequence
@@ -531,15 +554,15 @@ class DMTEngine:
             if st is not None:
                 st.wait_event(ready)
                 X[i].record_stream(st)            # (allocated on the compute stream, read on this one)
-                tar.record_stream(st)
+                tars[i].record_stream(st)
                 with torch.cuda.stream(st):
                     mem = self.encode_prepared(X[i], lens, i)
-                    y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
+                    y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i)
                     y.record_stream(main)
                     mem.record_stream(main)
             else:
                 mem = self.encode_prepared(X[i], lens, i)
-                y = self.decode_prepared(tar.unsqueeze(1), mem, lens, i)
+                y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i)
             us[i] = y.squeeze(1)
             self.intermediates["memory_%d" % i] = mem
         if main is not None:
