@@ -745,7 +745,13 @@ class DMTEngine:
             perm, recv_k, send_splits, recv_splits = parallel.request_rows(uniq, n)
         R = recv_k.numel()
         if opt is not None and opt.global_step > 0 and R > 0:
-            opt.catch_up(recv_k, torch.tensor([R], dtype=torch.int32, device=recv_k.device), R)
+            # replay on DISTINCT rows only: a hot row is requested by several ranks, and two wavefronts replaying the same row at once
+            # tear each other's p / m / v (seen as a 1e-5 loss difference in one run out of three at two ranks)
+            if plan is not None and plan.get("keys_s") is not None:
+                opt.catch_up(plan["uniq2"], plan["n_uniq2"], R)
+            else:
+                ku = torch.unique(recv_k)
+                opt.catch_up(ku.to(recv_k.dtype), torch.tensor([ku.numel()], dtype=torch.int32, device=recv_k.device), int(ku.numel()))
         tm = store.fill_table_map(L.TableMap())
         D = self.plan.max_dim
         rows_out = torch.empty((max(R, 1), D), dtype=F32, device=store.device)

@@ -75,7 +75,7 @@ class Trainer:
         ov = os.environ.get("DMT_DP_OVERLAP_WGRADS", "auto")
         self.overlap_wgrads = (parallel.world()[1] > 1) if ov == "auto" else (ov == "1")
         self.sparse_lane = os.environ.get("DMT_SPARSE_LANE", "0") == "1"     # one-GPU step: id-bound tail beside the deferred weight gradients (off: even at L=50, -3 % at L=200)
-        self.index_stream, self._ix_stream = True, None    # index plane (id sort, exchange plan) on a side stream: sync_rows
+        self.index_stream, self._ix_stream = os.environ.get("DMT_INDEX_STREAM", "1") == "1", None    # index plane (id sort, exchange plan) on a side stream: sync_rows
         if self.device.type == "cuda":
             streams.lanes(self.device)                     # bind the step's lanes to hardware queues before anything else (streams.py)
             if self._dp_active():

@@ -29,6 +29,12 @@ def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
+    if os.environ.get("DMT_TEST_POLLUTE", "nan") != "off":        # (NaN-filled free blocks: tests/test_gpu_sharded.py)
+        fill = float(os.environ.get("DMT_TEST_POLLUTE", "nan"))
+        junk = [torch.full((1 << 26,), fill, device="cuda:0") for _ in range(4)]
+        junk += [torch.full((n,), fill, device="cuda:0") for n in (7, 64, 300, 4096, 20000, 70000, 1 << 20) for _ in range(6)]
+        torch.cuda.synchronize()
+        del junk
     if not bf16:
         from cikm2020_dmt_amd import ops
         ops.set_deterministic(True)     # (bit-for-bit comparisons BETWEEN runs: the default mode's fp32 atomics follow kernel timing)
@@ -232,6 +238,12 @@ def _nccl_world1_overlap(q):
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     ops.set_deterministic(True)
+    if os.environ.get("DMT_TEST_POLLUTE", "nan") != "off":        # (NaN-filled free blocks: tests/test_gpu_sharded.py)
+        fill = float(os.environ.get("DMT_TEST_POLLUTE", "nan"))
+        junk = [torch.full((1 << 26,), fill, device="cuda:0") for _ in range(8)]
+        junk += [torch.full((n,), fill, device="cuda:0") for n in (7, 64, 300, 4096, 20000, 70000, 1 << 20) for _ in range(6)]
+        torch.cuda.synchronize()
+        del junk
     sp = S.scaled_spec(S.e64_spec(), {"Sku": 20000, "Brand": 3000, "Shopid": 3000, "Cid3": 1200})
     states, deferred = [], []
     for force, overlap, layout in ((False, False, "replicated"), (True, True, "replicated"), (True, False, "replicated"), (True, True, "sharded")):

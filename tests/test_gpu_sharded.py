@@ -34,6 +34,15 @@ def _worker(rank, world, port, q, steps, layout, bf16, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     so, sp = small_specs()
     P = O.init_params(so, seed=5)
+    if os.environ.get("DMT_TEST_POLLUTE", "nan") != "off":
+        # the caching allocator's free blocks are filled with NaNs first: a kernel that reads memory nobody wrote, or a buffer that
+        # lands elsewhere than in a fresh process, shows up here (this is how the duplicate-row replay race of fetch_rows was caught:
+        # inside the whole suite the test failed in two runs out of five, alone never)
+        fill = float(os.environ.get("DMT_TEST_POLLUTE", "nan"))
+        junk = [torch.full((1 << 26,), fill, device="cuda:0") for _ in range(8)]
+        junk += [torch.full((n,), fill, device="cuda:0") for n in (7, 64, 300, 4096, 20000, 70000, 1 << 20) for _ in range(6)]
+        torch.cuda.synchronize()
+        del junk
     if not bf16:
         # bit-for-bit claims hold in deterministic mode: in the default mode partial sums that meet in one element are combined with
         # fp32 atomics, and their order follows the timing of the kernels (two processes and three stream lanes share the GPU here)
