@@ -569,14 +569,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int qt = 0; qt < NTQ; ++qt) {
     const int q = qt * 32 + l31;
     float m = -3.0e38f;
+    int klv = kl, tkv = tk;          // (opaque copies: see attn_bwd_co_kernel)
+    asm volatile("" : "+v"(klv), "+v"(tkv));
 #pragma unroll
     for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
         float x = acc[kt][qt][r] * kscale;
-        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
-        x = (c >= tk) ? -3.0e38f : x;
+        x = (c >= klv) ? PADDING_NUM * LOG2E : x;
+        x = (c >= tkv) ? -3.0e38f : x;
         acc[kt][qt][r] = x;
         m = fmaxf(m, x);
       }
@@ -1043,14 +1045,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __builtin_amdgcn_sched_barrier(0);
       }
       float m = -3.0e38f;
+      // (opaque copies: hipcc would otherwise hoist the 2 x 32 x NTQ lane masks of these compares out of the query-tile loop and
+      //  keep them in SGPR pairs -- 153 spilled SGPRs)
+      int klv = kl, tkv = tk;
+      asm volatile("" : "+v"(klv), "+v"(tkv));
 #pragma unroll
       for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
           float x = acc[kt][r] * kscale;
-          x = (c >= kl) ? PADDING_NUM * LOG2E : x;
-          x = (c >= tk) ? -3.0e38f : x;
+          x = (c >= klv) ? PADDING_NUM * LOG2E : x;
+          x = (c >= tkv) ? -3.0e38f : x;
           acc[kt][r] = x;
           m = fmaxf(m, x);
         }
@@ -1081,14 +1087,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       dot += __shfl_xor(dot, 32, 64);
       const bool qpad = (q >= qlen);
+      asm volatile("" : "+v"(klv), "+v"(tkv));
 #pragma unroll
       for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
           float pv = acc[kt][r];
-          float ds = (c < kl) ? pv * (dp[kt][r] - dot) * inv_sc : 0.f;      // no gradient into masked keys
-          if (qpad) { ds = 0.f; pv = (c < tk) ? PADDING_NUM : 0.f; }        // constant rows: gradient reaches V only
+          float ds = (c < klv) ? pv * (dp[kt][r] - dot) * inv_sc : 0.f;     // no gradient into masked keys
+          if (qpad) { ds = 0.f; pv = (c < tkv) ? PADDING_NUM : 0.f; }       // constant rows: gradient reaches V only
           if (a.drop_on) pv = ((keep >> (kt * 16 + r)) & 1u) ? pv * a.drop_inv : 0.f;   // dropped weights feed dV
           dp[kt][r] = ds;
           acc[kt][r] = pv;
