@@ -7,8 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import math
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -9,8 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import ctypes as _ct
-import math
-from typing import Optional, Sequence
+from typing import Optional
 
 import torch
 

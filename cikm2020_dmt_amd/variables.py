@@ -12,7 +12,7 @@ TF-named variables are (leaf, slice) views used by state_dict()/load_state().
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
