@@ -140,3 +140,27 @@ def test_demo_fixture_shape_facts():
     assert np.bincount(cls, minlength=5).tolist() == [434, 1, 21, 4, 14]       # SURVEY.md §8c label distribution
     assert demo["l_clk_seq_sku_7d_50"].max() == 50 and demo["l_ord_seq_sku_12m_10"].max() == 10
     assert demo["l_clk_seq_sku_7d_50"].min() >= 1
+
+
+def test_deferred_weight_gradient_queue_semantics():
+    """ops.begin_deferred_wgrads / run_deferred_wgrads: closures run once, in collection order, in one or several batches (the
+    data-parallel step launches half of them beside the all_to_all and the rest beside the all-gather)."""
+    from cikm2020_dmt_amd import ops
+    assert ops.run_deferred_wgrads() == 0 and ops.deferred_wgrads_pending() == 0
+    seen = []
+    ops.begin_deferred_wgrads()
+    for i in range(5):
+        ops._deferred[0].append(lambda i=i: seen.append(i))
+    assert ops.deferred_wgrads_pending() == 5
+    assert ops.run_deferred_wgrads(upto=3) == 3 and seen == [0, 1, 2] and ops.deferred_wgrads_pending() == 2
+    assert ops.run_deferred_wgrads() == 2 and seen == [0, 1, 2, 3, 4]
+    assert ops._deferred[0] is None and ops.run_deferred_wgrads() == 0      # collection is off again: backward launches at once
+    ops.begin_deferred_wgrads()
+    assert ops.run_deferred_wgrads(upto=4) == 0 and ops._deferred[0] is None
+
+
+def test_index_group_is_the_default_group_without_rccl():
+    """parallel.index_group(): a second communicator exists only for RCCL; without a process group (or with gloo) the index plane
+    uses the default one (None)."""
+    from cikm2020_dmt_amd import parallel
+    assert parallel.index_group() is None
