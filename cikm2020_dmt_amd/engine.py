@@ -721,9 +721,9 @@ class DMTEngine:
         keys_s = torch.empty((n,), dtype=torch.int32, device=dev)
         vals_s = torch.empty((n,), dtype=torch.int32, device=dev)
         L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), ops.p(vals), st)
-        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n)
+        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n, own=True)      # (kept by the batch: no copies)
         cap = min(n, self.store.total_rows)
-        prep = dict(desc=desc, n=n, keys_s=keys_s, vals_s=vals_s, seg=seg.clone(), uniq=uniq[:cap].clone(), n_uniq=n_uniq.clone(), cap=cap)
+        prep = dict(desc=desc, n=n, keys_s=keys_s, vals_s=vals_s, seg=seg, uniq=uniq[:cap], n_uniq=n_uniq, cap=cap)
         batch._prep = prep
         return prep
 
@@ -824,9 +824,10 @@ class DMTEngine:
                ops.p(grad_rows), plan.max_dim, ws, wsb, ops.stream_ptr())
         self.sparse = (prep["uniq"], prep["n_uniq"], grad_rows, prep["cap"])
 
-    def sort_segments(self, keys, vals, keys_s, vals_s, n, tag=""):
+    def sort_segments(self, keys, vals, keys_s, vals_s, n, tag="", own=False):
         """Stable sort of (row, entry) pairs + segment ids of equal rows.  `tag` names the scratch set: callers on different streams
-        (index plane / compute stream) must not share one."""
+        (index plane / compute stream) must not share one.  own: the results are fresh tensors the caller may keep (otherwise views of
+        the scratch set, to be cloned before the next call)."""
         store = self.store
         st = ops.stream_ptr()
         end_bit = max(1, int(store.total_rows).bit_length())
@@ -835,9 +836,14 @@ class DMTEngine:
         ws = self._buf(tag + "sort_ws", (max(int(need.value), 16),), torch.uint8)
         have = C.c_uint64(ws.numel())
         L.call("dmt_sort_pairs", ops.p(keys), ops.p(keys_s), ops.p(vals), ops.p(vals_s), n, end_bit, ops.p(ws), C.byref(have), st)
-        seg = self._buf(tag + "seg", (n,), torch.int32)
-        uniq = self._buf(tag + "uniq", (n,), torch.int32)
-        n_uniq = self._buf(tag + "n_uniq", (1,), torch.int32)
+        if own:
+            dev = store.device
+            seg, uniq, n_uniq = (torch.empty((n,), dtype=torch.int32, device=dev), torch.empty((n,), dtype=torch.int32, device=dev),
+                                 torch.empty((1,), dtype=torch.int32, device=dev))
+        else:
+            seg = self._buf(tag + "seg", (n,), torch.int32)
+            uniq = self._buf(tag + "uniq", (n,), torch.int32)
+            n_uniq = self._buf(tag + "n_uniq", (1,), torch.int32)
         need2 = C.c_uint64(0)
         L.call("dmt_segment_heads", ops.p(keys_s), n, store.total_rows, ops.p(seg), ops.p(uniq), ops.p(n_uniq), None, C.byref(need2), st)
         ws2 = self._buf(tag + "heads_ws", (max(int(need2.value), 16),), torch.uint8)

@@ -193,8 +193,8 @@ class Trainer:
             vals = torch.arange(Rn, dtype=torch.int32, device=dev)
             keys_s = torch.empty((Rn,), dtype=torch.int32, device=dev)
             vals_s = torch.empty((Rn,), dtype=torch.int32, device=dev)
-            uniq2, n_uniq2, seg = eng.sort_segments(recv_k, vals, keys_s, vals_s, Rn)
-            plan.update(keys_s=keys_s, vals_s=vals_s, seg=seg.clone(), uniq2=uniq2[:Rn].clone(), n_uniq2=n_uniq2.clone())
+            uniq2, n_uniq2, seg = eng.sort_segments(recv_k, vals, keys_s, vals_s, Rn, own=True)
+            plan.update(keys_s=keys_s, vals_s=vals_s, seg=seg, uniq2=uniq2[:Rn], n_uniq2=n_uniq2)
         else:
             plan.update(keys_s=None, uniq2=uniq[:0], n_uniq2=torch.zeros(1, dtype=torch.int32, device=dev))
         if self.table_layout == "sharded":

@@ -38,6 +38,7 @@ tot_t = sum(v[1] for v in acc["t"].values()) / nt / 1e6
 tot_x = sum(v[1] for v in acc["x"].values()) / max(nx, 1) / 1e6
 span_t = (bounds_t[1] - bounds_t[0]) / nt / 1e6
 print("timed steps: %.3f ms wall per step, %.3f ms of kernel time per step (lanes overlap); exclusive steps: %.3f ms of kernel time per step" % (span_t, tot_t, tot_x))
+print("launches per step: %.1f (timed), %.1f (exclusive)" % (sum(v[0] for v in acc["t"].values()) / nt, sum(v[0] for v in acc["x"].values()) / max(nx, 1)))
 print("%-88s %7s %10s %10s %10s" % ("kernel", "calls", "ms/step", "avg us", "avg us"))
 print("%-88s %7s %10s %10s %10s" % ("", "/step", "(timed)", "(timed)", "(exclusive)"))
 for nm, (c, d) in sorted(acc["t"].items(), key=lambda kv: -kv[1][1])[:45]:
