@@ -127,7 +127,6 @@ _SIGS = {
     "dmt_rows_permute": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp],
     "dmt_zero_rows": [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp],
     "dmt_rows_reduce_bf16": [c_vp, c_vp, c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_i32, c_vp, C.c_uint64, c_vp],
-    "dmt_set_deterministic": [c_i32],
     "dmt_gemm": [C.POINTER(GemmDesc), c_vp],
     "dmt_attn_fwd": [C.POINTER(AttnDesc), c_vp],
     "dmt_attn_bwd": [C.POINTER(AttnBwdDesc), c_vp],
@@ -163,8 +162,8 @@ _SIGS = {
     "dmt_cast_transpose_bf16_batched": [c_i32, c_vp, c_i32, c_vp],
     "dmt_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_vp, c_vp],
     "dmt_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_vp],
-    "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp],
-    "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_vp],
+    "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp],
+    "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
     "dmt_confusion_counts": [c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],
     "dmt_l2_unique_rows": [c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
@@ -184,7 +183,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported", "dmt_proj_supported", "dmt_image_job_bytes",
-                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_get_deterministic", "dmt_reduce_det_ws_bytes"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_reduce_det_ws_bytes", "dmt_route_trace", "dmt_route_count", "dmt_route_dump"])
 
 _lib = None
 
@@ -221,14 +220,37 @@ def load():
     lib.dmt_heads_supported.argtypes = [c_i32] * 6
     lib.dmt_mmoe_experts_supported.restype = c_i32
     lib.dmt_mmoe_experts_supported.argtypes = [c_i32] * 5
-    lib.dmt_get_deterministic.restype = c_i32
-    lib.dmt_get_deterministic.argtypes = []
     lib.dmt_reduce_det_ws_bytes.restype = C.c_uint64
     lib.dmt_reduce_det_ws_bytes.argtypes = [c_i64, c_i32]
     lib.dmt_attn_long_supported.restype = c_i32
     lib.dmt_attn_long_supported.argtypes = [c_i32, c_i32, c_i32, c_i32]
+    lib.dmt_route_trace.restype = c_i32
+    lib.dmt_route_trace.argtypes = [c_i32]
+    lib.dmt_route_count.restype = c_i64
+    lib.dmt_route_count.argtypes = [C.c_char_p]
+    lib.dmt_route_dump.restype = c_i32
+    lib.dmt_route_dump.argtypes = [C.c_char_p, c_i32]
     _lib = lib
     return lib
+
+
+class route_trace:
+    """with route_trace() as rt: ...; rt.counts -> {route label: launches} of the kernels launched inside (diagnostic; tests)."""
+
+    def __enter__(self):
+        load().dmt_route_trace(1)
+        self.counts = {}
+        return self
+
+    def __exit__(self, *a):
+        lib = load()
+        lib.dmt_route_trace(0)
+        buf = C.create_string_buffer(16384)
+        lib.dmt_route_dump(buf, 16384)
+        for line in buf.value.decode().splitlines():
+            k, _, v = line.rpartition("=")
+            self.counts[k] = int(v)
+        return False
 
 
 class DmtError(RuntimeError):

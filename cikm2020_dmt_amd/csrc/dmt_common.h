@@ -10,7 +10,8 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 void dmt_set_error(const char* fmt, ...);
-int dmt_deterministic(void);      // dmt_set_deterministic(): fixed-order reductions instead of fp32 atomics
+extern int g_dmt_route_trace;     // dmt_route_trace(1): every successful launch notes its route label (which kernel variant ran)
+void dmt_route_note(const char* what);
 
 #define DMT_CHECK_ARG(cond, ...)            \
   do {                                      \
@@ -27,6 +28,7 @@ int dmt_deterministic(void);      // dmt_set_deterministic(): fixed-order reduct
       dmt_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));          \
       return DMT_ERR_LAUNCH;                                                         \
     }                                                                                \
+    if (g_dmt_route_trace) dmt_route_note(what);                                     \
   } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -12,12 +12,53 @@ void dmt_set_error(const char* fmt, ...) {
 
 extern "C" const char* dmt_last_error(void) { return g_err; }
 
-// Deterministic mode: every reduction that normally combines partial sums with fp32 atomics (order = scheduling) takes a fixed-order
-// form instead -- slower, bit-reproducible from run to run.
-static int g_deterministic = 0;
-int dmt_deterministic(void) { return g_deterministic; }
-extern "C" int dmt_set_deterministic(int32_t on) { g_deterministic = on ? 1 : 0; return DMT_OK; }
-extern "C" int dmt_get_deterministic(void) { return g_deterministic; }
+
+// Launch-route trace (diagnostic, off by default): while on, every successful launch counts under its route label -- the string its
+// DMT_CHECK_LAUNCH names, e.g. "dmt_attn_fwd(mfma, coalesced)" -- so a test can assert WHICH kernel variant an entry point took.
+#include <string.h>
+#include <mutex>
+int g_dmt_route_trace = 0;
+namespace {
+struct RouteSlot { char label[64]; long long count; };
+RouteSlot g_routes[128];
+int g_n_routes = 0;
+std::mutex g_route_mu;
+}  // namespace
+void dmt_route_note(const char* what) {
+  std::lock_guard<std::mutex> lk(g_route_mu);
+  for (int i = 0; i < g_n_routes; ++i)
+    if (strncmp(g_routes[i].label, what, sizeof(g_routes[i].label) - 1) == 0) { ++g_routes[i].count; return; }
+  if (g_n_routes < 128) {
+    strncpy(g_routes[g_n_routes].label, what, sizeof(g_routes[0].label) - 1);
+    g_routes[g_n_routes].label[sizeof(g_routes[0].label) - 1] = 0;
+    g_routes[g_n_routes++].count = 1;
+  }
+}
+extern "C" int dmt_route_trace(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_route_mu);
+  if (on) g_n_routes = 0;
+  g_dmt_route_trace = on ? 1 : 0;
+  return DMT_OK;
+}
+extern "C" int64_t dmt_route_count(const char* label) {
+  if (!label) return -1;
+  std::lock_guard<std::mutex> lk(g_route_mu);
+  for (int i = 0; i < g_n_routes; ++i)
+    if (strcmp(g_routes[i].label, label) == 0) return g_routes[i].count;
+  return 0;
+}
+extern "C" int dmt_route_dump(char* buf, int32_t cap) {
+  if (!buf || cap <= 0) return DMT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_route_mu);
+  int off = 0;
+  buf[0] = 0;
+  for (int i = 0; i < g_n_routes; ++i) {
+    const int n = snprintf(buf + off, (size_t)(cap - off), "%s=%lld\n", g_routes[i].label, g_routes[i].count);
+    if (n < 0 || n >= cap - off) break;
+    off += n;
+  }
+  return DMT_OK;
+}
 extern "C" int dmt_version(void) { return 1; }
 extern "C" const char* dmt_build_arch(void) { return "gfx950"; }
 

@@ -269,7 +269,6 @@ __global__ __launch_bounds__(DW_NT, 2) void wgrad320_kernel(const DwArgs g) {
 
 extern "C" int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream) {
   DMT_CHECK_ARG(d != nullptr, "dmt_wgrad320: null descriptor");
-  if (dmt_deterministic()) { dmt_set_error("dmt_wgrad320: sums its row blocks with fp32 atomics; deterministic mode uses dmt_gemm (split_k = 1)"); return DMT_ERR_UNSUPPORTED; }
   DMT_CHECK_ARG(d->A && d->B && d->C && d->M > 0 && d->N > 0, "dmt_wgrad320: bad argument");
   DMT_CHECK_ARG(d->a_cols == DW_AW, "dmt_wgrad320: A must be %d columns wide (got %d)", DW_AW, d->a_cols);
   DMT_CHECK_ARG(d->ld_a % 8 == 0 && d->ld_b % 8 == 0 && (((uintptr_t)d->A | (uintptr_t)d->B) & 15) == 0, "dmt_wgrad320: operand rows must be 16-byte aligned");

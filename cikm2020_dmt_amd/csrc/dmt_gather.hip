@@ -734,7 +734,7 @@ extern "C" int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_
 
 static int det_ws_check(int64_t n, int32_t max_dim, void* ws, uint64_t ws_bytes, const char* who) {
   DMT_CHECK_ARG(ws != nullptr && ws_bytes >= dmt_reduce_det_ws_bytes(n, max_dim) && (((uintptr_t)ws) & 15) == 0,
-                "%s: deterministic mode needs a 16-byte aligned workspace of dmt_reduce_det_ws_bytes(n, max_dim) bytes", who);
+                "%s: the ordered form needs a 16-byte aligned workspace of dmt_reduce_det_ws_bytes(n, max_dim) bytes", who);
   return DMT_OK;
 }
 
@@ -756,7 +756,7 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
   const long long chunks = cdiv64(n, 64);
   const unsigned nb = (unsigned)cdiv64(chunks, 4);
   hipStream_t st = (hipStream_t)stream;
-  if (dmt_deterministic()) {
+  if (det_ws != nullptr) {
     if (det_ws_check(n, max_dim, det_ws, det_ws_bytes, "dmt_embgrad_reduce") != DMT_OK) return DMT_ERR_ARG;
     float* part = (float*)det_ws;
     int* pseg = (int*)(part + chunks * 2 * max_dim);
@@ -808,7 +808,7 @@ static int rows_reduce_launch(const uint32_t* sorted_keys, const uint32_t* sorte
                               const char* who) {
   const long long chunks = cdiv64(n, 64);
   const unsigned nb = (unsigned)cdiv64(chunks, 4);
-  if (dmt_deterministic()) {
+  if (det_ws != nullptr) {
     if (det_ws_check(n, max_dim, det_ws, det_ws_bytes, who) != DMT_OK) return DMT_ERR_ARG;
     float* part = (float*)det_ws;
     int* pseg = (int*)(part + chunks * 2 * max_dim);

@@ -1110,7 +1110,6 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   DMT_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "dmt_gemm: M, N, K must be positive (%d %d %d)", d->M, d->N, d->K);
   DMT_CHECK_ARG(d->A && d->B && d->C, "dmt_gemm: null operand");
   const int split = d->split_k > 1 ? d->split_k : 1;
-  if (split > 1 && dmt_deterministic()) { dmt_set_error("dmt_gemm: split_k > 1 sums with fp32 atomics; deterministic mode needs split_k = 1"); return DMT_ERR_UNSUPPORTED; }
   const int batch = d->batch > 1 ? d->batch : 1;
   DMT_CHECK_ARG((split == 1 && !d->accumulate) || d->out_dtype == DMT_F32, "dmt_gemm: split_k / accumulate need an fp32 C");
   DMT_CHECK_ARG(split == 1 || (d->act_ncols == 0 && d->gate == nullptr), "dmt_gemm: split_k cannot fuse relu / gate");

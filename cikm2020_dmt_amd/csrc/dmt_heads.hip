@@ -314,7 +314,6 @@ extern "C" int dmt_heads_bwd(const dmt_heads_desc* d, void* stream) {
   DMT_CHECK_ARG(d->dlogits && d->dmix && d->dzb && d->dz_fc && d->dz0 && d->dz1 && d->g_bias_w2 && d->g_bias_b2, "dmt_heads_bwd: null argument");
   for (int t = 0; t < d->T; ++t) DMT_CHECK_ARG(d->g_out_w[t] && d->g_out_b[t], "dmt_heads_bwd: null gradient view");
   DMT_CHECK_ARG((((uintptr_t)d->dmix) & 15) == 0, "dmt_heads_bwd: dmix rows must be 16-byte aligned");
-  if (dmt_deterministic()) { dmt_set_error("dmt_heads_bwd: sums the 1-wide layers' gradients with fp32 atomics; deterministic mode uses the layer path"); return DMT_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL(heads_bwd_kernel, dim3((unsigned)cdiv64(d->B, 64)), dim3(256), 0, (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_heads_bwd");
   return DMT_OK;

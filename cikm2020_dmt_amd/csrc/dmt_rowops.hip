@@ -845,10 +845,10 @@ extern "C" int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const voi
 }
 
 extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, float scale, float* out, uint32_t seed,
-                               float keep_prob, void* stream) {
+                               float keep_prob, int32_t ordered, void* stream) {
   DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum_drop: bad argument");
   DMT_CHECK_ARG(keep_prob > 0.f && keep_prob <= 1.f, "dmt_colsum_drop: keep_prob must be in (0, 1]");
-  const bool det = dmt_deterministic() != 0;        // one row block per column: a single, ordered sum (one atomicAdd onto the accumulator)
+  const bool det = ordered != 0;        // one row block per column: a single, ordered sum (one atomicAdd onto the accumulator)
   const int rpb = det ? (int)(rows < 0x7fffffff ? rows : 0x7fffffff) : 64;
   dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
   DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum_drop: too many rows");
@@ -871,9 +871,9 @@ extern "C" int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const 
 }
 
 extern "C" int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
-                          void* stream) {
+                          int32_t ordered, void* stream) {
   DMT_CHECK_ARG(rows > 0 && cols > 0 && x && out, "dmt_colsum: bad argument");
-  const int rpb = dmt_deterministic() ? (int)(rows < 0x7fffffff ? rows : 0x7fffffff) : 64;     // deterministic: one ordered sum per column
+  const int rpb = ordered ? (int)(rows < 0x7fffffff ? rows : 0x7fffffff) : 64;     // ordered: one sum per column, in row order
   dim3 grid((unsigned)cdiv64(cols, 256), (unsigned)cdiv64(rows, rpb));
   DMT_CHECK_ARG(grid.y <= 65535, "dmt_colsum: too many rows");
   hipStream_t st = (hipStream_t)stream;

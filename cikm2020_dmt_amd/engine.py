@@ -288,7 +288,7 @@ class GatherFn(torch.autograd.Function):
             seeds, keep = ctx.drop
             if 0.0 < keep < 1.0:
                 L.call("dmt_colsum_drop", ops.dt_code(dX[s].dtype), B, ctx.seq_T[s] * d, ops.p(dX[s]), 1.0, ops.p(g), int(seeds[s]), float(keep),
-                       ops.stream_ptr())
+                       1 if ops.DETERMINISTIC else 0, ops.stream_ptr())
             else:
                 ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
             dpos.append(None if direct else g)
@@ -341,6 +341,7 @@ class DMTEngine:
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
+        self.kopts = ops.KernelOptions()  # attention / projection kernel choices of THIS engine (fp8 MFMA forward, long fused form, dmt_proj)
 
     @property
     def use_mhsa(self):
@@ -471,7 +472,7 @@ class DMTEngine:
             return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
                                          self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8)
         s1 = ops.SelfAttnBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"), lens, H,
-                                       *self._attn_drop(stream))
+                                       *self._attn_drop(stream), self.kopts)
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
     def mha_cross(self, q_in, mem, q_lens, k_lens, blk, stream=3):
@@ -488,7 +489,7 @@ class DMTEngine:
             s = ops.CrossQ1Fn.apply(q.reshape(-1, d), mem, q_in.reshape(-1, d), k_lens, w, wl, bl, wv_aug, H, seed, keep).unsqueeze(1)
             return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
         kv = ops.linear(mem, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d))
-        s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False, *self._attn_drop(stream))
+        s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False, *self._attn_drop(stream), self.kopts)
         return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
     def ff(self, x, ffs):
@@ -525,7 +526,7 @@ class DMTEngine:
         wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
         q = ops.linear(y, wl[:, :d], bl[:d], self._wslice(w, 0, d))
         kv = ops.linear(mem1, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d)).expand(y.shape[0], -1, -1)
-        s = ops.AttnFn.apply(q, kv, y, None, k_lens, H, d, False, 0, 1.0)
+        s = ops.AttnFn.apply(q, kv, y, None, k_lens, H, d, False, 0, 1.0, self.kopts)
         s = ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(s, blk + ffs)

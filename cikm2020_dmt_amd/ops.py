@@ -40,7 +40,10 @@ class _Timed:
         return False
 
 
-# Deterministic mode (DMT_DETERMINISTIC=1 or set_deterministic(True)): fixed-order reductions instead of fp32 atomics (include/dmt_hip.h)
+# Deterministic mode (DMT_DETERMINISTIC=1 or set_deterministic(True)): the numerics mode of this ops layer, in the sense of
+# torch.use_deterministic_algorithms -- every call site below then asks the library for the ordered form of a reduction (workspace
+# argument / `ordered` flag), keeps GEMMs unsplit and stays away from the kernels that sum with fp32 atomics.  The LIBRARY keeps no
+# mode (include/dmt_hip.h); kernel CHOICES that may differ between two engines of one process live in KernelOptions.
 DETERMINISTIC = False
 _det_ws = {}
 
@@ -48,7 +51,6 @@ _det_ws = {}
 def set_deterministic(on: bool):
     global DETERMINISTIC
     DETERMINISTIC = bool(on)
-    L.call("dmt_set_deterministic", 1 if on else 0)
 
 
 def det_ws(n: int, max_dim: int, device, tag=""):
@@ -489,7 +491,7 @@ def proj_image_build(w_f32, bias_f32, image):
 
 def proj_ok(x2, w):
     img = getattr(w, "proj", None)
-    return (USE_PROJ and img is not None and x2.dtype == BF16 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+    return (img is not None and x2.dtype == BF16 and x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
             and x2.data_ptr() % 16 == 0 and x2.shape[0] >= PROJ_MIN_ROWS)
 
 
@@ -504,7 +506,6 @@ def proj_forward(x2, w, n):
     return out
 
 
-USE_PROJ = os.environ.get("DMT_PROJ", "1") == "1"
 PROJ_MIN_ROWS = 1
 
 
@@ -643,7 +644,7 @@ class FFNLNChainFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out):
+def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out, mma_fp8=False):
     d = L.AttnDesc()
     d.dtype, d.B, d.H, d.dh, d.Tq, d.Tk = dt_code(dtype), B, H, dh, Tq, Tk
     d.Q, d.q_bs, d.q_rs = q.data_ptr(), q.stride(0), q.stride(1)
@@ -655,7 +656,7 @@ def _attn_desc(dtype, B, H, dh, Tq, Tk, q, k, v, q_lens, k_lens, resid, out):
         d.resid, d.r_bs, d.r_rs = resid.data_ptr(), resid.stride(0), resid.stride(1)
     if out is not None:
         d.out, d.o_bs, d.o_rs = out.data_ptr(), out.stride(0), out.stride(1)
-    d.mma_dtype = L.DMT_FP8_E4M3 if ATTN_MMA_FP8 else 0
+    d.mma_dtype = L.DMT_FP8_E4M3 if mma_fp8 else 0
     return d
 
 
@@ -757,21 +758,42 @@ class Unbind0Fn(torch.autograd.Function):
         return g
 
 
+class KernelOptions:
+    """Kernel choices of ONE engine (DMTEngine.kopts), handed to the autograd Functions as an argument -- no process-wide switch, so two
+    Trainers in one process can differ (tests/test_gpu_boundary.py::test_two_trainers_with_different_kernel_options_in_one_process).
+      attn_mma_fp8     the long-sequence (64 < T <= 256) attention forward multiplies in OCP e4m3 (Trainer(attn_dtype="fp8"))
+      attn_long_fused  False: force the unfused batched-GEMM form for T > 64 (comparison runs)
+      use_proj         streamed-weight QKV projection (dmt_proj) where the weight has an image; default from DMT_PROJ (1)"""
+    __slots__ = ("attn_mma_fp8", "attn_long_fused", "use_proj")
+
+    def __init__(self, attn_mma_fp8=False, attn_long_fused=True, use_proj=None):
+        self.attn_mma_fp8 = bool(attn_mma_fp8)
+        self.attn_long_fused = bool(attn_long_fused)
+        self.use_proj = (os.environ.get("DMT_PROJ", "1") == "1") if use_proj is None else bool(use_proj)
+
+    def replace(self, **kw):
+        o = KernelOptions(self.attn_mma_fp8, self.attn_long_fused, self.use_proj)
+        for k, v in kw.items():
+            setattr(o, k, bool(v))
+        return o
+
+
+DEFAULT_OPTIONS = KernelOptions()      # what a direct caller of the Functions gets when it passes none (never mutated)
+
+
 # ---- attention core: fused kernels for T <= 64 (one wavefront per (example, head)) and for 64 < T <= 256 (dmt_attn_long.hip: one
 #      workgroup per (example, head), flash style); the unfused batched-GEMM form remains for what neither takes (fp32, odd head dims)
 ATTN_FUSED_MAX_T = 64
-ATTN_MMA_FP8 = False            # True: the long-sequence forward kernel multiplies in OCP e4m3 (Trainer(attn_dtype="fp8"), BASELINE configs[4])
-ATTN_LONG_FUSED = True          # False: force the unfused form for T > 64 (comparison runs, tests)
 
 
 def _rows16(t):
     return t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.stride(2) == 1)
 
 
-def long_fused_ok(H, *tensors):
+def long_fused_ok(H, *tensors, opts=None):
     """The flash-style long-sequence kernels take this call: bf16, head dim 16/32/64/80, T <= 256, 16-byte aligned rows."""
     q, k = tensors[0], tensors[1]
-    if not ATTN_LONG_FUSED or q.dtype != BF16:
+    if not (opts or DEFAULT_OPTIONS).attn_long_fused or q.dtype != BF16:
         return False
     if not L.load().dmt_attn_long_supported(dt_code(q.dtype), q.shape[2] // H, q.shape[1], k.shape[1]):
         return False
@@ -826,13 +848,14 @@ def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, d
              c_bs=dv.stride(0))
 
 
-def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
+def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts=None):
     """Returns what the backward needs beyond its inputs: None (fused kernels recompute P) or the saved P of the long form."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
-    if max(Tq, Tk) > ATTN_FUSED_MAX_T and not long_fused_ok(H, q, k, v, resid, out):
+    opts = opts or DEFAULT_OPTIONS
+    if max(Tq, Tk) > ATTN_FUSED_MAX_T and not long_fused_ok(H, q, k, v, resid, out, opts=opts):
         return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
-    desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out)
+    desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out, mma_fp8=opts.attn_mma_fp8)
     desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
     with _Timed("attn_long" if max(Tq, Tk) > ATTN_FUSED_MAX_T else "attn", 4.0 * B * Tq * Tk * d):
         L.call("dmt_attn_fwd", C.byref(desc), stream_ptr())
@@ -860,7 +883,7 @@ class AttnFn(torch.autograd.Function):
     their gradients are written straight into one packed buffer per distinct base tensor (`pack`)."""
 
     @staticmethod
-    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn, drop_seed=0, drop_keep=1.0):
+    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn, drop_seed=0, drop_keep=1.0, opts=None):
         # self_attn: packed_q is [B,T,3d] = (Q|K|V), packed_kv is None.
         # cross:     packed_q is [B,Tq,d] = Q, packed_kv is [B,Tk,2d] = (K|V).
         if self_attn:
@@ -871,7 +894,7 @@ class AttnFn(torch.autograd.Function):
             q, k, v = packed_q, packed_kv[..., :d], packed_kv[..., d:]
         B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
         out = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
-        ctx.P = attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
+        ctx.P = attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts)
         ctx.save_for_backward(packed_q, packed_kv, q_lens, k_lens)
         ctx.H, ctx.d, ctx.self_attn = H, d, self_attn
         ctx.drop = (int(drop_seed), float(drop_keep))
@@ -896,7 +919,7 @@ class AttnFn(torch.autograd.Function):
             dq, dk, dv = dpq, dpkv[..., :d], dpkv[..., d:]
         attn_core_bwd(q, k, v, q_lens, k_lens, ctx.P, dout, dq, dk, dv, H, *ctx.drop)
         ctx.P = None
-        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None
+        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None, None
 
 
 def q1mem_supported(d, H, T, dtype=BF16):
@@ -980,17 +1003,18 @@ class SelfAttnBlockFn(torch.autograd.Function):
     (as two nodes autograd adds the residual gradient in a separate pass over [B, T, d])."""
 
     @staticmethod
-    def forward(ctx, x, w_leaf, b_leaf, w: Weight, lens, H, drop_seed, drop_keep):
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, lens, H, drop_seed, drop_keep, opts=None):
         _chk3(x, "x")
         B, T, d = x.shape
         x2 = x.reshape(-1, d)
-        if b_leaf is not None and proj_ok(x2, w):
+        opts = opts or DEFAULT_OPTIONS
+        if b_leaf is not None and opts.use_proj and proj_ok(x2, w):
             qkv = proj_forward(x2, w, 3 * d).reshape(B, T, 3 * d)        # streamed-weight projection (dmt_proj)
         else:
             qkv = linear_forward(x2, w, b_leaf).reshape(B, T, 3 * d)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         out = torch.empty((B, T, d), dtype=x.dtype, device=x.device)
-        ctx.P = attn_core_fwd(q, k, v, lens, lens, x, out, H, drop_seed, drop_keep)
+        ctx.P = attn_core_fwd(q, k, v, lens, lens, x, out, H, drop_seed, drop_keep, opts)
         ctx.save_for_backward(x2, qkv, lens)
         ctx.w, ctx.leaves, ctx.H, ctx.drop = w, (w_leaf, b_leaf), H, (int(drop_seed), float(drop_keep))
         return out
@@ -1010,7 +1034,7 @@ class SelfAttnBlockFn(torch.autograd.Function):
         dz = dqkv.reshape(-1, d3)
         dx = linear_backward_input(dz, ctx.w, resid=dout.reshape(-1, d)).reshape(B, T, d) if ctx.needs_input_grad[0] else None
         dW, db = linear_backward_weight(x2, dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
-        return dx, dW, db, None, None, None, None, None
+        return dx, dW, db, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ fused self-attention block
@@ -1413,5 +1437,5 @@ def colsum(x2d, scale=1.0, out=None):
     rows, cols = x2d.shape
     if out is None:
         out = torch.zeros((cols,), dtype=F32, device=x2d.device)
-    L.call("dmt_colsum", dt_code(x2d.dtype), rows, cols, p(x2d), _row_major2d(x2d, "x"), float(scale), p(out), stream_ptr())
+    L.call("dmt_colsum", dt_code(x2d.dtype), rows, cols, p(x2d), _row_major2d(x2d, "x"), float(scale), p(out), 1 if DETERMINISTIC else 0, stream_ptr())
     return out

@@ -45,15 +45,14 @@ class Trainer:
         self.device = torch.device(device)
         if attn_dtype not in (None, "bf16", "fp8"):
             raise ValueError("attn_dtype must be None, 'bf16' or 'fp8'")
-        if attn_dtype is not None:
-            # BASELINE configs[4]: the long-sequence (64 < T <= 256) attention forward multiplies in OCP e4m3 (process-wide switch)
-            ops.ATTN_MMA_FP8 = attn_dtype == "fp8"
         if table_layout not in ("replicated", "sharded"):
             raise ValueError("table_layout must be 'replicated' or 'sharded'")
         self.table_layout = table_layout
         shard = parallel.world() if table_layout == "sharded" else None
         self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init, table_shard=shard)
         self.engine = DMTEngine(spec, self.store)
+        # BASELINE configs[4]: the long-sequence (64 < T <= 256) attention forward of THIS trainer multiplies in OCP e4m3
+        self.engine.kopts = ops.KernelOptions(attn_mma_fp8=(attn_dtype == "fp8"))
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
         # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in

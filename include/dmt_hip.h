@@ -9,7 +9,8 @@
  * Conventions
  *   - plain C, POD arguments only; every pointer is a DEVICE pointer unless named h_*;
  *   - the caller owns every buffer (incl. workspaces); the library allocates nothing, keeps no global
- *     mutable state except the thread-local error string, never synchronises, and launches only on
+ *     mutable state except the thread-local error string (and the off-by-default diagnostic launch-route
+ *     counters of dmt_route_trace), never synchronises, and launches only on
  *     the `stream` argument (a hipStream_t passed as void*);
  *   - return 0 on success, <0 on error (message: dmt_last_error()); no C++ exception crosses the ABI;
  *   - dtype codes: DMT_F32 = 0, DMT_BF16 = 1.  Accumulation is always fp32.  Parameters that are
@@ -44,6 +45,13 @@ const char* dmt_build_arch(void);
 /* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
  * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc, 10 mhsa_desc (lets a binding verify its struct layout). */
 int dmt_struct_size(int which);
+/* Launch-route trace (diagnostic, off by default).  dmt_route_trace(1) clears the counters and starts counting every successful launch
+ * under its route label (the name of the kernel variant an entry point dispatched to, e.g. "dmt_attn_fwd(mfma, coalesced)",
+ * "dmt_proj", "dmt_chain2", "dmt_wgrad320", "dmt_q1mem_fwd"); dmt_route_trace(0) stops.  dmt_route_count(label) -> launches counted
+ * under exactly that label; dmt_route_dump writes "label=count" lines.  Used by the parity tests to state which kernels they covered. */
+int dmt_route_trace(int32_t on);
+int64_t dmt_route_count(const char* label);
+int dmt_route_dump(char* buf, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Embedding gather + concat + mean-pool (forward).
@@ -155,16 +163,15 @@ int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_k
  * The slices slots[entry_base[f] ...] are the idx / idx_seq columns of dmt_gather_feature in its row-cache form.                  */
 int dmt_entry_slots(const dmt_embgrad_desc* d, const uint32_t* keys_sorted, const uint32_t* vals_sorted, const int32_t* seg,
                     const int32_t* slot_of_row, int64_t n, int32_t* slots, void* stream);
-/* Deterministic mode (process-wide switch).  By default partial sums that meet in one output element are combined with fp32
- * atomics -- their order, hence the last bits, depends on scheduling.  With the switch on, the segmented reductions
- * (dmt_embgrad_reduce, dmt_rows_reduce*) route the runs that cross a 64-entry chunk through a workspace and add the pieces in chunk
- * order, column sums use one ordered pass per column; callers then also avoid split-K GEMMs and dmt_wgrad320 (both refuse).  Results
- * are bit-reproducible from run to run (tests/test_gpu_deterministic.py); they equal the default mode's to fp32 rounding.
- * det_ws / det_ws_bytes: workspace of dmt_reduce_det_ws_bytes(n, max_dim) bytes, 16-byte aligned; ignored (may be NULL) when the
- * switch is off.  The reference's counterpart is TF's own non-deterministic unsorted_segment_sum / atomics on GPU; on CPU (the
- * reference run: run_dnn.py:45-80) the order is fixed. */
-int dmt_set_deterministic(int32_t on);
-int dmt_get_deterministic(void);
+/* Ordered (bit-reproducible) reductions are chosen PER CALL; the library keeps no mode.  By default partial sums that meet in one
+ * output element are combined with fp32 atomics -- their order, hence the last bits, depends on scheduling.  The segmented reductions
+ * (dmt_embgrad_reduce, dmt_rows_reduce*) take the ordered form when the caller passes a workspace (det_ws != NULL, of
+ * dmt_reduce_det_ws_bytes(n, max_dim) bytes, 16-byte aligned): runs that cross a 64-entry chunk go through the workspace and the
+ * pieces are added in chunk order.  dmt_colsum / dmt_colsum_drop take `ordered` (one pass per column, in row order).  A caller that
+ * wants a bit-reproducible step also keeps to split_k = 1 in dmt_gemm and away from dmt_wgrad320 / dmt_heads_bwd (fp32 atomics by
+ * construction) -- cikm2020_dmt_amd/ops.py does so under ops.set_deterministic (tests/test_gpu_deterministic.py).  Results equal the
+ * default forms' to fp32 rounding.  The reference's counterpart is TF's own non-deterministic unsorted_segment_sum / atomics on GPU;
+ * on CPU (the reference run: run_dnn.py:45-80) the order is fixed. */
 uint64_t dmt_reduce_det_ws_bytes(int64_t n, int32_t max_dim);
 
 int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sorted_keys, const uint32_t* sorted_vals,
@@ -521,11 +528,11 @@ int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream);
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */
 int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t ldx, float scale, float* out,
-               void* stream);
+               int32_t ordered, void* stream);
 /* out[c] += scale * sum_r mask(r*cols + c) * x[r, c] / keep  with the dmt_dropout counter mask (flat index r*cols + c, x must be
  * dense: ldx == cols): the gradient of the learned positions behind the dropout fused into dmt_gather_fwd. */
 int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, float scale, float* out, uint32_t seed,
-                    float keep_prob, void* stream);
+                    float keep_prob, int32_t ordered, void* stream);
 
 /* Streaming 200-threshold confusion histogram behind tf.metrics.auc (run_dnn.py:228-241):
  * hist[(label?1:0) * (n_thr+1) + #thresholds below pred] += 1 (int64).                                */
@@ -580,7 +587,7 @@ int dmt_mmoe_experts_bwd(const dmt_mmoe_desc* d, void* stream);
  *   forward : logits [T+1][B] fp32 (task logits, then y_bias) + saved activations h_fc, h0, h1 (h0 / h1 after dropout).
  *   backward: dlogits [T+1][B] fp32 -> dmix, dzb, the pre-activation gradients dz_fc / dz0 / dz1 (operands of the weight-gradient
  *             GEMMs of the hidden layers), and the weight / bias gradients of the three 1-wide output layers ACCUMULATED into
- *             g_out_w / g_out_b / g_bias_w2 / g_bias_b2 (fp32 atomics; refuses in deterministic mode).
+ *             g_out_w / g_out_b / g_bias_w2 / g_bias_b2 (fp32 atomics: not for a bit-reproducible step).
  * Weights: bf16 plain shadows [K][N] row-major, fp32 biases.  Dropout: counter mask, index row * width + unit.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {

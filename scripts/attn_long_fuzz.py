@@ -7,12 +7,12 @@ import numpy as np, torch
 from cikm2020_dmt_amd import ops
 
 def run(pq, pkv, x, ql, kl, w, H, drop, fused, fp8=False):
-    ops.ATTN_LONG_FUSED, ops.ATTN_MMA_FP8 = fused, fp8
     d = x.shape[2]
     a = pq.clone().requires_grad_(True)
     b = pkv.clone().requires_grad_(True) if pkv is not None else None
     xd = x.clone().requires_grad_(True)
-    out = ops.AttnFn.apply(a, b, xd, ql, kl, H, d, pkv is None, 0x1234567 if drop else 0, 0.9 if drop else 1.0)
+    out = ops.AttnFn.apply(a, b, xd, ql, kl, H, d, pkv is None, 0x1234567 if drop else 0, 0.9 if drop else 1.0,
+                           ops.KernelOptions(attn_mma_fp8=fp8, attn_long_fused=fused))
     (out.float() * w).sum().backward()
     return out.detach().float(), [a.grad.float()] + ([b.grad.float()] if b is not None else []) + [xd.grad.float()]
 

@@ -5,7 +5,7 @@ import torch
 from cikm2020_dmt_amd import ops
 
 def run(B, Tq, Tk, H, dh, fused, drop, iters=10):
-    ops.ATTN_LONG_FUSED = fused
+    ko = ops.KernelOptions(attn_long_fused=fused)
     d = H * dh
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -20,7 +20,7 @@ def run(B, Tq, Tk, H, dh, fused, drop, iters=10):
     kl = torch.full((B,), Tk, dtype=torch.int32, device=dev)
     w = torch.randn((B, Tq, d), generator=g).to(torch.bfloat16).to(dev)
     def fwd():
-        return ops.AttnFn.apply(qkv, kv, x, ql, kl, H, d, kv is None, 1234 if drop else 0, 0.9 if drop else 1.0)
+        return ops.AttnFn.apply(qkv, kv, x, ql, kl, H, d, kv is None, 1234 if drop else 0, 0.9 if drop else 1.0, ko)
     for _ in range(2):
         out = fwd(); out.backward(w)
     torch.cuda.synchronize()

@@ -14,12 +14,6 @@ from cikm2020_dmt_amd import ops
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _restore_switches():
-    yield
-    ops.ATTN_LONG_FUSED, ops.ATTN_MMA_FP8 = True, False
-
-
 def _inputs(B, Tq, Tk, H, dh, cuda, seed=1):
     d = H * dh
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -37,12 +31,13 @@ def _inputs(B, Tq, Tk, H, dh, cuda, seed=1):
     return pq, pkv, x, ql, kl, w
 
 
-def _run(pq, pkv, x, ql, kl, w, H, cuda, drop):
+def _run(pq, pkv, x, ql, kl, w, H, cuda, drop, fused=True, fp8=False):
     d = x.shape[2]
     a = pq.to(cuda).requires_grad_(True)
     bkv = pkv.to(cuda).requires_grad_(True) if pkv is not None else None
     xd = x.to(cuda).requires_grad_(True)
-    out = ops.AttnFn.apply(a, bkv, xd, ql, kl, H, d, pkv is None, 0xC0FFEE if drop else 0, 0.9 if drop else 1.0)
+    out = ops.AttnFn.apply(a, bkv, xd, ql, kl, H, d, pkv is None, 0xC0FFEE if drop else 0, 0.9 if drop else 1.0,
+                           ops.KernelOptions(attn_mma_fp8=fp8, attn_long_fused=fused))
     (out.float() * w).sum().backward()
     grads = [a.grad.float()] + ([bkv.grad.float()] if bkv is not None else []) + [xd.grad.float()]
     return out.detach().float(), grads
@@ -57,11 +52,9 @@ def test_fused_long_kernels_match_the_unfused_form(cuda, B, Tq, Tk, H, dh, drop)
     accumulation from the same inputs and the same counter mask, so they agree to bf16 rounding of the intermediates
     (2e-2 of the largest value; a wrong mask, tile or dropout bit shows up as O(1))."""
     pq, pkv, x, ql, kl, w = _inputs(B, Tq, Tk, H, dh, cuda, seed=Tq + Tk)
-    ops.ATTN_LONG_FUSED = True
     assert ops.long_fused_ok(H, *(t.to(cuda) for t in ([pq[..., :H * dh], pq[..., :H * dh]] if pkv is None else [pq, pkv[..., :H * dh]])))
-    o1, g1 = _run(pq, pkv, x, ql, kl, w, H, cuda, drop)
-    ops.ATTN_LONG_FUSED = False
-    o0, g0 = _run(pq, pkv, x, ql, kl, w, H, cuda, drop)
+    o1, g1 = _run(pq, pkv, x, ql, kl, w, H, cuda, drop, fused=True)
+    o0, g0 = _run(pq, pkv, x, ql, kl, w, H, cuda, drop, fused=False)
     valid = (torch.arange(Tq, device=cuda)[None, :, None] < ql[:, None, None])
     eo = ((o1 - o0).abs() * valid).max().item() / (o0.abs() * valid).max().item()
     assert eo < 2e-2, eo
@@ -84,10 +77,8 @@ def test_fp8_forward_stays_within_its_tolerance_of_the_bf16_kernel(cuda, B, T, H
     them); the backward pass is the bf16 one, unchanged."""
     pq, pkv, x, ql, kl, w = _inputs(B, T, T, H, dh, cuda, seed=9)
     x = torch.zeros_like(x)          # (no residual: the bf16 rounding of attn + x would otherwise dominate the comparison)
-    ops.ATTN_MMA_FP8 = False
-    o0, g0 = _run(pq, pkv, x, ql, kl, w, H, cuda, True)
-    ops.ATTN_MMA_FP8 = True
-    o8, g8 = _run(pq, pkv, x, ql, kl, w, H, cuda, True)
+    o0, g0 = _run(pq, pkv, x, ql, kl, w, H, cuda, True, fp8=False)
+    o8, g8 = _run(pq, pkv, x, ql, kl, w, H, cuda, True, fp8=True)
     valid = (torch.arange(T, device=cuda)[None, :, None] < ql[:, None, None])
     xa = x.to(cuda).float()
     a0, a8 = (o0 - xa) * valid, (o8 - xa) * valid
@@ -140,7 +131,7 @@ def test_full_size_long_attention_properties(cuda, fp8):
       (c) the gradients of the slice (dropout ON, same counters as in the full batch need the same (b, h) -- so the slice is the
           head of the batch) are bit-identical too;
       (d) keys past k_len get no gradient; padded query rows send none to Q and K."""
-    ops.ATTN_MMA_FP8 = fp8
+    ko = ops.KernelOptions(attn_mma_fp8=fp8)
     B, T, H, dh = 8192, 200, 4, 80
     d = H * dh
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -154,7 +145,7 @@ def test_full_size_long_attention_properties(cuda, fp8):
     ones = qkv.clone()
     ones[..., 2 * d:] = 1.0
     zero_resid = torch.zeros((B, T, d), dtype=torch.bfloat16, device=cuda)
-    out = ops.AttnFn.apply(ones, None, zero_resid, lens, lens, H, d, True, 0, 1.0).float()
+    out = ops.AttnFn.apply(ones, None, zero_resid, lens, lens, H, d, True, 0, 1.0, ko).float()
     err = ((out - 1.0).abs() * valid[:, :, None]).max().item()
     assert err < (7e-2 if fp8 else 1e-2), err        # fp8: a dominant weight near 1 is rounded with relative error up to 2^-4
     del ones, out
@@ -162,10 +153,10 @@ def test_full_size_long_attention_properties(cuda, fp8):
     n = 64
     w = torch.randn((B, T, d), generator=g, dtype=torch.bfloat16).to(cuda) * valid[:, :, None]
     full = qkv.clone().requires_grad_(True)
-    o_full = ops.AttnFn.apply(full, None, zero_resid, lens, lens, H, d, True, 0xBEEF, 0.9)
+    o_full = ops.AttnFn.apply(full, None, zero_resid, lens, lens, H, d, True, 0xBEEF, 0.9, ko)
     (o_full.float() * w).sum().backward()
     part = qkv[:n].clone().requires_grad_(True)
-    o_part = ops.AttnFn.apply(part, None, zero_resid[:n], lens[:n], lens[:n], H, d, True, 0xBEEF, 0.9)
+    o_part = ops.AttnFn.apply(part, None, zero_resid[:n], lens[:n], lens[:n], H, d, True, 0xBEEF, 0.9, ko)
     (o_part.float() * w[:n]).sum().backward()
     assert torch.equal(o_full[:n], o_part)
     assert torch.equal(full.grad[:n], part.grad)

@@ -9,6 +9,7 @@ from cikm2020_dmt_amd.data_feed.synthetic import make_batch
 from cikm2020_dmt_amd.metrics import StreamingPrecisionRecall, precision_recall_reference
 from cikm2020_dmt_amd.model.inference_mlp import Inference
 from cikm2020_dmt_amd.optim import TFAdam
+from cikm2020_dmt_amd.train import Trainer
 from cikm2020_dmt_amd.variables import VariableStore
 from tests.util import small_specs
 
@@ -176,3 +177,33 @@ def test_lazy_adam_long_gaps_are_bounded_and_match_the_dense_sweep(cuda):
         big = np.abs(ya) > 1e-30
         assert (np.abs(xa - ya)[big] / np.abs(ya)[big]).max() < 1e-4
         assert np.abs(xa[~big]).max() < 1e-29
+
+
+def test_two_trainers_with_different_kernel_options_in_one_process(cuda):
+    """Kernel choices are fields of an engine (ops.KernelOptions), not process-wide switches: a Trainer(attn_dtype="fp8") and a
+    Trainer(attn_dtype="bf16") alive in the same process, used alternately, each take their own long-sequence forward kernel; so do
+    two engines that differ in the streamed-weight projection."""
+    from cikm2020_dmt_amd import _lib as L
+    from cikm2020_dmt_amd import spec as S
+    sp = dict(S.scaled_spec(S.e64_spec(), {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120}), maxlen_k=200)
+    long_feats = {grp[0][0]: 200 for grp in sp["attention_embed_pairs"][:2]}
+    inputs, mask, _ = make_batch(sp, 8, seed=3, lengths="full", seq_lens=long_feats)
+    t8 = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=1, dropout=False, attn_dtype="fp8")
+    tb = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=1, dropout=False, attn_dtype="bf16")
+    tn = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=1, dropout=False)
+    tn.engine.kopts = tn.engine.kopts.replace(use_proj=False)
+    assert t8.engine.kopts.attn_mma_fp8 and not tb.engine.kopts.attn_mma_fp8
+    outs = {}
+    for rnd in range(2):
+        for name, tr in (("fp8", t8), ("bf16", tb), ("noproj", tn)):
+            with L.route_trace() as rt:
+                loss = float(tr.forward_backward(tr.make_batch(inputs, mask)))
+                torch.cuda.synchronize()
+            f8, fb, pj = (rt.counts.get(k, 0) for k in ("dmt_attn_long_fwd(fp8)", "dmt_attn_long_fwd", "dmt_proj"))
+            assert (f8 > 0 and fb == 0) if name == "fp8" else (f8 == 0 and fb > 0), (name, rt.counts)
+            assert (pj == 0) if name == "noproj" else (pj > 0), (name, rt.counts)
+            outs.setdefault(name, []).append(loss)
+    for name, v in outs.items():
+        assert abs(v[0] - v[1]) < 1e-3 * abs(v[0]), (name, v)        # the same step twice (atomics: not bitwise)
+    assert outs["fp8"][0] != outs["bf16"][0]                          # another arithmetic
+    assert abs(outs["fp8"][0] - outs["bf16"][0]) < 5e-2 * abs(outs["bf16"][0])

@@ -1,4 +1,4 @@
-"""Deterministic mode: with dmt_set_deterministic(1) every reduction whose partial sums normally meet in fp32 atomics
+"""Deterministic mode (ops.set_deterministic): every reduction whose partial sums normally meet in fp32 atomics
 takes a fixed-order form.  Two runs of the same train steps -- at a size where hot rows span many 64-entry chunks and the weight
 gradients are split over many workgroups in the default mode -- must then agree bit for bit; and the mode changes nothing but the
 order of summation (default-mode results agree to fp32 rounding)."""
@@ -36,9 +36,7 @@ def _run(cuda, dtype, det, steps=3, B=1024):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_deterministic_mode_is_bit_reproducible(cuda, dtype):
-    assert L.load().dmt_get_deterministic() == 0
     l1, s1 = _run(cuda, dtype, True)
-    assert L.load().dmt_get_deterministic() == 1
     l2, s2 = _run(cuda, dtype, True)
     assert l1 == l2
     for k in s1:
@@ -54,23 +52,34 @@ def test_deterministic_mode_is_bit_reproducible(cuda, dtype):
     assert worst < 6.5e-3, worst
 
 
-def test_atomic_kernels_refuse_in_deterministic_mode(cuda):
-    import ctypes as C
-    ops.set_deterministic(True)
+def test_the_library_keeps_no_mode_and_the_ops_layer_avoids_the_atomic_kernels(cuda):
+    """The ordered form of a reduction is chosen per call (workspace argument / `ordered` flag): the library has no switch.  Under
+    ops.set_deterministic(True) a train step launches neither dmt_wgrad320 nor dmt_heads_bwd (fp32 atomics by construction)."""
     lib = L.load()
-    x = torch.randn((32768, 320), device=cuda).to(torch.bfloat16)
-    dz = torch.randn((32768, 256), device=cuda).to(torch.bfloat16)
-    gw = torch.zeros((320, 256), device=cuda)
-    d = L.WgradDesc()
-    d.A, d.ld_a, d.a_cols, d.B, d.ld_b, d.M, d.N, d.C, d.ldc = x.data_ptr(), 320, 320, dz.data_ptr(), 256, 32768, 256, gw.data_ptr(), 256
-    assert lib.dmt_wgrad320(C.byref(d), ops.stream_ptr()) == -3
-    with pytest.raises(L.DmtError, match="split_k"):
-        ops.gemm(x, 1, 320, dz, 256, 1, 320, 256, 32768, gw, 256, split_k=4, accumulate=True)
-    # the segmented reductions need their workspace
+    assert not hasattr(lib, "dmt_set_deterministic")
+    # a too-small workspace for the ordered form is an argument error, not a silent fall back to atomics
     keys = torch.arange(100, dtype=torch.int32, device=cuda)
     seg = torch.arange(100, dtype=torch.int32, device=cuda)
     rows = torch.randn((100, 64), device=cuda)
     out = torch.zeros((100, 64), device=cuda)
-    assert lib.dmt_rows_reduce(ops.p(keys), ops.p(keys), ops.p(seg), 100, 1000, ops.p(rows), ops.p(out), 64, None, 0, ops.stream_ptr()) == -1
+    ws = torch.empty(16, dtype=torch.uint8, device=cuda)
+    assert lib.dmt_rows_reduce(ops.p(keys), ops.p(keys), ops.p(seg), 100, 1000, ops.p(rows), ops.p(out), 64, ops.p(ws), 16, ops.stream_ptr()) == -1
     assert b"workspace" in lib.dmt_last_error()
-    torch.cuda.synchronize()
+    # ordered and atomic column sums agree to rounding; the ordered one is bit-reproducible
+    x = torch.randn((5000, 333), device=cuda)
+    outs = []
+    for ordered in (1, 1, 0):
+        o = torch.zeros(333, device=cuda)
+        L.call("dmt_colsum", L.DMT_F32, 5000, 333, ops.p(x), 333, 1.0, ops.p(o), ordered, ops.stream_ptr())
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.allclose(outs[0], outs[2], rtol=1e-4, atol=1e-3)
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120})
+    inputs, mask, _ = make_batch(sp, 400, seed=1, lengths="full")
+    for det in (True, False):
+        ops.set_deterministic(det)
+        tr = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=3, dropout=True)
+        with L.route_trace() as rt:
+            tr.train_step(tr.make_batch(inputs, mask))
+            torch.cuda.synchronize()
+        atomic = rt.counts.get("dmt_wgrad320", 0) + rt.counts.get("dmt_heads_bwd", 0)
+        assert (atomic == 0) if det else (atomic > 0), rt.counts

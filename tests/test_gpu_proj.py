@@ -53,14 +53,13 @@ def test_self_attention_block_same_with_and_without_proj(cuda):
     ops.set_deterministic(True)
     try:
         for use in (False, True):
-            ops.USE_PROJ = use
             tr = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=4, dropout=True)
+            tr.engine.kopts = tr.engine.kopts.replace(use_proj=use)
             assert len(tr.store.proj) == 3
             loss = tr.forward_backward(tr.make_batch(inputs, mask, label))
             torch.cuda.synchronize()
             res.append((float(loss), tr.store.grads.clone()))
     finally:
-        ops.USE_PROJ = True
         ops.set_deterministic(False)
     (l0, g0), (l1, g1) = res
     # same bf16 operands, same fp32 accumulation up to its order: the q | k | v values differ by rounding-level amounts at most
