@@ -218,28 +218,31 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
 __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, int* __restrict__ last_step,
                                                          const float* __restrict__ state, const float* __restrict__ lr_hist,
-                                                         float b1, float b2, float eps) {
+                                                         float b1, float b2, float eps, long long n_local) {
   const int lane = threadIdx.x & 63;
-  const long long lsi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // local row index (= the global row when not sharded)
-  const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
-  if (row >= tm.row_base[tm.n_tables]) return;
-  // (a sharded layout pads every table to a multiple of shard_w rows; the padding rows have storage -- zeros -- and are skipped below)
   const int step = reinterpret_cast<const int*>(state)[3];
-  const int last = last_step[lsi];
-  if (last >= step) return;
-  const int t = find_table(tm, (int)row);
-  const int dim = tm.dim[t];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
-  for (int j = lane; j < dim; j += 64) {
-    const long long off = tm_elem(tm, t, row, dim) + j;
-    float pv = p[off], mv = m[off], vv = v[off];
-    if (mv != 0.f || vv != 0.f) {
-      catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
-      p[off] = pv; m[off] = mv; v[off] = vv;
+  // grid-stride over the local rows: a 100 M-row table (BASELINE configs[3]) has 25 M four-row blocks = 6.4e9 threads, more than one
+  // launch may carry (2^32); tests/test_gpu_configs.py::test_config3_* caught the one-block-per-four-rows form skipping rows
+  for (long long lsi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); lsi < n_local; lsi += (long long)gridDim.x * 4) {   // local row (= global row when not sharded)
+    const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
+    if (row >= tm.row_base[tm.n_tables]) break;
+    // (a sharded layout pads every table to a multiple of shard_w rows; the padding rows have storage -- zeros -- and are skipped below)
+    const int last = last_step[lsi];
+    if (last >= step) continue;
+    const int t = find_table(tm, (int)row);
+    const int dim = tm.dim[t];
+    for (int j = lane; j < dim; j += 64) {
+      const long long off = tm_elem(tm, t, row, dim) + j;
+      float pv = p[off], mv = m[off], vv = v[off];
+      if (mv != 0.f || vv != 0.f) {
+        catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
+        p[off] = pv; m[off] = mv; v[off] = vv;
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) last_step[lsi] = step;
   }
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) last_step[lsi] = step;
 }
 
 }  // namespace
@@ -323,9 +326,10 @@ extern "C" int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, 
                                    const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
   DMT_CHECK_ARG(tm && p && m && v && last_step && state && lr_hist, "dmt_adam_flush_rows: null argument");
   const long long rows = cdiv64(tm->row_base[tm->n_tables], tm->shard_w > 1 ? tm->shard_w : 1);
-  const unsigned nb = (unsigned)cdiv64(rows, 4);
+  const long long nb_all = cdiv64(rows, 4);
+  const unsigned nb = (unsigned)(nb_all < (1ll << 20) ? nb_all : (1ll << 20));          // (2^20 blocks x 256 threads < 2^32 threads per launch)
   hipLaunchKernelGGL(adam_flush_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, state, lr_hist, beta1,
-                     beta2, eps);
+                     beta2, eps, rows);
   DMT_CHECK_LAUNCH("dmt_adam_flush_rows");
   return DMT_OK;
 }

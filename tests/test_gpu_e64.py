@@ -194,9 +194,10 @@ def test_e64_bf16_three_train_steps_match_oracle(cuda, monkeypatch):
         assert dev.max() <= 2 * lr3 * 1.05, (k, float(dev.max()))
         if sel.sum() >= 16:
             stats.append((float(np.median(dev[sel])), float((dev[sel] > 0.25 * lr3).mean()), k))
-        untouched = moved == 0
-        if untouched.any():
-            assert float(dev[untouched].max()) < 1e-6, k          # lazy rows: untouched rows equal the initial values
+        if k in tr.store.tables:
+            untouched = moved.max(axis=1) == 0
+            if untouched.any():
+                assert float(dev[untouched].max()) < 1e-6, k      # lazy Adam: rows no batch read equal their initial values
     print("E64 bf16 3 steps: worst median deviation:", sorted(stats, reverse=True)[:3], "| worst fraction beyond lr*0.75:",
           sorted(stats, key=lambda s: -s[1])[:3])
     assert max(s[0] for s in stats) < 0.05 * lr3, sorted(stats, reverse=True)[:3]

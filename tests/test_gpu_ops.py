@@ -205,7 +205,7 @@ def test_colsum_drop_equals_column_sum_of_dropped_gradient(cuda, rows, cols, dty
     mask = (dropped != 0) | (x == 0)
     want = (x.double() * mask / keep).sum(0)
     out = torch.zeros(cols, dtype=torch.float32, device=cuda)
-    L.call("dmt_colsum_drop", ops.dt_code(dtype), rows, cols, ops.p(x), 1.0, ops.p(out), seed, keep, ops.stream_ptr())
+    L.call("dmt_colsum_drop", ops.dt_code(dtype), rows, cols, ops.p(x), 1.0, ops.p(out), seed, keep, 0, ops.stream_ptr())
     torch.cuda.synchronize()
     assert 0.85 < mask.float().mean().item() < 0.95
     np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-4)
