@@ -34,17 +34,54 @@ def step_of(ckpt_name: str) -> int:
     return int(base.split("-")[1])
 
 
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def _write_npz(path: str, arrays: Dict[str, np.ndarray], tag: str):
+    tmp = "%s.tmp-%s.npz" % (path, tag)            # (one temporary per writer: two ranks never truncate each other's file)
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+def shard_name(step: int, rank: int, world: int) -> str:
+    return "%s.shard-%05d-of-%05d" % (checkpoint_name(step), rank, world)
+
+
 def save(trainer, model_path: str, step: Optional[int] = None) -> str:
-    """saver.save(sess, model_path + 'model.ckpt', global_step=step); create_file(model_path, 'step-%d.model.DONE' % step)."""
+    """saver.save(sess, model_path + 'model.ckpt', global_step=step); create_file(model_path, 'step-%d.model.DONE' % step).
+    More than one rank: every rank calls it (it ends in a barrier).  Replicated tables: rank 0 writes the one file (every replica
+    holds the same values).  Row-sharded tables: NO table is gathered -- rank r writes the rows it owns to
+    `model.ckpt-N.shard-r-of-W.npz` (local row l = global row l * W + r), rank 0 writes the dense variables and the shard count to
+    `model.ckpt-N.npz`; the DONE marker appears after all shard files exist."""
     step = trainer.opt.global_step if step is None else int(step)
+    dist, rank, world = _dist()
     os.makedirs(model_path, exist_ok=True)
     trainer.opt.flush_tables()
-    state = trainer.store.state_dict()
+    store = trainer.store
     path = os.path.join(model_path, checkpoint_name(step) + ".npz")
-    tmp = path + ".tmp.npz"
-    np.savez(tmp, **{PREFIX + k: np.asarray(v, dtype=np.float32) for k, v in state.items()})
-    os.replace(tmp, path)
-    open(os.path.join(model_path, "step-%d.model.DONE" % step), "w").close()
+    sharded = store.shard is not None and store.shard[1] > 1
+    if sharded:
+        r, W = store.shard
+        mine = {PREFIX + name: store.table[name].detach().float().cpu().numpy() for name in store.tables}
+        _write_npz(os.path.join(model_path, shard_name(step, r, W) + ".npz"), mine, "r%d" % r)
+    if rank == 0:
+        arrays = {PREFIX + k: v for k, v in store.dense_state_dict().items()}
+        if sharded:
+            arrays["__table_shards__"] = np.array([store.shard[1]], dtype=np.int64)
+        else:
+            for name in store.tables:
+                arrays[PREFIX + name] = store.table[name].detach().float().cpu().numpy()[: store.tables[name].shape[0]]
+        _write_npz(path, arrays, "r0")
+    if dist is not None and world > 1:
+        dist.barrier()
+    if rank == 0:
+        open(os.path.join(model_path, "step-%d.model.DONE" % step), "w").close()
+    if dist is not None and world > 1:
+        dist.barrier()
     return path
 
 
@@ -59,28 +96,77 @@ def latest(model_path: str) -> Optional[str]:
     return checkpoint_name(best) if best >= 0 else None
 
 
-def restore_arrays(trainer, arrays: Dict[str, np.ndarray], step: int = 0):
-    """Load variables given under their graph names (with or without the 'DnnModel/' scope) and restart the optimizer at `step`."""
-    state = {}
-    for k, v in arrays.items():
-        state[k[len(PREFIX):] if k.startswith(PREFIX) else k] = np.asarray(v)
-    have = trainer.store.state_dict()
-    missing = sorted(set(have) - set(state))
+def _expected_shapes(store) -> Dict[str, tuple]:
+    """Variable name -> shape, from the store's declarations (no tensor is touched: with row-sharded tables a state_dict() would
+    gather every whole table onto every rank)."""
+    shapes = {name: tuple(v.shape) for name, v in store.views.items()}
+    shapes.update({name: tuple(info.shape) for name, info in store.tables.items()})
+    return shapes
+
+
+def restore_arrays(trainer, arrays, step: int = 0, table_loader=None):
+    """Load variables given under their graph names (with or without the 'DnnModel/' scope) and restart the optimizer at `step`.
+    arrays: a mapping name -> array (an open .npz works: members are read one at a time).  table_loader(name) -> full [rows, dim]
+    array for tables the mapping does not hold (sharded checkpoints)."""
+    names = {(k[len(PREFIX):] if k.startswith(PREFIX) else k): k for k in arrays.keys() if not k.startswith("__")}
+    want = _expected_shapes(trainer.store)
+    missing = sorted(n for n in want if n not in names and not (table_loader is not None and n in trainer.store.tables))
     if missing:
         raise KeyError("checkpoint lacks %d variable(s), e.g. %s" % (len(missing), missing[:3]))
-    for k in have:
-        if tuple(state[k].shape) != tuple(have[k].shape):
-            raise ValueError("variable %s: checkpoint shape %s, model shape %s" % (k, state[k].shape, have[k].shape))
-    trainer.store.load_state({k: state[k] for k in have})
+    for n, shp in want.items():          # one variable at a time: the host never holds more than one table
+        a = np.asarray(arrays[names[n]]) if n in names else np.asarray(table_loader(n))
+        if tuple(a.shape) != shp:
+            raise ValueError("variable %s: checkpoint shape %s, model shape %s" % (n, a.shape, shp))
+        trainer.store.load_state({n: a}, refresh=False)
+    trainer.store.refresh_shadows()
     trainer.opt.reset_slots(step)
 
 
 def restore(trainer, model_path: str, ckpt_name: Optional[str] = None) -> int:
-    """saver.restore(sess, model_path + ckpt_name) (run_dnn.py:300-304); returns the step the run resumes at."""
+    """saver.restore(sess, model_path + ckpt_name) (run_dnn.py:300-304); returns the step the run resumes at.  A checkpoint written
+    with row-sharded tables restores into any layout / rank count: same shard count -> every rank reads its own shard file; otherwise
+    each table is re-assembled on the host from the shard files (one table at a time) and re-sliced by load_state."""
     ckpt_name = ckpt_name or latest(model_path)
     if ckpt_name is None:
         raise FileNotFoundError("no finished checkpoint under %s" % model_path)
-    fn = os.path.join(model_path, ckpt_name if ckpt_name.endswith(".npz") else ckpt_name + ".npz")
-    with np.load(fn) as z:
-        restore_arrays(trainer, {k: z[k] for k in z.files}, step_of(ckpt_name))
+    base = ckpt_name[:-4] if ckpt_name.endswith(".npz") else ckpt_name
+    step = step_of(base)
+    store = trainer.store
+    with np.load(os.path.join(model_path, base + ".npz")) as z:
+        if "__table_shards__" not in z.files:
+            restore_arrays(trainer, z, step)
+            return trainer.opt.global_step
+        Wf = int(z["__table_shards__"][0])
+        files = [os.path.join(model_path, "%s.shard-%05d-of-%05d.npz" % (base, r, Wf)) for r in range(Wf)]
+        if store.shard is not None and store.shard[1] == Wf:
+            # the same sharding: this rank's rows, as they lie
+            dense = {k: z[k] for k in z.files if not k.startswith("__")}
+            want = _expected_shapes(store)
+            for k, a in dense.items():
+                n = k[len(PREFIX):] if k.startswith(PREFIX) else k
+                if n in store.views:
+                    if tuple(a.shape) != want[n]:
+                        raise ValueError("variable %s: checkpoint shape %s, model shape %s" % (n, a.shape, want[n]))
+                    store.load_state({n: a}, refresh=False)
+            with np.load(files[store.shard[0]]) as zs:
+                for name in store.tables:
+                    loc = zs[PREFIX + name]
+                    if tuple(loc.shape) != tuple(store.table[name].shape):
+                        raise ValueError("table %s: shard shape %s, this rank holds %s" % (name, loc.shape, tuple(store.table[name].shape)))
+                    store.load_local_rows(name, loc)
+            store.refresh_shadows()
+            trainer.opt.reset_slots(step)
+            return trainer.opt.global_step
+
+        def assemble(name):
+            rows, dim = store.tables[name].shape
+            full = np.empty((rows, dim), dtype=np.float32)
+            for r in range(Wf):
+                with np.load(files[r]) as zs:
+                    part = zs[PREFIX + name]
+                    n_r = len(range(r, rows, Wf))
+                    full[r::Wf] = part[:n_r]
+            return full
+
+        restore_arrays(trainer, z, step, table_loader=assemble)
     return trainer.opt.global_step

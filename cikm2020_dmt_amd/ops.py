@@ -202,13 +202,39 @@ WGRAD320_MIN_ROWS = 16384
 # the gradient-row exchange of a data-parallel step (train_step), or beside the id-bound tail of a one-GPU step (DMT_SPARSE_LANE).
 # (Tried and dropped: side streams per compute stream for them -- 1 %, and their queues collide with the lanes, streams.py.)
 _deferred = [None]      # list of closures while a Trainer step collects its long-row weight gradients (begin_deferred_wgrads)
+_deferred_limit = [None]  # only gradients that end before this element offset of the gradient arena may be collected
 
 
-def begin_deferred_wgrads():
+def begin_deferred_wgrads(limit=None):
     """From now on the long-row weight gradients of backward are COLLECTED instead of launched: nothing in backward reads them, so
     the dX chain -- the critical path to the embedding gradients -- runs through first; run_deferred_wgrads() launches them afterwards
-    (Trainer.train_step: beside the id-bound tail of the step, which runs on the index lane meanwhile)."""
+    (Trainer.train_step: beside the id-bound tail of the step, which runs on the index lane meanwhile).
+    limit: element offset into the flat gradient arena.  In a data-parallel step the arena's tail [limit:] (MMoE, towers, bias tower)
+    is all-reduced from a hook DURING backward (Trainer.forward_backward): a gradient of that region must be complete when the hook
+    fires, so only gradients that lie entirely before `limit` (the Transformers') are collected; the others run in place."""
     _deferred[0] = []
+    _deferred_limit[0] = None if limit is None else int(limit)
+
+
+def reset_deferred_wgrads():
+    """Drop whatever a step that did not finish left collected (an exception between backward and run_deferred_wgrads)."""
+    _deferred[0] = None
+    _deferred_limit[0] = None
+
+
+def _may_defer(M, *grad_views):
+    if _deferred[0] is None or M < WGRAD320_MIN_ROWS:
+        return False
+    lim = _deferred_limit[0]
+    if lim is None:
+        return True
+    for g in grad_views:
+        if g is None:
+            continue
+        last = g.storage_offset() + sum((n - 1) * st for n, st in zip(g.shape, g.stride())) + 1 if g.numel() else g.storage_offset()
+        if last > lim:
+            return False
+    return True
 
 
 def run_deferred_wgrads(upto=None):
@@ -221,6 +247,7 @@ def run_deferred_wgrads(upto=None):
         now, _deferred[0] = todo[:upto], todo[upto:]
     else:
         now, _deferred[0] = todo, None
+        _deferred_limit[0] = None
     for fn in now:
         fn()
     return len(now)
@@ -275,7 +302,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
             and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
             and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
         # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block
-        if _deferred[0] is not None:
+        if _may_defer(M, gw, gb if want_bias else None):
             _deferred[0].append(lambda: _deferred_wgrad320(x, dz, gw, gb if want_bias else None, K == 320))
             return None, None
         if K == 320:
@@ -284,7 +311,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
             wgrad320(dz, x, gw, True, gb if want_bias else None, 2)
         return None, None
     if gw is not None and (gb is not None or not want_bias):
-        if _deferred[0] is not None and M >= WGRAD320_MIN_ROWS:
+        if _may_defer(M, gw, gb):
             def _later(x=x, dz=dz, gw=gw, gb=gb):
                 cur = torch.cuda.current_stream(x.device)
                 x.record_stream(cur)

@@ -292,6 +292,8 @@ class Trainer:
     def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False):
         """join=False (one-GPU train_step with the sparse lane): backward only collects the long-row weight gradients and leaves the
         embedding-gradient tail to the caller.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
+        ops.reset_deferred_wgrads()       # (closures a step that raised half-way left behind reference that step's tensors)
+        self.engine._pending_sparse = None
         self.sync_rows(batch)
         self.store.zero_grad()
         rank, _W = parallel.world()
@@ -301,14 +303,18 @@ class Trainer:
         if prefetch is not None and prefetch is not batch:
             self.prefetch(prefetch)
         defer = (not join) and self.sparse_lane and self.device.type == "cuda" and self._index_stream() is not None
+        dp = _W > 1 or (self.force_dp and parallel.dist.is_initialized())
         if defer:
             ops.begin_deferred_wgrads()
             self.engine.defer_sparse = True
         elif defer_wgrads:
-            # (data-parallel step: the caller launches them while the gradient rows are on the links -- train_step)
-            ops.begin_deferred_wgrads()
+            # (data-parallel step: the caller launches them while the gradient rows are on the links -- train_step.)  The arena's tail
+            # is all-reduced from the dL/dz hook below while backward is still running: only weight gradients of the head (the
+            # Transformers) may be collected -- with a per-rank batch >= WGRAD320_MIN_ROWS the MMoE layer 0 and the towers' hidden
+            # layers qualify by their row count, and collecting them would leave them out of the all-reduce
+            ops.begin_deferred_wgrads(limit=self.store.leaves["mmoe_layers/l0_cat_weights"].offset if dp else None)
         self._early = None
-        if _W > 1 or (self.force_dp and parallel.dist.is_initialized()):
+        if dp:
             # The gradient arena is laid out [Transformers | MMoE, towers, bias tower].  Everything behind the MMoE input z is
             # final the moment dL/dz exists (91 % of the dense parameters): its all-reduce runs on the collective's own stream
             # while the three Transformer backward passes are still computing (run_dnn.py:45-80 average_gradients).
@@ -323,7 +329,7 @@ class Trainer:
         try:
             loss.backward()
         except BaseException:
-            ops._deferred[0] = None
+            ops.reset_deferred_wgrads()
             self.engine._pending_sparse = None
             raise
         finally:
@@ -411,6 +417,15 @@ class Trainer:
         return (uniq2, n_uniq2, out_rows, capm)
 
     def train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):
+        try:
+            return self._train_step(batch, prefetch)
+        except BaseException:
+            # (e.g. a collective error between backward and the optimizer: the collected weight gradients must not leak into the next step)
+            ops.reset_deferred_wgrads()
+            self.engine._pending_sparse = None
+            raise
+
+    def _train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):
         rank, W = parallel.world()
         dp = W > 1 or (self.force_dp and parallel.dist.is_initialized())
         plan_dp = dp and self.dp_exchange == "owner" and self.overlap_wgrads

@@ -285,7 +285,16 @@ class VariableStore:
             g.manual_seed(seed * 1000003 + 17 * i + (self.shard[0] if self.shard is not None else 0))
             self.table[tf_name].uniform_(-lim, lim, generator=g)
 
-    def load_state(self, state: Dict[str, np.ndarray]):
+    def load_local_rows(self, tf_name: str, local_rows):
+        """Row-sharded layout: this rank's rows of one table as they lie in its shard (local row l = global row l * W + rank)."""
+        with torch.no_grad():
+            self.table[tf_name].copy_(torch.as_tensor(np.asarray(local_rows, dtype=np.float32)).to(self.device))
+
+    def dense_state_dict(self) -> Dict[str, np.ndarray]:
+        """Every variable that is not an embedding table (name -> fp32 array).  No collective."""
+        return {tf_name: self.leaf[v.leaf].detach()[v.index].float().cpu().numpy().copy() for tf_name, v in self.views.items()}
+
+    def load_state(self, state: Dict[str, np.ndarray], refresh: bool = True):
         """state: TF variable name (Appendix B, no 'DnnModel/' prefix) -> array."""
         with torch.no_grad():
             for tf_name, arr in state.items():
@@ -303,9 +312,12 @@ class VariableStore:
                         self.table[tf_name].copy_(a.to(self.device))
                 else:
                     raise KeyError("unknown variable %s" % tf_name)
-        self.refresh_shadows()
+        if refresh:
+            self.refresh_shadows()
 
     def state_dict(self) -> Dict[str, np.ndarray]:
+        """Every variable as a host array.  Row-sharded layout: a COLLECTIVE that gathers every whole table onto every rank (tests and
+        small tables only -- checkpoint.save / restore never call it: they move shards)."""
         out = {}
         for tf_name, v in self.views.items():
             out[tf_name] = self.leaf[v.leaf].detach()[v.index].float().cpu().numpy().copy()
@@ -323,14 +335,17 @@ class VariableStore:
         rows, dim = self.tables[tf_name].shape
         if W == 1 or not (dist.is_available() and dist.is_initialized()):
             return t[:rows]
-        parts = [torch.empty_like(t) for _ in range(W)]
+        # gathered and interleaved on the HOST (a device-side stack of W parts would hold ~2x the whole table in HBM, which is what
+        # sharding is there to avoid): local row l of rank r is global row l * W + r
         if dist.get_backend() != "nccl" and t.is_cuda:
             cp = [torch.empty(t.shape, dtype=t.dtype) for _ in range(W)]
             dist.all_gather(cp, t.cpu())
-            parts = [c.to(t.device) for c in cp]
         else:
+            parts = [torch.empty_like(t) for _ in range(W)]
             dist.all_gather(parts, t.contiguous())
-        full = torch.stack(parts, dim=1).reshape(-1, dim)      # local row l of rank r is global row l * W + r
+            cp = [c.cpu() for c in parts]
+            del parts
+        full = torch.stack(cp, dim=1).reshape(-1, dim)
         return full[:rows]
 
     def grad_dict(self) -> Dict[str, np.ndarray]:

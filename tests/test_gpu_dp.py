@@ -21,9 +21,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
+def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner", wgrad_min_rows=None):
     import torch.distributed as dist
+    from cikm2020_dmt_amd import ops as _ops
     from cikm2020_dmt_amd.train import Trainer
+    if wgrad_min_rows is not None:
+        _ops.WGRAD320_MIN_ROWS = wgrad_min_rows          # every weight gradient with M >= this many rows counts as "long-row"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,12 +55,16 @@ def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner"):
     dist.destroy_process_group()
 
 
-def test_two_rank_train_steps_match_oracle(cuda):
+@pytest.mark.parametrize("wgrad_min_rows", [None, 4])
+def test_two_rank_train_steps_match_oracle(cuda, wgrad_min_rows):
+    """wgrad_min_rows = 4: with a per-rank batch of 6 EVERY weight gradient of the step counts as long-row (as the MMoE layer 0 and the
+    towers' hidden layers do at a per-rank batch >= 16384): those of the arena's tail must still be complete when the early
+    all-reduce fires from the dL/dz hook (round-2 advice: they were collected, missed the all-reduce, and the replicas diverged)."""
     world, steps = 2, 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps, False, "owner", wgrad_min_rows)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])

@@ -78,8 +78,9 @@ def test_model_step_with_and_without_the_raw_memory_decoders(cuda):
         loss = tr.forward_backward(tr.make_batch(inputs, mask))
         out.append((float(loss), tr.store.grads.clone()))
     # a 0.5 % change of the decoder output (bf16 re-association) flips relu units of the decoder FFN; with 40 rows that shows in the
-    # gradients: the forms agree to a few per cent of the gradient norm here, and each agrees with the fp64 oracle within the bf16
-    # tolerances of tests/test_gpu_model.py (which run with this path on)
+    # gradients: the forms agree to a few per cent of the gradient norm here.  The comparison with the fp64 ORACLE -- of the raw-memory
+    # kernels directly (forward + every gradient) and of the whole E64 model with this path on -- is tests/test_gpu_e64.py
+    # (tests/test_gpu_model.py runs at reference dims, where this path is not dispatched)
     assert abs(out[0][0] - out[1][0]) < 5e-3 * abs(out[1][0]) + 1e-3
     rel = ((out[0][1] - out[1][1]).norm() / out[1][1].norm()).item()
     assert rel < 0.15, rel
