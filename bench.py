@@ -44,6 +44,11 @@ def main():
     ap.add_argument("--shard-tables", action="store_true", help="BASELINE configs[3]: row-sharded embedding tables (rank r holds rows id %% W == r; "
                     "all-to-all id / row / gradient-row exchange, owner-only Adam) instead of one replica per GPU")
     ap.add_argument("--sku-rows", type=int, default=0, help="SKU vocabulary (default: the reference's 5 M); configs[3] quotes 100000000")
+    ap.add_argument("--fresh-batches", type=int, default=64, help="distinct resident batches the steps cycle through (a row's gap between two reads "
+                    "is then the law's own up to this many steps; 4 was round 2's setting: every touched row at most 4 steps stale)")
+    ap.add_argument("--age-tables", type=int, default=100000, help="start the run as if this many steps had been trained: per-row last-touch ages drawn "
+                    "from the id law's inter-arrival distribution, Adam slots non-zero -- the lazy Adam's replay then does its steady-state work "
+                    "from the first step (0: fresh tables, nothing to replay)")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-warmup", type=int, default=5)
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -97,12 +102,13 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp,
                  table_layout="sharded" if args.shard_tables else "replicated", attn_dtype=args.attn_dtype)
-    nb = 4
-    batches = []
-    for i in range(nb):
-        inputs, mask, label = make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law, seq_lens=seq_lens)
-        batches.append(tr.make_batch(inputs, mask, label))
-    del inputs
+    nb = max(2, args.fresh_batches)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:      # (numpy releases the GIL: ~0.15 s per batch on 8 threads)
+        raw = list(ex.map(lambda i: make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law, seq_lens=seq_lens), range(nb)))
+    batches = [tr.make_batch(inputs, mask, label) for (inputs, mask, label) in raw]
+    del raw
+    age_info = age_tables(tr, sp, args, seq_lens) if args.age_tables > 0 else None
 
     def barrier():
         if world > 1:
@@ -119,12 +125,14 @@ def main():
         step(i)
     barrier()
     ops.PROFILE = {}
+    tr.diag = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    diag, tr.diag = tr.diag, None
     # the same kernels with the chip to themselves: a few extra steps (outside the timed region) with the sequences' streams serialised
     prof_x, steps_x = None, 4
     if tr.engine.seq_streams:
@@ -198,21 +206,30 @@ def main():
                      "in_step": in_step})
     fams.sort(key=lambda f: -f["time_share"])
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process (rocprofv3 wraps it); the committed
-    # measurement of the same command is quoted (profiles/r02_traffic.json, made by scripts/pmc_traffic.sh: separate --pmc passes,
+    # measurement of the same command is quoted (profiles/r03_traffic.json, made by scripts/pmc_traffic.sh: separate --pmc passes,
     # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
-    tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    default_cfg = args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and not args.shard_tables and not args.sku_rows
-    tj = {}
+    tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    default_cfg = (args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and not args.shard_tables and not args.sku_rows
+                   and args.fresh_batches == 64 and args.age_tables == 100000)
+    tj, traffic_stale = {}, None
     if default_cfg and os.path.exists(tfile):
         try:
-            tj = json.load(open(tfile)).get(args.law, {})
+            tall = json.load(open(tfile))
+            # the counters describe the kernels they were collected from: a traffic file made from other kernel sources is not quoted
+            if tall.get("kernel_source_sha") == kernel_source_sha():
+                tj = tall.get(args.law, {})
+            else:
+                traffic_stale = "profiles/r03_traffic.json was collected from other kernel sources (sha %s, now %s): not quoted" % (
+                    str(tall.get("kernel_source_sha"))[:12], kernel_source_sha()[:12])
         except Exception:
             tj = {}
     for f in fams:
         t = tj.get(f["key"])
+        if traffic_stale:
+            f["traffic_source"] = traffic_stale
         if t:
             f["traffic"] = int(t["hbm_bytes_per_step"] / max(f["launches_per_step"], 1e-9))      # per launch as counted here
-            f["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % t["launches"]
+            f["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % t["launches"]
     # `roofline` names ONE kernel (its rocprofv3 row must agree): the single-kernel family with the largest share of the step; the
     # dmt_gemm family spans three kernels and is listed with the others
     single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts", "proj")] or fams
@@ -227,20 +244,23 @@ def main():
     tg = tj.get("gather_fwd")
     if tg:
         gather["traffic"] = int(tg["hbm_bytes_per_step"] / max(ga_per_step, 1e-9))   # one dmt_gather_fwd call = its group kernels
-        gather["traffic_source"] = "profiles/r02_traffic.json (same method; the Zipf head is served by L2 / Infinity Cache, uniform ids are not)"
+        gather["traffic_source"] = "profiles/r03_traffic.json (same method; the Zipf head is served by L2 / Infinity Cache, uniform ids are not)"
 
     out = {
         "metric": "train samples/sec", "value": round(args.batch * world * args.steps / dt, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=%s full%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s"
+                               "per-GPU batch %d, L=%s full%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s, "
+                               "%d distinct resident batches, tables %s"
                                % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10",
                                   (" (flash-style attention kernels, %s MFMA forward)" % args.attn_dtype) if args.long_seq > 64 else "", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
-                                  "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)"),
+                                  "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)", max(2, args.fresh_batches),
+                                  ("pre-aged to step %d (per-row last-touch gaps from the id law: the lazy Adam replays them)" % args.age_tables) if args.age_tables > 0 else "fresh (nothing for the lazy Adam to replay)"),
                    "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" + row-sharded tables" if args.shard_tables else "") + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
+        "step_phases_ms": phases(diag, args.steps, world, tr), "lazy_adam": age_info,
         "roofline": roofline, "other_mfma_kernels": [f for f in fams if f["key"] != roofline.get("key")], "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }
     if not args.no_cpu_baseline and world == 1:
@@ -249,6 +269,126 @@ def main():
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources (csrc/*.hip, dmt_common.h): what a committed counter file is tied to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cikm2020_dmt_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + [os.path.join(d, "dmt_common.h")]):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()
+
+
+def phases(diag, steps, world, tr):
+    """Mean milliseconds per step of the phases Trainer.train_step brackets with HIP events (Trainer.diag): the index plane, the lazy
+    Adam's row catch-up, the optimizer, and -- in a data-parallel step -- each collective from issue to completion as seen by the
+    stream that waits for it (so time hidden behind compute still shows: these are spans, not exclusive times)."""
+    import torch.distributed as dist
+    out = {"world_size_seen_by_torch_distributed": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+           "data_parallel_path": bool(tr._dp_active()), "table_layout": tr.table_layout,
+           "note": "HIP-event spans on the stream that issues / waits for the phase, mean over the timed steps; phases overlap each other and the step's compute"}
+    for key, ent in sorted((diag or {}).items()):
+        ms = [e0.elapsed_time(e1) for (e0, e1) in ent]
+        if ms:
+            out[key + "_ms"] = round(sum(ms) / max(steps, 1), 4)
+    return out
+
+
+def age_tables(tr, sp, args, seq_lens):
+    """Put the tables and the optimizer in the state a run of K = --age-tables steps leaves behind, as far as the lazy Adam's cost is
+    concerned: the device step counter and the lr_t history at K, every row's last-touch step K - age with age drawn from the row's
+    own inter-arrival law, non-zero Adam slots on every row that was ever touched.
+    A row's per-step touch probability follows from the id law of BASELINE.md section 3 (data_feed/synthetic.py): id = 1 + (z mod (V - 1)),
+    z ~ Zipf(1.05) truncated at 2^63 as numpy draws it; a feature with T ids per example makes B * T draws per step; the pooled path
+    touches row id, the Transformer path row id - 1 (base.py:87-89).  The model is checked against the run: `expected_distinct_rows`
+    beside the measured distinct rows of a batch."""
+    from scipy.special import zeta
+    K = int(args.age_tables)
+    st, opt, dev = tr.store, tr.opt, tr.device
+    B = args.batch
+    a = 1.05
+    xmax = 2.0 ** 63
+    Z = float(zeta(a, 1)) - xmax ** (1 - a) / (a - 1)
+    seq_feats = set()
+    for grp in sp["attention_embed_pairs"]:
+        for (uf, itf) in grp:
+            seq_feats.update((uf, itf))
+    per_table = {}
+    groups = {grp[0][0]: [uf for (uf, _i) in grp] for grp in sp["attention_embed_pairs"]}
+    len_of = {}
+    for g0, ufs in groups.items():
+        L_ = int((seq_lens or {}).get(g0, 0) or int(g0.rsplit("_", 1)[1]))
+        for uf in ufs:
+            len_of[uf] = L_
+    for gi, tsf in enumerate(sp["attention_embed_seq_ts"]):
+        len_of[tsf] = len_of[sp["attention_embed_pairs"][gi][0][0]]
+    for (n, rows, _d, f, side) in sp["embedding_list"]:
+        T = 1 if side == "i" else len_of.get(f, 1)
+        e = per_table.setdefault("embedding_trans/%s/embedding" % n, [rows, 0, 0])
+        e[1] += B * T
+        if f in seq_feats:
+            e[2] += B * T
+    for (n, rows, _d, f, side) in sp["embedding_list_bias"]:
+        e = per_table.setdefault("%s/embedding" % n, [rows, 0, 0])
+        e[1] += B * (1 if side == "i" else 6)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    expected = 0.0
+    with torch.no_grad():
+        opt.global_step, opt._step_base = K, 0
+        t = torch.arange(1, K + 1, dtype=torch.float64, device=dev)
+        lr_t = (opt.current_lr() * torch.sqrt(1.0 - opt.b2 ** t) / (1.0 - opt.b1 ** t)).float()
+        opt.lr_hist[1: K + 1] = lr_t
+        opt.state[0], opt.state[1], opt.state[2] = float(opt.b1 ** (K + 1)), float(opt.b2 ** (K + 1)), float(lr_t[-1])
+        opt.state.view(torch.int32)[3] = K
+        for name, (V, n_pool, n_seq) in per_table.items():
+            base, rows = st.table_rows[name]
+            j = torch.arange(0, rows + 1, dtype=torch.float64, device=dev)            # id j (0 is never drawn)
+            if args.law == "uniform" or V <= 2:
+                q = torch.full_like(j, 1.0 / max(V - 1, 1))
+            else:
+                w = float(V - 1)
+                c = (j - 1.0).clamp_min(0.0)
+                head = torch.where(j >= 2, c.clamp_min(1.0) ** (-a), torch.zeros_like(j))
+                tail = ((c + 0.5 * w) ** (1 - a) - xmax ** (1 - a)) / ((a - 1) * w)        # sum over the wrapped copies z = j - 1 + m w, m >= 1 (midpoint rule)
+                q = (head + tail) / Z
+            q[0] = 0.0
+            if V <= 1:
+                q.zero_()
+            log_miss = n_pool * torch.log1p(-q[:rows].clamp(max=0.999999)) + n_seq * torch.log1p(-q[1: rows + 1].clamp(max=0.999999))
+            p_touch = (1.0 - torch.exp(log_miss)).clamp(1e-12, 1.0)
+            expected += float(p_touch.sum())
+            u = torch.rand(rows, generator=g, device=dev, dtype=torch.float64).clamp_min(1e-300)
+            age = torch.floor(torch.log(u) / torch.log1p(-p_touch.clamp(max=1.0 - 1e-12))).clamp(0, K)      # geometric: steps since the last touch
+            rk, W = st.shard if st.shard is not None else (0, 1)
+            age = age[rk::W]                     # row-sharded tables: this rank holds the rows with id % W == rank, densely (local row = id // W)
+            rows = int(age.numel())
+            touched = age < K
+            st.last_step[base // W: base // W + rows] = (K - age).clamp(0, K).to(torch.int32)
+            info = st.tables[name]
+            dim = info.shape[1]
+            gs = 1e-4
+            m = st.tab_m[info.offset: info.offset + rows * dim].view(rows, dim)
+            v = st.tab_v[info.offset: info.offset + rows * dim].view(rows, dim)
+            chunk = 1 << 20
+            for r0 in range(0, rows, chunk):
+                r1 = min(rows, r0 + chunk)
+                tt = touched[r0:r1, None].float()
+                m[r0:r1] = 0.1 * gs * torch.randn((r1 - r0, dim), generator=g, device=dev) * tt
+                v[r0:r1] = 1e-3 * gs * gs * (1.0 + torch.rand((r1 - r0, dim), generator=g, device=dev)) * tt
+    torch.cuda.synchronize()
+    ages = (K - st.last_step.long()).clamp_min(0)
+    live = ages < K
+    return {"simulated_steps": K, "resident_batches": max(2, args.fresh_batches),
+            "expected_distinct_rows_per_batch": int(expected),
+            "rows_ever_touched_frac": round(float(live.float().mean()), 4),
+            "median_age_of_touched_rows": int(ages[live].median()) if bool(live.any()) else None,
+            "note": "per-row last-touch ages drawn from the id law's inter-arrival distribution at step K (bench.py:age_tables); the timed steps then "
+                    "replay those gaps in dmt_adam_catchup_rows (bounded replay: DESIGN.md section 5)"}
 
 
 def cpu_baseline(sp, args):

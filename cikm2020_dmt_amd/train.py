@@ -55,6 +55,7 @@ class Trainer:
         self.engine.kopts = ops.KernelOptions(attn_mma_fp8=(attn_dtype == "fp8"))
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
+        self.diag = None       # dict: train_step brackets its phases with HIP events (key -> [(start, end)]); bench.py's step_phases_ms
         # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in
         # train(), so it is the default here; parity runs against the oracle pass dropout=False (or the same seeds).
         self.dropout, self.dropout_seed = dropout, dropout_seed
@@ -80,6 +81,39 @@ class Trainer:
             if self._dp_active():
                 streams.warm_communicators(self.device)
 
+    class _Span:
+        """with self._span("key"): ...  -- a HIP-event pair on the CURRENT stream around the block when self.diag is a dict (else free)."""
+        __slots__ = ("tr", "key", "e0")
+
+        def __init__(self, tr, key):
+            self.tr, self.key, self.e0 = tr, key, None
+
+        def __enter__(self):
+            if self.tr.diag is not None and self.tr.device.type == "cuda":
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *a):
+            if self.e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.tr.diag.setdefault(self.key, []).append((self.e0, e1))
+            return False
+
+    def _span(self, key):
+        return Trainer._Span(self, key)
+
+    def _mark(self, key, e0=None):
+        """Open (e0 None -> returns the start event) or close a span whose two ends lie in different methods."""
+        if self.diag is None or self.device.type != "cuda":
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if e0 is not None:
+            self.diag.setdefault(key, []).append((e0, ev))
+        return ev
+
     def make_batch(self, inputs, mask=None, label=None, pad_to=None) -> DeviceBatch:
         return DeviceBatch.from_inputs(inputs, self.spec, self.device, mask=mask, label=label, pad_to=pad_to)
 
@@ -102,9 +136,11 @@ class Trainer:
         else:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            prep = self.engine.prepare(batch)
+            with self._span("index_plane_sort"):
+                prep = self.engine.prepare(batch)
             if need_plan and "xplan" not in prep:
-                prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
+                with self._span("exchange_ids"):
+                    prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
             _record_stream(prep, main)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -130,10 +166,12 @@ class Trainer:
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
         if self.table_layout == "sharded":
-            self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
+            with self._span("row_fetch"):
+                self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
             return prep
         if self.opt.global_step > 0:
-            self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
+            with self._span("adam_catchup"):
+                self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
         return prep
 
     def _index_stream(self):
@@ -242,7 +280,7 @@ class Trainer:
             parallel._a2a(recv_r, send_r, plan["recv_splits"], plan["send_splits"])
         return (work, send_r, recv_r)
 
-    def exchange_rows_reduce(self, handle, plan):
+    def exchange_rows_reduce(self, handle, plan, t_issue=None):
         """DATA PLANE, second part: the owner sums what it received per row, in rank order, with the segments prepared by
         plan_exchange (dmt_rows_reduce).  Sharded layout: done -- the owner applies Adam to its rows.  Replicated layout: the reduced
         shards leave in an all-gather (padded to the largest shard; padding slots carry an invalid key the optimizer kernels skip),
@@ -250,6 +288,7 @@ class Trainer:
         work, _send_r, recv_r = handle
         if work is not None:
             work.wait()
+        self._mark("exchange_rows_a2a", t_issue)          # issue -> the compute stream may read what arrived
         eng, st = self.engine, self.store
         rank, W = parallel.world()
         Rn, D = plan["R"], int(recv_r.shape[1])
@@ -262,7 +301,7 @@ class Trainer:
             L.call("dmt_rows_reduce_bf16" if recv_r.dtype == torch.bfloat16 else "dmt_rows_reduce", ops.p(plan["keys_s"]), ops.p(plan["vals_s"]),
                    ops.p(plan["seg"]), Rn, st.total_rows, ops.p(recv_r), ops.p(out_rows), D, ws, wsb, ops.stream_ptr())
         if sharded:
-            return (None, (plan["uniq2"], plan["n_uniq2"], out_rows, Rn), None)
+            return (None, (plan["uniq2"], plan["n_uniq2"], out_rows, Rn), None, None)
         cap_m = plan["cap_m"]
         r_loc = out_rows[:cap_m]
         if recv_r.dtype == torch.bfloat16:
@@ -270,19 +309,21 @@ class Trainer:
         r_loc = r_loc.contiguous()
         all_r = torch.empty((W * cap_m, D), dtype=r_loc.dtype, device=r_loc.device)
         work2 = None
+        t_ag = self._mark("exchange_rows_allgather")
         if not parallel.dist.is_initialized():
             all_r.copy_(r_loc)
         elif parallel.dist.get_backend() == "nccl" and hasattr(parallel.dist, "all_gather_into_tensor"):
             work2 = parallel.dist.all_gather_into_tensor(all_r, r_loc, async_op=True)
         else:
             parallel._all_gather_cat(all_r, r_loc, W, cap_m)
-        return (work2, (plan["all_k"], plan["n_dev"], all_r, W * cap_m), r_loc)
+        return (work2, (plan["all_k"], plan["n_dev"], all_r, W * cap_m), r_loc, t_ag)
 
-    @staticmethod
-    def exchange_rows_collect(handle2):
-        work2, sparse, _keep = handle2
+    def exchange_rows_collect(self, handle2):
+        work2, sparse, _keep, t_ag = handle2
         if work2 is not None:
             work2.wait()
+        if t_ag is not None:
+            self._mark("exchange_rows_allgather", t_ag)
         return sparse
 
     def exchange_rows_finish(self, handle, plan):
@@ -323,6 +364,7 @@ class Trainer:
             if z is not None and z.requires_grad:
                 def _hook(g, off=off):
                     if self._early is None:
+                        self._early_t0 = self._mark("allreduce_tail")
                         self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True, force=self.force_dp))
                     return g
                 z.register_hook(_hook)
@@ -450,11 +492,12 @@ class Trainer:
                 self.store.refresh_shadows()
                 return loss
             ops.run_deferred_wgrads()
-            self.opt.begin()
-            self.opt.apply_sparse(sparse, 1.0)
-            self.opt.apply_dense(1.0)
-            self.opt.end()
-            self.store.refresh_shadows()
+            with self._span("optimizer"):
+                self.opt.begin()
+                self.opt.apply_sparse(sparse, 1.0)
+                self.opt.apply_dense(1.0)
+                self.opt.end()
+                self.store.refresh_shadows()
             return loss
         if dp:
             early, self._early = getattr(self, "_early", None), None
@@ -465,23 +508,31 @@ class Trainer:
                 # EARLY and go on the links at once; the collected weight gradients -- MFMA work nothing else waits for -- run while
                 # the rows travel (first half beside the all_to_all, second half beside the all-gather of the reduced shards).
                 n_w = ops.deferred_wgrads_pending()
+                t_a2a = self._mark("exchange_rows_a2a")
                 handle = self.exchange_rows_begin(sparse, plan)
-                ops.run_deferred_wgrads(upto=(n_w + 1) // 2)
-                handle2 = self.exchange_rows_reduce(handle, plan)
-                ops.run_deferred_wgrads()
+                with self._span("wgrads_beside_wire"):
+                    ops.run_deferred_wgrads(upto=(n_w + 1) // 2)
+                handle2 = self.exchange_rows_reduce(handle, plan, t_a2a)
+                with self._span("wgrads_beside_wire"):
+                    ops.run_deferred_wgrads()
                 self.n_deferred = n_w
+                t_head = self._mark("allreduce_head")
                 works = [early[1] if early is not None else None,
                          parallel.allreduce_dense_(self.store.grads[: early[0]] if early is not None else self.store.grads, async_op=True, force=self.force_dp)]
                 for w in works:
                     if w is not None:
                         w.wait()
+                self._mark("allreduce_head", t_head)
+                if early is not None:
+                    self._mark("allreduce_tail", getattr(self, "_early_t0", None))
                 loss = parallel.mean_scalar(loss)
-                self.opt.begin()
-                self.opt.apply_dense(1.0 / W)
-                sparse = self.exchange_rows_collect(handle2)
-                self.opt.apply_sparse(sparse, 1.0 / W)
-                self.opt.end()
-                self.store.refresh_shadows()
+                with self._span("optimizer"):
+                    self.opt.begin()
+                    self.opt.apply_dense(1.0 / W)
+                    sparse = self.exchange_rows_collect(handle2)
+                    self.opt.apply_sparse(sparse, 1.0 / W)
+                    self.opt.end()
+                    self.store.refresh_shadows()
                 return loss
             ops.run_deferred_wgrads()          # (no exchange plan: nothing to overlap them with)
             if early is not None:
@@ -490,17 +541,23 @@ class Trainer:
                 works = [parallel.allreduce_dense_(self.store.grads, async_op=True, force=self.force_dp)]
             if plan is not None:
                 # no host sync between backward and the optimizer: sizes were fixed by plan_exchange before the forward pass
+                t_a2a = self._mark("exchange_rows_a2a")
                 handle = self.exchange_rows_begin(sparse, plan)
+                t_head = self._mark("allreduce_head")
                 for w in works:
                     if w is not None:
                         w.wait()
+                self._mark("allreduce_head", t_head)
+                if early is not None:
+                    self._mark("allreduce_tail", getattr(self, "_early_t0", None))
                 loss = parallel.mean_scalar(loss)
-                self.opt.begin()
-                self.opt.apply_dense(1.0 / W)                  # overlaps the row exchange (RCCL: its own stream)
-                sparse = self.exchange_rows_finish(handle, plan)
-                self.opt.apply_sparse(sparse, 1.0 / W)
-                self.opt.end()
-                self.store.refresh_shadows()
+                with self._span("optimizer"):
+                    self.opt.begin()
+                    self.opt.apply_dense(1.0 / W)                  # overlaps the row exchange (RCCL: its own stream)
+                    sparse = self.exchange_rows_collect(self.exchange_rows_reduce(handle, plan, t_a2a))
+                    self.opt.apply_sparse(sparse, 1.0 / W)
+                    self.opt.end()
+                    self.store.refresh_shadows()
                 return loss
             sparse = self.merge_sparse(sparse)
             for w in works:

@@ -1,12 +1,12 @@
 #!/bin/bash
 # The measurement set of a build, in one call on one box (run from the repo root on the GPU box):  scripts/final_sweep.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r02}
+tag=${1:-r03}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
 bash scripts/pmc_traffic.sh ${tag}_pmc > $O/pmc.log 2>&1
-cp gpurun_out/${tag}_pmc_traffic.json profiles/r02_traffic.json && cp gpurun_out/${tag}_pmc_traffic.json $O/traffic.json
+cp gpurun_out/${tag}_pmc_traffic.json profiles/r03_traffic.json && cp gpurun_out/${tag}_pmc_traffic.json $O/traffic.json
 python bench.py 2>/dev/null | grep '^{' > $O/bench_n1.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
