@@ -180,11 +180,13 @@ __device__ __forceinline__ void swap_lo(unsigned& a, unsigned& b) {
   a = r[0]; b = r[1];
 }
 
-// DBG (timing experiments only, results are garbage): 1 no DMA, 2 no side-output stores (mid, mask), 64 no main loop
+// DBG (timing experiments only, results are garbage): 1 no DMA, 2 no side-output stores (mid, mask), 4 no LDS fragment reads,
+// 8 no MFMA, 16 no per-stage workgroup barrier, 32 no hand-off / relu work
 template <typename G, int MODE, int DBG = 0>
 __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
   constexpr int KC = G::KC, NJT = G::NJT, NOT = G::NOT, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE, NST = G::NST;
   constexpr int NF = 2 * NOT;   // GEMM-2 fragments (output tile, k half) per mid tile
+  static_assert(PER_WAVE * 8192 == STAGE, "a stage is a whole number of 8 KB rounds");
   // 8 wavefronts = 4 producer / consumer pairs on the 4 SIMDs (wavefronts w and w + 4 share a SIMD), a pair owns 32 rows:
   //   producer (w < 4):  holds the input rows as B fragments, GEMM 1 of every mid tile, mid op, hands the tile over through LDS
   //   consumer (w >= 4): holds the output accumulators, GEMM 2 of every mid tile, epilogue (LayerNorm, stores)
@@ -204,10 +206,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
 
   const __amdgpu_buffer_rsrc_t rimg =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(g.image), 0, (int)G::IMAGE_BYTES, 0x00020000);
+  // The DMA ring is fed by the CONSUMER wavefronts only (PER_C pieces of 1 KB per wavefront and stage).  vmcnt retires in issue
+  // order, loads and stores alike: a producer that issued ring pieces had to see its own side-output stores of the previous mid tile
+  // (h, gate bits: partial-line writes, microseconds under load) retire before it could tell that a stage had landed.  Now a producer
+  // never waits on vmcnt in the loop -- the barrier tells it a stage is there -- and the consumers' queue holds ring pieces only.
+  constexpr int PER_C = 2 * PER_WAVE;
   auto issue1 = [&](int buf, int u, int p) {
     if constexpr ((DBG & 1) != 0) return;
-    unsigned char* sb = smem + buf * STAGE + wave * 1024 + p * 8192;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + wave * 1024 + p * 8192, 0, 0);
+    unsigned char* sb = smem + buf * STAGE + (wave - 4) * 1024 + p * 4096;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + (wave - 4) * 1024 + p * 4096, 0, 0);
   };
 
   const int G_ = (int)gridDim.x;
@@ -215,40 +222,50 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
   // static priority for the producers: their 20 MFMAs of a mid tile go first, so the accumulator conversion that follows them runs
   // beside the consumer's MFMAs instead of after them (the condition is wave-uniform: s_setprio ignores EXEC)
   if (wave < 4) __builtin_amdgcn_s_setprio(2);
+  if (!producer) {
 #pragma unroll
-  for (int p = 0; p < PER_WAVE; ++p) issue1(0, 0, p);
+    for (int p = 0; p < PER_C; ++p) issue1(0, 0, p);
 #pragma unroll
-  for (int p = 0; p < PER_WAVE; ++p) issue1(1, 1, p);
+    for (int p = 0; p < PER_C; ++p) issue1(1, 1, p);
+  }
   int gs = 0;   // global stage counter of this workgroup
 
-  for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
-    const long long row0 = (long long)tile * 128 + pair * 32;
-    const long long m = row0 + ml;
-    const bool mvalid = m < g.M;
-    const long long mc = mvalid ? m : (g.M - 1);
-    const long long blk = row0 >> 5;
+  // producers: the raw input rows of the NEXT row tile are requested in the middle of the current tile's loop (one workgroup per CU:
+  // nothing else would hide the ~2 us of these row-strided loads at a tile's start)
+  u32x4_t Xn[KC];
+  auto request_rows = [&](int tile_) {
+    const long long m_ = (long long)tile_ * 128 + pair * 32 + ml;
+    const bf16_t* xr = g.in + (m_ < g.M ? m_ : (g.M - 1)) * g.ld_in + 8 * hi;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) Xn[c] = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
+  };
+  if (producer) request_rows((int)blockIdx.x);
 
-    // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
-    // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
-    // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
-    // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
-    auto top = [&](int u) {
-      if (producer && g.relax == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE + 3) : "memory");
-      else if (producer && g.relax == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE + 2) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_WAVE) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      (void)u;
-    };
+  if (producer) {
+    for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
+      const long long row0 = (long long)tile * 128 + pair * 32;
+      const long long m = row0 + ml;
+      const bool mvalid = m < g.M;
+      const long long mc = mvalid ? m : (g.M - 1);
+      const long long blk = row0 >> 5;
 
-    if (producer) {
+      // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
+      // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
+      // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
+      // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
+      auto top = [&](int u) {
+        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
+        (void)u;
+      };
+
       // ---- input rows -> B fragments (k permuted inside every 16-chunk: the lower lane takes elements 0-3 | 8-11, the upper 4-7 | 12-15)
       bf16x8_t X[KC];
       {
-        const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
-          const u32x4_t vl = *reinterpret_cast<const u32x4_t*>(xr + 16 * c);
+          const u32x4_t vl = Xn[c];
           uint4 v = make_uint4(vl[0], vl[1], vl[2], vl[3]);
           if (!mvalid) v = make_uint4(0u, 0u, 0u, 0u);
           swap_lo(v.x, v.z);
@@ -259,15 +276,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
       unsigned bits_next = 0;
       if constexpr (MODE == DMT_CHAIN_FFN_BWD) bits_next = g.mask[(blk * NJT + 0) * 64 + lane];
 #pragma unroll 1
-      for (int u = 0; u < NJT; ++u, ++gs) {
+      for (int u = 0; u < ((DBG & 64) ? 1 : NJT); ++u, ++gs) {
         const int buf = gs % CH_NS;
         top(u);
+        if (u == NJT / 4 && tile + G_ < g.tiles) request_rows(tile + G_);
         unsigned bits = bits_next;
         if constexpr (MODE == DMT_CHAIN_FFN_BWD) {
           bits_next = g.mask[(blk * NJT + (u + 1 < NJT ? u + 1 : u)) * 64 + lane];   // gate bits of the next tile, older than the DMA below
           asm volatile("" ::: "memory");
         }
-        const int dbuf = (gs + 2) % CH_NS, du = (u + 2) % NST;
         const unsigned so = (unsigned)buf * STAGE;
         const unsigned a1a = a1_lane + so;
         constexpr int PB = (KC % 5 == 0) ? 5 : 4, NBAT = KC / PB;
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
           sfor<5>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int c = b * PB + (i < PB ? i : 0);
-            ch_read128<c * 32>(R[i], a1a);
+            if constexpr ((DBG & 4) != 0) ch_fake(R[i]); else ch_read128<c * 32>(R[i], a1a);
           });
         };
         auto mm = [&](bf16x8_t (&R)[5], auto bic) {
@@ -288,7 +305,8 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
           sfor<PB>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int c = b * PB + i;
-            Ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[c], Ha, 0, 0, 0);
+            if constexpr ((DBG & 8) != 0) Ha[i] += __builtin_bit_cast(f32x4_t, R[i])[0] + __builtin_bit_cast(f32x4_t, X[c])[1];
+            else Ha = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], X[c], Ha, 0, 0, 0);
           });
         };
         if constexpr (MODE == DMT_CHAIN_FFN_LN) {
@@ -304,8 +322,6 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             if constexpr ((b & 1) == 0) rd(R1, std::integral_constant<int, b + 1>{});
             else rd(R0, std::integral_constant<int, b + 1>{});
           }
-#pragma unroll
-          for (int p = (PER_WAVE * b) / NBAT; p < (PER_WAVE * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
           if constexpr (b == 0) {
             if constexpr (MODE == DMT_CHAIN_FFN_LN) {
               ch_wait4f<(NBAT > 1 ? 10 : 5)>(b4[0], b4[1], b4[2], b4[3]);
@@ -354,7 +370,12 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             // row m, columns 16 p + 8 hi .. +8 of the tile after pairing q = 2p (kept by the lower lane) with q = 2p + 1 (upper lane)
             swap_lo(ho[0], ho[2]); swap_lo(ho[1], ho[3]);
             swap_lo(ho[4], ho[6]); swap_lo(ho[5], ho[7]);
-            if (mvalid) {
+            if constexpr ((DBG & 256) != 0) {
+              // (timing experiment: the same bytes as fully coalesced 1 KB stores, garbage layout)
+              bf16_t* dst = g.mid_out + ((blk * NJT + u) * 2) * 512 + lane * 8;
+              *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{ho[0], ho[1], ho[2], ho[3]};
+              *reinterpret_cast<u32x4_t*>(dst + 512) = u32x4_t{ho[4], ho[5], ho[6], ho[7]};
+            } else if (mvalid) {
               bf16_t* dst = g.mid_out + m * g.ld_mid + u * 32 + 8 * hi;
               // (plain stores: a row receives 64 bytes per mid tile, the L2 merges the pieces of a line; non-temporal partial-line
               //  stores were 4x slower)
@@ -364,28 +385,53 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
           }
         }
       }
-      // (iteration NJT: the consumer multiplies the last mid tile; the producer only keeps the ring going)
+      // (iteration NJT: the consumer multiplies the last mid tile)
       top(NJT);
-      {
-        const int dbuf = (gs + 2) % CH_NS, du = (NJT + 2) % NST;
-#pragma unroll
-        for (int p = 0; p < PER_WAVE; ++p) issue1(dbuf, du, p);
-      }
       ++gs;
-    } else {
+    }
+  } else {
+    for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
+      const long long row0 = (long long)tile * 128 + pair * 32;
+      const long long m = row0 + ml;
+      const bool mvalid = m < g.M;
+      const long long mc = mvalid ? m : (g.M - 1);
+      const long long blk = row0 >> 5;
+
+      // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
+      // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
+      // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
+      // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
+      auto top = [&](int u) {
+        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
+        (void)u;
+      };
+
       // ---- consumer: out^T accumulators start as bias2 + residual (register (t, 4 q + i) of lane (m, hi) is column 32 t + 8 q + 4 hi + i)
       f32x16_t Y[NOT];
       {
-        const bf16_t* xr = g.in + mc * g.ld_in + 8 * hi;
+        // Every residual piece is requested back to back from a VALID address (row clamped to M - 1, column to 0) and masked afterwards:
+        // a load under a per-lane predicate is waited for (vmcnt(0)) before hipcc issues the next one -- 20 serial round trips per
+        // tile, ~90 us of a 600 us launch (seen in the ISA; DESIGN.md section 3 "a recurring compiler effect").
+        const bf16_t* xrow = g.in + mc * g.ld_in;
+        u32x4_t xraw[2 * NOT];
 #pragma unroll
-        for (int t = 0; t < NOT; ++t) {
+        for (int t = 0; t < NOT; ++t)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int col = 32 * t + 16 * p + 8 * hi;
+            xraw[2 * t + p] = *reinterpret_cast<const u32x4_t*>(xrow + (col < G::KIN ? col : 0));
+          }
+        sfor<NOT>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
           unsigned xv[8];
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const int col = 32 * t + 16 * p + 8 * hi;
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (col < G::KIN && mvalid) v = *reinterpret_cast<const u32x4_t*>(xr + 32 * t + 16 * p);
-            xv[4 * p + 0] = v[0]; xv[4 * p + 1] = v[1]; xv[4 * p + 2] = v[2]; xv[4 * p + 3] = v[3];
+            const bool ok = col < G::KIN && mvalid;
+            const u32x4_t v = xraw[2 * t + p];
+            xv[4 * p + 0] = ok ? v[0] : 0u; xv[4 * p + 1] = ok ? v[1] : 0u; xv[4 * p + 2] = ok ? v[2] : 0u; xv[4 * p + 3] = ok ? v[3] : 0u;
           }
           // undo the store pairing: the lower lane holds columns 16 p + 0..7, the upper 16 p + 8..15; register group q wants 8 q + 4 hi + 0..3
           swap_lo(xv[0], xv[2]); swap_lo(xv[1], xv[3]);
@@ -400,18 +446,18 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             Y[t][4 * q + 2] = b[2] + __uint_as_float(xv[2 * q + 1] << 16);
             Y[t][4 * q + 3] = b[3] + __uint_as_float(xv[2 * q + 1] & 0xFFFF0000u);
           }
-        }
+        });
       }
       // (iteration 0: nothing produced yet; the consumer only keeps the ring going)
       top(0);
       {
         const int dbuf = (gs + 2) % CH_NS, du = 2 % NST;
 #pragma unroll
-        for (int p = 0; p < PER_WAVE; ++p) issue1(dbuf, du, p);
+        for (int p = 0; p < PER_C; ++p) issue1(dbuf, du, p);
       }
       ++gs;
 #pragma unroll 1
-      for (int u = 1; u <= NJT; ++u, ++gs) {
+      for (int u = 1; u <= ((DBG & 64) ? 1 : NJT); ++u, ++gs) {
         const int buf = gs % CH_NS;
         top(u);
         const int dbuf = (gs + 2) % CH_NS, du = (u + 2) % NST;
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             constexpr int i = decltype(ic)::value;
             constexpr int fi = b * PB + (i < PB ? i : 0);
             constexpr int t = fi >> 1, f = fi & 1;
-            ch_read128<t * 32 * G::A2_STRIDE + f * 32>(R[i], a2a);
+            if constexpr ((DBG & 4) != 0) ch_fake(R[i]); else ch_read128<t * 32 * G::A2_STRIDE + f * 32>(R[i], a2a);
           });
         };
         auto mm = [&](bf16x8_t (&R)[5], auto bic) {
@@ -438,7 +484,8 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             constexpr int i = decltype(ic)::value;
             constexpr int fi = b * PB + i;
             constexpr int t = fi >> 1, f = fi & 1;
-            Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], f == 0 ? Hb0 : Hb1, Y[t], 0, 0, 0);
+            if constexpr ((DBG & 8) != 0) Y[t][i] += __builtin_bit_cast(f32x4_t, R[i])[0] + __builtin_bit_cast(f32x4_t, f == 0 ? Hb0 : Hb1)[1];
+            else Y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R[i], f == 0 ? Hb0 : Hb1, Y[t], 0, 0, 0);
           });
         };
         rd(R0, std::integral_constant<int, 0>{});
@@ -449,7 +496,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             else rd(R0, std::integral_constant<int, b + 1>{});
           }
 #pragma unroll
-          for (int p = (PER_WAVE * b) / NBAT; p < (PER_WAVE * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
+          for (int p = (PER_C * b) / NBAT; p < (PER_C * (b + 1)) / NBAT; ++p) issue1(dbuf, du, p);
           if constexpr (b == 0) ch_wait2<(NBAT > 1 ? 10 : 5)>(Hb0, Hb1);
           if constexpr (b + 1 < NBAT) {
             if constexpr ((b & 1) == 0) { ch_wait<5>(R0[0], R0[1], R0[2], R0[3], R0[4]); mm(R0, bic); }
@@ -490,15 +537,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
         if (g.stats != nullptr && mvalid && hi == 0) { g.stats[2 * m] = mean; g.stats[2 * m + 1] = rstd; }
       }
       // stores: 16 bytes per lane after pairing q = 2p (lower lane) with q = 2p + 1 (upper lane): row m, columns 32 t + 16 p + 8 hi .. +8
-#pragma unroll
-      for (int t = 0; t < NOT; ++t) {
+      sfor<NOT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
         unsigned su[8], yu[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n0 = 32 * t + 8 * q + 4 * hi;
           su[2 * q] = dmt_pack_bf16(Y[t][4 * q + 0], Y[t][4 * q + 1]);
           su[2 * q + 1] = dmt_pack_bf16(Y[t][4 * q + 2], Y[t][4 * q + 3]);
           if constexpr (MODE == DMT_CHAIN_FFN_LN) {
+            const int n0 = 32 * t + 8 * q + 4 * hi;
             f32x4_t gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
             if (n0 < G::NOUT) { gm = *reinterpret_cast<const f32x4_t*>(g.gamma + n0); bt = *reinterpret_cast<const f32x4_t*>(g.beta + n0); }
             float o[4];
@@ -517,14 +564,14 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const int col = 32 * t + 16 * p + 8 * hi;
-          if (mvalid && col < G::NOUT) {
+          if (mvalid && col < G::NOUT && ((DBG & 128) == 0 || su[0] == 0x12345u)) {
             if (g.s_out != nullptr)
               *reinterpret_cast<u32x4_t*>(g.s_out + m * g.ld_out + col) = u32x4_t{su[4 * p], su[4 * p + 1], su[4 * p + 2], su[4 * p + 3]};
             if constexpr (MODE == DMT_CHAIN_FFN_LN)
               *reinterpret_cast<u32x4_t*>(g.y_out + m * g.ld_out + col) = u32x4_t{yu[4 * p], yu[4 * p + 1], yu[4 * p + 2], yu[4 * p + 3]};
           }
         }
-      }
+      });
     }
   }
   // the ring runs two stages ahead of the last multiply: let those pieces land before the workgroup (and its LDS) goes away
@@ -556,8 +603,13 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
     const char* dbg = getenv("DMT_CHAIN_DEBUG");   // timing experiments (see DBG above); never set in production
     const int v = dbg ? atoi(dbg) : 0;
     if (v != 0 && d->mode == DMT_CHAIN_FFN_LN) {
-      if (v == 1) hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 1>), dim3(grid), dim3(CH_NT), 0, st, a);
-      else hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 3>), dim3(grid), dim3(CH_NT), 0, st, a);
+#define DMT_CHAIN_DBG(V) case V: hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, V>), dim3(grid), dim3(CH_NT), 0, st, a); break;
+      switch (v) {
+        DMT_CHAIN_DBG(1) DMT_CHAIN_DBG(2) DMT_CHAIN_DBG(3) DMT_CHAIN_DBG(4) DMT_CHAIN_DBG(8) DMT_CHAIN_DBG(16) DMT_CHAIN_DBG(7) DMT_CHAIN_DBG(11)
+        DMT_CHAIN_DBG(15) DMT_CHAIN_DBG(31) DMT_CHAIN_DBG(95) DMT_CHAIN_DBG(223) DMT_CHAIN_DBG(159) DMT_CHAIN_DBG(128) DMT_CHAIN_DBG(130) DMT_CHAIN_DBG(256) DMT_CHAIN_DBG(384)
+        default: dmt_set_error("dmt_chain2: DMT_CHAIN_DEBUG=%d is not compiled", v); return DMT_ERR_ARG;
+      }
+#undef DMT_CHAIN_DBG
       DMT_CHECK_LAUNCH("dmt_chain2(debug)");
       return DMT_OK;
     }
