@@ -154,6 +154,8 @@ _SIGS = {
                              c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_sparse_rows_bf16": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_f32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_catchup_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
+    "dmt_adam_catchup_rows_to": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_f32, c_f32, c_i32, c_vp, c_i32, c_vp],
+    "dmt_rows_stamp": [C.POINTER(TableMap), c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_rebase": [c_vp, c_vp, c_i64, c_vp],
     "dmt_rows_gather": [C.POINTER(TableMap), c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],

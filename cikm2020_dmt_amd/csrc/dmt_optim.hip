@@ -171,47 +171,53 @@ __global__ __launch_bounds__(256) void adam_sparse_kernel(const dmt_table_map tm
   }
 }
 
+// One WAVEFRONT per row, one lane per element (dim <= 64: one pass; wider rows in 64-element strides).  The replay length is a
+// property of the ROW (its last-touch step), so the loop is wave-uniform up to the per-element early exit -- the four-rows-per-wave
+// form paid 4 x max(age of its 4 rows) serial iterations per wavefront (each lane walked 4 elements one after the other); with real
+// id gaps (bench.py --age-tables: median 6, tail > 100 steps) that was 0.9 ms of a 10.4 ms step.
+// to_step < 0: replay through the last completed step (state.step).  stamp != null: rows whose stamp equals stamp_skip are left alone
+// (rows the optimizer step IN FLIGHT is going to update itself: the early catch-up of the next batch, Trainer.train_step).
 __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ m,
                                                            float* __restrict__ v, int* __restrict__ last_step,
                                                            const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
                                                            const float* __restrict__ state, const float* __restrict__ lr_hist,
-                                                           float b1, float b2, float eps) {
-  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+                                                           float b1, float b2, float eps, int to_step, const int* __restrict__ stamp,
+                                                           int stamp_skip) {
+  const int lane = threadIdx.x & 63;
   const long long n = n_uniq[0];
-  const int step = reinterpret_cast<const int*>(state)[3];
+  const int step = to_step >= 0 ? to_step : reinterpret_cast<const int*>(state)[3];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
-  const long long groups = (long long)gridDim.x * 16;
-  for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < n; u += waves) {
     const int row = (int)uniq[u];
     if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables] || !tm_owned(tm, row)) continue;
     const int lsi = row / tm_sw(tm);
     const int last = last_step[lsi];
     if (last >= step) continue;
+    if (stamp != nullptr && stamp[lsi] == stamp_skip) continue;
     const int t = find_table(tm, row);
     const int dim = tm.dim[t];
     const long long base = tm_elem(tm, t, row, dim);
-    if ((dim & 3) == 0) {
-      for (int j = c * 4; j < dim; j += 64) {
-        float4 pv = ld4(p + base + j), mv = ld4(m + base + j), vv = ld4(v + base + j);
-        const bool live = (mv.x != 0.f) | (vv.x != 0.f) | (mv.y != 0.f) | (vv.y != 0.f) | (mv.z != 0.f) | (vv.z != 0.f) | (mv.w != 0.f) | (vv.w != 0.f);
-        if (live) {
-          catch_up(pv.x, mv.x, vv.x, last + 1, step, lr_hist, c1, c2, eps);
-          catch_up(pv.y, mv.y, vv.y, last + 1, step, lr_hist, c1, c2, eps);
-          catch_up(pv.z, mv.z, vv.z, last + 1, step, lr_hist, c1, c2, eps);
-          catch_up(pv.w, mv.w, vv.w, last + 1, step, lr_hist, c1, c2, eps);
-          st4(p + base + j, pv); st4(m + base + j, mv); st4(v + base + j, vv);
-        }
-      }
-    } else {
-      for (int j = c; j < dim; j += 16) {
-        float pv = p[base + j], mv = m[base + j], vv = v[base + j];
-        if (mv != 0.f || vv != 0.f) {
-          catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
-          p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
-        }
+    for (int j = lane; j < dim; j += 64) {
+      float pv = p[base + j], mv = m[base + j], vv = v[base + j];
+      if (mv != 0.f || vv != 0.f) {
+        catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
+        p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
       }
     }
-    if (c == 0) last_step[lsi] = step;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) last_step[lsi] = step;
+  }
+}
+
+// stamp[row] = value for every listed row (Trainer: "the optimizer step in flight updates this row itself")
+__global__ __launch_bounds__(256) void rows_stamp_kernel(const dmt_table_map tm, const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
+                                                         int* __restrict__ stamp, int value) {
+  const long long n = n_uniq[0];
+  for (long long u = (long long)blockIdx.x * 256 + threadIdx.x; u < n; u += (long long)gridDim.x * 256) {
+    const int row = (int)uniq[u];
+    if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables] || !tm_owned(tm, row)) continue;
+    stamp[row / tm_sw(tm)] = value;
   }
 }
 
@@ -302,16 +308,42 @@ extern "C" int dmt_adam_sparse_rows_bf16(const dmt_table_map* tm, float* p, floa
   return DMT_OK;
 }
 
+static int catchup_launch(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step, const uint32_t* uniq_keys,
+                          const int32_t* n_uniq, int32_t max_uniq, const float* state, const float* lr_hist, float beta1, float beta2,
+                          float eps, int to_step, const int32_t* stamp, int stamp_skip, void* stream, const char* who) {
+  DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && state && lr_hist, "%s: null argument", who);
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "%s: bad table map / max_uniq", who);
+  const long long need = cdiv64(max_uniq, 4);            // one wavefront per row, four per block
+  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
+  hipLaunchKernelGGL(adam_catchup_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
+                     state, lr_hist, beta1, beta2, eps, to_step, stamp, stamp_skip);
+  DMT_CHECK_LAUNCH(who);
+  return DMT_OK;
+}
+
 extern "C" int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                                      const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* state,
                                      const float* lr_hist, float beta1, float beta2, float eps, void* stream) {
-  DMT_CHECK_ARG(tm && p && m && v && last_step && uniq_keys && n_uniq && state && lr_hist, "dmt_adam_catchup_rows: null argument");
-  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0, "dmt_adam_catchup_rows: bad table map / max_uniq");
-  const long long need = cdiv64(max_uniq, 16);
-  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
-  hipLaunchKernelGGL(adam_catchup_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, p, m, v, last_step, uniq_keys, n_uniq,
-                     state, lr_hist, beta1, beta2, eps);
-  DMT_CHECK_LAUNCH("dmt_adam_catchup_rows");
+  return catchup_launch(tm, p, m, v, last_step, uniq_keys, n_uniq, max_uniq, state, lr_hist, beta1, beta2, eps, -1, nullptr, 0, stream,
+                        "dmt_adam_catchup_rows");
+}
+
+extern "C" int dmt_adam_catchup_rows_to(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                                        const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* state,
+                                        const float* lr_hist, float beta1, float beta2, float eps, int32_t to_step,
+                                        const int32_t* stamp, int32_t stamp_skip, void* stream) {
+  DMT_CHECK_ARG(to_step >= 0, "dmt_adam_catchup_rows_to: to_step must be >= 0");
+  return catchup_launch(tm, p, m, v, last_step, uniq_keys, n_uniq, max_uniq, state, lr_hist, beta1, beta2, eps, to_step, stamp, stamp_skip,
+                        stream, "dmt_adam_catchup_rows_to");
+}
+
+extern "C" int dmt_rows_stamp(const dmt_table_map* tm, const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq,
+                              int32_t* stamp, int32_t value, void* stream) {
+  DMT_CHECK_ARG(tm && uniq_keys && n_uniq && stamp && max_uniq > 0, "dmt_rows_stamp: bad argument");
+  const long long need = cdiv64(max_uniq, 256);
+  const unsigned nb = (unsigned)(need < 4096 ? need : 4096);
+  hipLaunchKernelGGL(rows_stamp_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *tm, uniq_keys, n_uniq, stamp, value);
+  DMT_CHECK_LAUNCH("dmt_rows_stamp");
   return DMT_OK;
 }
 

@@ -32,6 +32,8 @@ class TFAdam:
         self.max_steps = max_steps
         self.global_step = 0
         self._step_base = 0          # global_step at which the device-side step counter / lr history last restarted
+        self._begun = False          # begin() of the step in flight has run (it may run early: Trainer.train_step)
+        self.stamp = None            # int32 per local table row: "the optimizer step with this local number updates the row itself"
         self.tm = store.fill_table_map(L.TableMap())
 
     def current_lr(self) -> float:
@@ -45,14 +47,38 @@ class TFAdam:
         # the lr history holds one entry per step since the last restart of the device-side counter (reset_slots / rebase), NOT per
         # global step: a run resumed from model.ckpt-1500000 starts it at 0.  When it fills up, pending lazy rows are flushed (so no
         # row needs an older entry) and the history restarts; the Adam state (m, v, beta powers) is untouched.
+        if self._begun:              # (idempotent within a step: the Trainer calls it at the step's start, the optimizer phase again)
+            return
         if self.global_step - self._step_base + 1 >= self.max_steps:
             self.rebase()
         L.call("dmt_adam_begin_step", ops.p(self.state), ops.p(self.lr_hist), self.max_steps, float(self.current_lr()), self.b1,
                self.b2, ops.stream_ptr())
+        self._begun = True
 
     def end(self):
         L.call("dmt_adam_end_step", ops.p(self.state), self.b1, self.b2, ops.stream_ptr())
         self.global_step += 1
+        self._begun = False
+
+    def step_in_flight(self) -> int:
+        """Local number (index into the lr history) of the optimizer step between begin() and end()."""
+        assert self._begun
+        return self.global_step - self._step_base + 1
+
+    def stamp_rows(self, uniq, n_uniq, cap):
+        """Mark the rows the step in flight updates itself (call after begin()): catch_up_early leaves them alone."""
+        if self.stamp is None:
+            self.stamp = torch.zeros_like(self.store.last_step)
+        L.call("dmt_rows_stamp", C.byref(self.tm), ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self.stamp), self.step_in_flight(), ops.stream_ptr())
+
+    def catch_up_early(self, uniq, n_uniq, cap, to_step: int):
+        """EARLY catch-up of a later batch's rows while step `to_step` is in flight (its lr_t is in the history since begin()): rows that
+        step does not update (not stamped with its number) receive their pending zero-gradient updates THROUGH that step now -- the
+        same arithmetic the dense sweep applies to them at that step -- so nothing is left to replay in front of the next gather."""
+        s = self.store
+        L.call("dmt_adam_catchup_rows_to", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, int(to_step),
+               ops.p(self.stamp) if self.stamp is not None else None, int(to_step), ops.stream_ptr())
 
     def apply_dense(self, grad_scale: float = 1.0):
         s = self.store
@@ -100,6 +126,9 @@ class TFAdam:
         self.state[0], self.state[1] = self.b1, self.b2
         self.global_step = int(global_step)
         self._step_base = int(global_step)
+        self._begun = False
+        if self.stamp is not None:
+            self.stamp.zero_()
 
     def rebase(self):
         """Restart the per-step lr history without changing any value: replay every pending zero-gradient row update (flush), then
@@ -108,6 +137,8 @@ class TFAdam:
         L.call("dmt_adam_rebase", ops.p(self.state), ops.p(self.store.last_step), self.store.last_step.numel(), ops.stream_ptr())
         self.lr_hist.zero_()
         self._step_base = self.global_step
+        if self.stamp is not None:
+            self.stamp.zero_()           # (local step numbers restart: old stamps must not match new steps)
 
     def flush_tables(self):
         """Replay pending zero-gradient updates on every table row (before checkpoint / full-table export)."""

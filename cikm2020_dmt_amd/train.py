@@ -76,6 +76,12 @@ class Trainer:
         self.overlap_wgrads = (parallel.world()[1] > 1) if ov == "auto" else (ov == "1")
         self.sparse_lane = os.environ.get("DMT_SPARSE_LANE", "0") == "1"     # one-GPU step: id-bound tail beside the deferred weight gradients (off: even at L=50, -3 % at L=200)
         self.index_stream, self._ix_stream = os.environ.get("DMT_INDEX_STREAM", "1") == "1", None    # index plane (id sort, exchange plan) on a side stream: sync_rows
+        # lazy Adam: the pending zero-gradient updates of batch i + 1's rows can be replayed on the index lane WHILE step i runs
+        # (train_step(prefetch=)) instead of in front of step i + 1's gather.  Exact (tests/test_gpu_boundary.py), but OFF by default:
+        # the one-GPU step is throughput-bound, not latency-bound -- measured 10.12 ms with it against 10.01 ms without (the replay
+        # takes the same GPU time on the index lane, 0.83 ms, and slows the kernels it runs beside)
+        self.early_catchup = os.environ.get("DMT_EARLY_CATCHUP", "0") == "1"
+        self._inflight = None        # (event "begin() of the step in flight has run and its rows are stamped", that step's local number)
         if self.device.type == "cuda":
             streams.lanes(self.device)                     # bind the step's lanes to hardware queues before anything else (streams.py)
             if self._dp_active():
@@ -153,7 +159,28 @@ class Trainer:
         need_plan = self._needs_plan(for_training)
         prep = getattr(batch, "_prep", None)
         if prep is None or (need_plan and "xplan" not in prep):
-            self._index_plane(batch, need_plan)
+            prep = self._index_plane(batch, need_plan)
+        self._catch_up_early(prep)
+
+    def _catch_up_early(self, prep):
+        """Replay, on the index lane and while the current step is still running, the pending zero-gradient Adam updates of the rows a
+        LATER batch reads -- through the step in flight, for every row that step does not update itself (stamped rows: it brings
+        those up to date when it applies their gradient).  Exact: a zero-gradient update of step t needs (p, m, v) and lr_t only, and
+        lr_t is in the history since that step's begin().  Off the critical path: the replay (0.9 ms with real id gaps) used to sit
+        between the optimizer of one step and the gather of the next."""
+        infl, side = self._inflight, self._index_stream()
+        if infl is None or side is None or prep is None or "_caught" in prep or self.table_layout == "sharded":
+            return
+        ev_begun, to_step = infl
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_begun)
+            with self._span("adam_catchup_early"):
+                self.opt.catch_up_early(prep["uniq"], prep["n_uniq"], prep["cap"], to_step)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        prep["_caught"] = ev
+        _record_stream(prep, main)
 
     def sync_rows(self, batch: DeviceBatch, for_training: bool = True):
         """Bring the table rows this batch reads up to date (exact lazy Adam), before any kernel gathers them; in a data-parallel
@@ -162,9 +189,10 @@ class Trainer:
         prep = getattr(batch, "_prep", None)
         if prep is None or (need_plan and "xplan" not in prep):
             prep = self._index_plane(batch, need_plan)
-        ev = prep.pop("_ready", None)
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+        for key in ("_ready", "_caught"):
+            ev = prep.pop(key, None)
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
         if self.table_layout == "sharded":
             with self._span("row_fetch"):
                 self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
@@ -330,12 +358,37 @@ class Trainer:
         """exchange_rows_reduce + exchange_rows_collect in one go."""
         return self.exchange_rows_collect(self.exchange_rows_reduce(handle, plan))
 
-    def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False):
+    def _open_step(self, batch):
+        """train_step only: begin() of the optimizer step NOW (lr_t into the history, device step counter advanced) and stamp the rows
+        this step will update, so that the index lane may catch the next batch's other rows up through this step (prefetch)."""
+        self._inflight = None
+        if not self.early_catchup or self.table_layout == "sharded" or self._index_stream() is None:
+            return
+        prep = getattr(batch, "_prep", None)
+        if prep is None:
+            return
+        dp = self._dp_active()
+        plan = prep.get("xplan")
+        if dp and (self.dp_exchange != "owner" or plan is None or "all_k" not in plan):
+            return                       # (the one-shot exchange forms learn the union of the ranks' rows only after backward)
+        self.opt.begin()
+        if dp:
+            self.opt.stamp_rows(plan["all_k"], plan["n_dev"], int(plan["all_k"].numel()))     # every rank's rows: each replica applies them all
+        else:
+            self.opt.stamp_rows(prep["uniq"], prep["n_uniq"], prep["cap"])
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._inflight = (ev, self.opt.step_in_flight())
+
+    def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False,
+                         open_step: bool = False):
         """join=False (one-GPU train_step with the sparse lane): backward only collects the long-row weight gradients and leaves the
         embedding-gradient tail to the caller.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
         ops.reset_deferred_wgrads()       # (closures a step that raised half-way left behind reference that step's tensors)
         self.engine._pending_sparse = None
         self.sync_rows(batch)
+        if open_step:
+            self._open_step(batch)
         self.store.zero_grad()
         rank, _W = parallel.world()
         self.engine.dropout_step_seed = (self.dropout_seed + self.opt.global_step + 7919 * rank) if self.dropout else None
@@ -471,7 +524,8 @@ class Trainer:
         rank, W = parallel.world()
         dp = W > 1 or (self.force_dp and parallel.dist.is_initialized())
         plan_dp = dp and self.dp_exchange == "owner" and self.overlap_wgrads
-        loss = self.forward_backward(batch, join=dp, prefetch=prefetch, defer_wgrads=plan_dp)
+        loss = self.forward_backward(batch, join=dp, prefetch=prefetch, defer_wgrads=plan_dp, open_step=True)
+        self._inflight = None
         sparse = self.engine.sparse
         if not dp:
             lane = self._index_stream() if self.engine._pending_sparse is not None else None

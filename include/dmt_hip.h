@@ -365,6 +365,17 @@ int dmt_adam_sparse_rows_bf16(const dmt_table_map* tm, float* p, float* m, float
 int dmt_adam_catchup_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                           const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* state,
                           const float* lr_hist, float beta1, float beta2, float eps, void* stream);
+/* The same through an explicit step `to_step` (>= 0), skipping rows whose stamp[row] == stamp_skip (stamp may be NULL).  Used for the
+ * EARLY catch-up of the NEXT batch while an optimizer step is in flight: a zero-gradient update of step t needs only (p, m, v) and
+ * lr_t, which dmt_adam_begin_step has already written to lr_hist[t]; rows the step in flight updates itself (stamped by
+ * dmt_rows_stamp with that step's number) are left to it.  The dense-sweep result is unchanged (the same updates, applied earlier). */
+int dmt_adam_catchup_rows_to(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
+                             const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const float* state,
+                             const float* lr_hist, float beta1, float beta2, float eps, int32_t to_step, const int32_t* stamp,
+                             int32_t stamp_skip, void* stream);
+/* stamp[row] = value for the listed global rows (indexing as last_step: row / shard_w); keys >= the total row count are skipped. */
+int dmt_rows_stamp(const dmt_table_map* tm, const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, int32_t* stamp,
+                   int32_t value, void* stream);
 /* Bring every row of every table up to date (before checkpoint / evaluation of untouched rows).      */
 int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, int32_t* last_step,
                         const float* state, const float* lr_hist, float beta1, float beta2, float eps, void* stream);

@@ -207,3 +207,41 @@ def test_two_trainers_with_different_kernel_options_in_one_process(cuda):
         assert abs(v[0] - v[1]) < 1e-3 * abs(v[0]), (name, v)        # the same step twice (atomics: not bitwise)
     assert outs["fp8"][0] != outs["bf16"][0]                          # another arithmetic
     assert abs(outs["fp8"][0] - outs["bf16"][0]) < 5e-2 * abs(outs["bf16"][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_early_catch_up_of_the_next_batch_changes_nothing(cuda, monkeypatch, dtype):
+    """train_step(batch, prefetch=next): the pending zero-gradient Adam updates of the next batch's rows are replayed on the index lane
+    while the current step runs (Trainer._catch_up_early) instead of in front of the next gather.  Same arithmetic, applied earlier:
+    in deterministic mode six steps over batches with disjoint and overlapping ids end in bit-identical variables, Adam slots and
+    last-touch steps, with and without it; and with it the catch-up in front of the gather finds nothing left to replay."""
+    from cikm2020_dmt_amd import _lib as L
+    from cikm2020_dmt_amd import ops
+    so, sp = small_specs()
+    P = O.init_params(so, seed=3)
+    batches = [make_batch(sp, 9, seed=60 + (i % 4), lengths="ragged", weights="random") for i in range(7)]      # ids recur with gaps of 1..4 steps
+    res = []
+    ops.set_deterministic(True)
+    try:
+        for early in (True, False):
+            tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=True, dropout_seed=5)
+            tr.early_catchup = early
+            tr.store.load_state(P)
+            bs = [tr.make_batch(i, m) for (i, m, _l) in batches]
+            losses = []
+            for s in range(6):
+                losses.append(float(tr.train_step(bs[s], prefetch=bs[s + 1])))
+            assert (tr.opt.stamp is not None) == early
+            last = tr.store.last_step.clone()
+            tr.opt.flush_tables()                  # every row through the last step: what a dense sweep holds
+            torch.cuda.synchronize()
+            res.append((losses, tr.store.tab_p.clone(), tr.store.tab_m.clone(), tr.store.tab_v.clone(), last, tr.store.params.clone()))
+    finally:
+        ops.set_deterministic(False)
+    a, b = res
+    assert a[0] == b[0]
+    for x, y in zip(a[1:4], b[1:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[5], b[5])
+    # the early pass leaves rows of the prefetched batch at a LATER last-touch step than the lazy form (they are already up to date)
+    assert bool((a[4] >= b[4]).all()) and bool((a[4] > b[4]).any())
