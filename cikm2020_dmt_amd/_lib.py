@@ -162,8 +162,8 @@ _SIGS = {
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "dmt_cast_transpose_bf16_batched": [c_i32, c_vp, c_i32, c_vp],
-    "dmt_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_vp, c_vp],
-    "dmt_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_vp],
+    "dmt_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_vp, c_i32, c_vp],
+    "dmt_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],

@@ -142,8 +142,13 @@ class Conf:
         if self[MODEL][IS_BN] or self[MODEL][IS_DROPOUT]:
             raise NotImplementedError("is_bn / is_dropout are false in dmt.conf and not implemented")
         if str(self[PARAMETER].get(LOSS_WEIGHT_METHOD, "fixed")).strip() != "fixed":
-            raise NotImplementedError("loss_weight_method = %s: only 'fixed' (dmt.conf) is implemented; 'uncertainty' learns "
-                                      "click_weight / order_weight (inference_mlp.py:244-253)" % self[PARAMETER].get(LOSS_WEIGHT_METHOD))
+            # inference_mlp.py:216-219, 251-254 weights the task losses by exp(-model.click_weight) / exp(-model.order_weight); those two
+            # variables ('uncertainty_click_weight' / 'uncertainty_order_weight') are created by model/net/multi_task.py:124-128 and
+            # multi_task_transformer.py:181-185 ONLY -- mmoe_transformer[_unbias].py (the DMT model this path rebuilds) and base.py never
+            # define them, so the reference itself fails with AttributeError for this model type.  Same outcome here, said plainly.
+            raise NotImplementedError("loss_weight_method = %s: the DMT model (mmoe_transformer[_unbias]) has no uncertainty_click_weight / "
+                                      "uncertainty_order_weight variables in the reference either (only multi_task*.py creates them); "
+                                      "use 'fixed' (dmt.conf)" % self[PARAMETER].get(LOSS_WEIGHT_METHOD))
         m = self[MODEL]
         return dict(
             embedding_list=[tuple(e) for e in self.embedding_list], embedding_list_bias=[tuple(e) for e in self.embedding_list_bias],

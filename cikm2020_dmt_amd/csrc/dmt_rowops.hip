@@ -540,7 +540,7 @@ constexpr float SM_PADDING_NUM = -4294967295.0f;   // -2**32 + 1
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int Tq, int Tk, T* __restrict__ S, long long ld,
                                                           const int* __restrict__ q_lens, const int* __restrict__ k_lens, float scale,
-                                                          int drop_on, uint32_t seed, uint32_t thr24, float inv_keep, T* __restrict__ P) {
+                                                          int drop_on, uint32_t seed, uint32_t thr24, float inv_keep, T* __restrict__ P, int causal) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)B * H * Tq) return;
@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int Tq, 
   const int b = (int)(row / ((long long)H * Tq));
   int klen = k_lens ? k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  // future blinding (TransformerModel_util.py:34-36, 99-105: mask(type="future") after the key mask): keys k > q get the padding value too
+  if (causal && klen > q + 1) klen = q + 1;
   const int qlen = q_lens ? q_lens[b] : Tq;
   T* s = S + row * ld;
   T* p = P + row * ld;
@@ -581,7 +583,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int Tq, int Tk, const T* __restrict__ P, T* __restrict__ dPS,
                                                           T* __restrict__ Pd, long long ld, const int* __restrict__ q_lens,
                                                           const int* __restrict__ k_lens, float scale, int drop_on, uint32_t seed,
-                                                          uint32_t thr24, float inv_keep) {
+                                                          uint32_t thr24, float inv_keep, int causal) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)B * H * Tq) return;
@@ -589,6 +591,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int Tq, 
   const int b = (int)(row / ((long long)H * Tq));
   int klen = k_lens ? k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
+  if (causal && klen > q + 1) klen = q + 1;
   const int qlen = q_lens ? q_lens[b] : Tq;
   const bool qpad = q >= qlen;
   const T* p = P + row * ld;
@@ -910,7 +913,7 @@ extern "C" int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_jo
 }
 
 extern "C" int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* S, int64_t ld, const int32_t* q_lens,
-                               const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, void* stream) {
+                               const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, int32_t causal, void* stream) {
   DMT_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0 && S && P && ld >= Tk, "dmt_softmax_fwd: bad argument");
   DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_softmax_fwd: bad dtype");
   DMT_CHECK_ARG((long long)B * H * Tq * Tk < 0xFFFFFFFFll, "dmt_softmax_fwd: B*H*Tq*Tk exceeds the 32-bit dropout counter");
@@ -920,15 +923,15 @@ extern "C" int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, 
   const unsigned nb = (unsigned)cdiv64((long long)B * H * Tq, 4);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DMT_F32)
-    hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (float*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (float*)P);
+    hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (float*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (float*)P, causal);
   else
-    hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (bf16_t*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (bf16_t*)P);
+    hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (bf16_t*)S, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, (bf16_t*)P, causal);
   DMT_CHECK_LAUNCH("dmt_softmax_fwd");
   return DMT_OK;
 }
 
 extern "C" int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, const void* P, void* dP_dS, void* Pd, int64_t ld,
-                               const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* stream) {
+                               const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, int32_t causal, void* stream) {
   DMT_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0 && P && dP_dS && Pd && ld >= Tk, "dmt_softmax_bwd: bad argument");
   DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_softmax_bwd: bad dtype");
   const int drop_on = (drop_keep > 0.f && drop_keep < 1.f) ? 1 : 0;
@@ -937,9 +940,9 @@ extern "C" int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, 
   const unsigned nb = (unsigned)cdiv64((long long)B * H * Tq, 4);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DMT_F32)
-    hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const float*)P, (float*)dP_dS, (float*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv);
+    hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const float*)P, (float*)dP_dS, (float*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, causal);
   else
-    hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const bf16_t*)P, (bf16_t*)dP_dS, (bf16_t*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv);
+    hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, B, H, Tq, Tk, (const bf16_t*)P, (bf16_t*)dP_dS, (bf16_t*)Pd, (long long)ld, q_lens, k_lens, scale, drop_on, drop_seed, thr, inv, causal);
   DMT_CHECK_LAUNCH("dmt_softmax_bwd");
   return DMT_OK;
 }

@@ -65,14 +65,16 @@ def mask(inputs, query_masks=None, key_masks=None, type=None):
         h = inputs.shape[0] // query_masks.shape[0]
         qm = query_masks.bool().repeat(h, 1)[:, :, None].expand_as(inputs)
         return torch.where(qm, inputs, torch.full_like(inputs, PADDING_NUM))
-    raise NotImplementedError("mask type %r (causality is never used by DMT)" % (type,))
+    if type in ("f", "future", "right"):
+        Tq, Tk = inputs.shape[1], inputs.shape[2]
+        tril = torch.ones((Tq, Tk), dtype=torch.bool, device=inputs.device).tril()
+        return torch.where(tril[None], inputs, torch.full_like(inputs, PADDING_NUM))
+    raise ValueError("mask type %r (the reference prints 'Check if you entered type correctly!')" % (type,))
 
 
 def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, causality=False, dropout_rate=0., training=True,
                                  scope="scaled_dot_product_attention"):
     """Q,K,V: [h*N, T, d_k] head-major packing of the reference; masks [N, T] bool / 0-1.  Returns [h*N, T_q, d_k]."""
-    if causality:
-        raise NotImplementedError("causality=True is never used by DMT")
     seed, keep = _attn_dropout(dropout_rate, training, 2)
     N = key_masks.shape[0]
     h = Q.shape[0] // N
@@ -85,16 +87,15 @@ def scaled_dot_product_attention(Q, K, V, query_masks, key_masks, causality=Fals
     q_lens = query_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
     k_lens = key_masks.to(torch.int32).sum(1).to(torch.int32).contiguous()
     kv = torch.cat([k, v], dim=-1)
-    out = ops.AttnFn.apply(q, kv, None, q_lens, k_lens, h, h * dk, False, seed, keep)
+    out = ops.AttnFn.apply(q, kv, None, q_lens, k_lens, h, h * dk, False, seed, keep, None, bool(causality))
     return torch.cat(torch.split(out, dk, dim=2), dim=0)
 
 
 def multihead_attention(queries, keys, values, queries_length, keys_length, num_heads=8, dropout_rate=0, training=True,
                         causality=False, scope="multihead_attention"):
-    if causality:
-        raise NotImplementedError("causality=True is never used by DMT")
-    if values is not keys:
-        raise NotImplementedError("DMT always attends with values = keys")
+    """causality=True (future blinding) and values != keys are kept for signature parity (TransformerModel_util.py:160-209); DMT's own
+    graph uses neither (TransformerModel.py:117, 165: causality=False, values = keys).  Both take the same kernels: causality through the
+    unfused score / softmax / value launches (dmt_softmax_fwd's `causal`), separate values through a second projection launch."""
     d = queries.shape[-1]
     with R.variable_scope(scope):
         wl, w = _leaf("qkv_kernel")
@@ -104,15 +105,22 @@ def multihead_attention(queries, keys, values, queries_length, keys_length, num_
     eng = R.get_default().engine
     ql = queries_length.to(torch.int32).contiguous() if queries_length is not None else None
     kl = keys_length.to(torch.int32).contiguous()
-    if queries is keys:
+    causal = bool(causality)
+    if queries is keys and values is keys:
         seed, keep = _attn_dropout(dropout_rate, training, 2)
         qkv = ops.linear(queries, wl, bl, w)
-        s = ops.AttnFn.apply(qkv, None, queries, ql, kl, num_heads, d, True, seed, keep)
+        s = ops.AttnFn.apply(qkv, None, queries, ql, kl, num_heads, d, True, seed, keep, None, causal)
     else:
         seed, keep = _attn_dropout(dropout_rate, training, 3)
         q = ops.linear(queries, wl[:, :d], bl[:d], eng._wslice(w, 0, d))
-        kv = ops.linear(keys, wl[:, d:], bl[d:], eng._wslice(w, d, 3 * d))
-        s = ops.AttnFn.apply(q, kv, queries, ql, kl, num_heads, d, False, seed, keep)
+        if values is keys:
+            kv = ops.linear(keys, wl[:, d:], bl[d:], eng._wslice(w, d, 3 * d))
+        else:
+            # K = keys W_k + b_k (dense_1), V = values W_v + b_v (dense_2): two projections, packed side by side for the attention core
+            kk = ops.linear(keys, wl[:, d:2 * d], bl[d:2 * d], eng._wslice(w, d, 2 * d))
+            vv = ops.linear(values, wl[:, 2 * d:], bl[2 * d:], eng._wslice(w, 2 * d, 3 * d))
+            kv = torch.cat([kk, vv], dim=-1)
+        s = ops.AttnFn.apply(q, kv, queries, ql, kl, num_heads, d, False, seed, keep, None, causal)
     return ops.layer_norm(s, gamma, beta, 1e-8)
 
 
@@ -132,13 +140,36 @@ def ff(inputs, num_units, scope="positionwise_feedforward"):
 
 def positional_encoding_learn(inputs, maxlen, masking=False, scope="positional_encoding_learn"):
     """Returns P[0:T] broadcast to inputs' shape (lookup by range(T))."""
-    if masking:
-        raise NotImplementedError("masking=True is never used by DMT")
     with R.variable_scope(scope):
         pos, _ = _leaf("embedding_position_learn")
     zeros = torch.zeros_like(inputs)
-    return ops.ScaleAddPosFn.apply(zeros, pos, 0.0)
+    out = ops.ScaleAddPosFn.apply(zeros, pos, 0.0)
+    if masking:          # :311-312: positions whose INPUT element is 0 keep the input (i.e. 0)
+        out = torch.where(inputs == 0, inputs, out)
+    return out
+
+
+_SINCOS = {}
 
 
 def positional_encoding(inputs, maxlen, masking=False, scope="positional_encoding"):
-    raise NotImplementedError("sinusoidal positions: dmt.conf uses transformer_position_encoding_method=position_learn")
+    """Sinusoidal positions (TransformerModel_util.py:238-279): PE[pos, i] = pos / 10000^((i - i % 2) / E), sin on the even columns,
+    cos on the odd ones, computed in float64 on the host as the reference does (numpy) and kept as a float32 constant per
+    (maxlen, E, device); returns PE[0:T] broadcast to the inputs' shape.  No variable is created (the reference's is a constant too)."""
+    import numpy as np
+    E, T = int(inputs.shape[-1]), int(inputs.shape[1])
+    if T > maxlen:
+        raise ValueError("positional_encoding: sequence length %d exceeds maxlen %d" % (T, maxlen))
+    key = (int(maxlen), E, str(inputs.device))
+    tab = _SINCOS.get(key)
+    if tab is None:
+        i = np.arange(E)
+        enc = np.arange(maxlen, dtype=np.float64)[:, None] / np.power(10000.0, (i - i % 2) / float(E))[None, :]
+        enc[:, 0::2] = np.sin(enc[:, 0::2])
+        enc[:, 1::2] = np.cos(enc[:, 1::2])
+        tab = torch.tensor(enc.astype(np.float32), device=inputs.device)
+        _SINCOS[key] = tab
+    out = ops.ScaleAddPosFn.apply(torch.zeros_like(inputs), tab, 0.0).float()
+    if masking:          # :271-272
+        out = torch.where(inputs == 0, inputs.float(), out)
+    return out

@@ -827,7 +827,7 @@ def long_fused_ok(H, *tensors, opts=None):
     return all(_rows16(t) for t in tensors)
 
 
-def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep):
+def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, causal=False):
     """T > 64 (BASELINE "long-seq variant", L = 200): S = Q K^T, P = softmax(mask(S / sqrt(dh))), out = dropout(P) V + resid as
     batched dmt_gemm launches (one per head, batch = B) around dmt_softmax_fwd.  Returns P (before dropout) for the backward."""
     B, Tq, d = q.shape
@@ -840,7 +840,7 @@ def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
         gemm(q[..., sl], q.stride(1), 1, k[..., sl], 1, k.stride(1), Tq, Tk, dh, S[:, h], ldp, batch=B, a_bs=q.stride(0), b_bs=k.stride(0),
              c_bs=H * Tq * ldp)
     L.call("dmt_softmax_fwd", dt_code(q.dtype), B, H, Tq, Tk, p(S), ldp, p(q_lens), p(k_lens), 1.0 / float(dh) ** 0.5, int(drop_seed),
-           float(drop_keep), p(P), stream_ptr())
+           float(drop_keep), p(P), 1 if causal else 0, stream_ptr())
     for h in range(H):
         sl = slice(h * dh, (h + 1) * dh)
         kw = {}
@@ -851,7 +851,7 @@ def _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
     return P
 
 
-def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep):
+def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal=False):
     """dP = dO V^T; dS = softmax'(P, dP); dQ = dS K; dK = dS^T Q; dV = dropout(P)^T dO -- batched GEMMs around dmt_softmax_bwd."""
     B, Tq, d = q.shape
     Tk, dh = k.shape[1], d // H
@@ -864,7 +864,7 @@ def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, d
         gemm(dout[..., sl], dout.stride(1), 1, v[..., sl], 1, v.stride(1), Tq, Tk, dh, dS[:, h], ldp, batch=B, a_bs=dout.stride(0),
              b_bs=v.stride(0), c_bs=cb)
     L.call("dmt_softmax_bwd", dt_code(q.dtype), B, H, Tq, Tk, p(P), p(dS), p(Pd), ldp, p(q_lens), p(k_lens), 1.0 / float(dh) ** 0.5,
-           int(drop_seed), float(drop_keep), stream_ptr())
+           int(drop_seed), float(drop_keep), 1 if causal else 0, stream_ptr())
     for h in range(H):
         sl = slice(h * dh, (h + 1) * dh)
         gemm(dS[:, h], ldp, 1, k[..., sl], k.stride(1), 1, Tq, dh, Tk, dq[..., sl], dq.stride(1), batch=B, a_bs=cb, b_bs=k.stride(0),
@@ -875,13 +875,14 @@ def _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, d
              c_bs=dv.stride(0))
 
 
-def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts=None):
-    """Returns what the backward needs beyond its inputs: None (fused kernels recompute P) or the saved P of the long form."""
+def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts=None, causal=False):
+    """Returns what the backward needs beyond its inputs: None (fused kernels recompute P) or the saved P of the long form.
+    causal (future blinding; never set by DMT's own graph) takes the unfused form at every length."""
     B, Tq, d = q.shape
     Tk = k.shape[1]
     opts = opts or DEFAULT_OPTIONS
-    if max(Tq, Tk) > ATTN_FUSED_MAX_T and not long_fused_ok(H, q, k, v, resid, out, opts=opts):
-        return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep)
+    if causal or (max(Tq, Tk) > ATTN_FUSED_MAX_T and not long_fused_ok(H, q, k, v, resid, out, opts=opts)):
+        return _long_attn_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, causal)
     desc = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, resid, out, mma_fp8=opts.attn_mma_fp8)
     desc.drop_seed, desc.drop_keep = int(drop_seed), float(drop_keep)
     with _Timed("attn_long" if max(Tq, Tk) > ATTN_FUSED_MAX_T else "attn", 4.0 * B * Tq * Tk * d):
@@ -889,11 +890,11 @@ def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, 
     return None
 
 
-def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep):
+def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal=False):
     B, Tq, d = q.shape
     Tk = k.shape[1]
     if P is not None:
-        return _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep)
+        return _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal)
     bd = L.AttnBwdDesc()
     bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
     bd.f.drop_seed, bd.f.drop_keep = int(drop_seed), float(drop_keep)
@@ -910,7 +911,7 @@ class AttnFn(torch.autograd.Function):
     their gradients are written straight into one packed buffer per distinct base tensor (`pack`)."""
 
     @staticmethod
-    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn, drop_seed=0, drop_keep=1.0, opts=None):
+    def forward(ctx, packed_q, packed_kv, resid, q_lens, k_lens, H, d, self_attn, drop_seed=0, drop_keep=1.0, opts=None, causal=False):
         # self_attn: packed_q is [B,T,3d] = (Q|K|V), packed_kv is None.
         # cross:     packed_q is [B,Tq,d] = Q, packed_kv is [B,Tk,2d] = (K|V).
         if self_attn:
@@ -921,9 +922,9 @@ class AttnFn(torch.autograd.Function):
             q, k, v = packed_q, packed_kv[..., :d], packed_kv[..., d:]
         B, Tq, Tk = q.shape[0], q.shape[1], k.shape[1]
         out = torch.empty((B, Tq, d), dtype=q.dtype, device=q.device)
-        ctx.P = attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts)
+        ctx.P = attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, opts, causal)
         ctx.save_for_backward(packed_q, packed_kv, q_lens, k_lens)
-        ctx.H, ctx.d, ctx.self_attn = H, d, self_attn
+        ctx.H, ctx.d, ctx.self_attn, ctx.causal = H, d, self_attn, bool(causal)
         ctx.drop = (int(drop_seed), float(drop_keep))
         ctx.has_resid = resid is not None
         return out
@@ -944,9 +945,9 @@ class AttnFn(torch.autograd.Function):
             dpq = torch.empty_like(packed_q)
             dpkv = torch.empty_like(packed_kv)
             dq, dk, dv = dpq, dpkv[..., :d], dpkv[..., d:]
-        attn_core_bwd(q, k, v, q_lens, k_lens, ctx.P, dout, dq, dk, dv, H, *ctx.drop)
+        attn_core_bwd(q, k, v, q_lens, k_lens, ctx.P, dout, dq, dk, dv, H, *ctx.drop, causal=ctx.causal)
         ctx.P = None
-        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None, None
+        return dpq, dpkv, (dout if ctx.has_resid else None), None, None, None, None, None, None, None, None, None
 
 
 def q1mem_supported(d, H, T, dtype=BF16):

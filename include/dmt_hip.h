@@ -408,14 +408,15 @@ int dmt_cast_transpose_bf16_batched(int32_t n_jobs, const dmt_cast_job* jobs_dev
  * S = Q K^T and the products around it run as batched dmt_gemm launches; these do what lies between them
  * (model/net/TransformerModel_util.py:11-56 scaled_dot_product_attention, :80-108 mask).  S [B, H, Tq, ld] holds the raw
  * scores on entry and the dropped weights (A operand of P.V) on return; P receives the weights before dropout (saved for
- * the backward).  Same masking rules, padding value and dropout counter as dmt_attn_fwd.                               */
+ * the backward).  Same masking rules, padding value and dropout counter as dmt_attn_fwd.  causal != 0: future blinding
+ * (mask(type="future"), :34-36, 99-105): key k of query q also gets the padding value when k > q.                      */
 int dmt_softmax_fwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* S, int64_t ld, const int32_t* q_lens,
-                    const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, void* stream);
+                    const int32_t* k_lens, float scale, uint32_t drop_seed, float drop_keep, void* P, int32_t causal, void* stream);
 /* dP_dS: gradient w.r.t. the dropped weights on entry, dS (gradient of the scaled scores' pre-image Q K^T) on return;
  * Pd receives the dropped weights again (the operand of dV = Pd^T dO).                                                */
 int dmt_softmax_bwd(int32_t dtype, int32_t B, int32_t H, int32_t Tq, int32_t Tk, const void* P, void* dP_dS, void* Pd,
                     int64_t ld, const int32_t* q_lens, const int32_t* k_lens, float scale, uint32_t drop_seed,
-                    float drop_keep, void* stream);
+                    float drop_keep, int32_t causal, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused position-wise feed-forward + LayerNorm (bf16): two chained MFMA GEMMs whose d_ff-wide intermediate stays on the

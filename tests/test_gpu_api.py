@@ -113,3 +113,95 @@ def test_transformer_util_functions_under_scopes(cuda):
     with R.variable_scope(pre.rstrip("/")), R.variable_scope("num_blocks_0"):
         with pytest.raises(RuntimeError, match="dropout_step_seed"):
             TU.multihead_attention(xd, xd, xd, ld, ld, num_heads=4, dropout_rate=0.1, training=True, scope="self-attention")
+
+
+def _mha_reference(q_in, k_in, v_in, q_len, k_len, H, P, s, causal):
+    """TransformerModel_util.py:160-209 + :11-56 + :80-108 in float64 torch (autograd gives the gradients): key mask, future mask
+    (causality), softmax, query mask, weighted sum, residual, ln."""
+    B, Tq, d = q_in.shape
+    Tk, dh = k_in.shape[1], d // H
+    Q = (q_in @ P[s + "dense/kernel"] + P[s + "dense/bias"]).view(B, Tq, H, dh).transpose(1, 2)
+    K = (k_in @ P[s + "dense_1/kernel"] + P[s + "dense_1/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    V = (v_in @ P[s + "dense_2/kernel"] + P[s + "dense_2/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    S = (Q @ K.transpose(-1, -2)) / (dh ** 0.5)
+    pad = torch.full_like(S, float(-2 ** 32 + 1))
+    S = torch.where((torch.arange(Tk)[None, :] < k_len[:, None])[:, None, None, :], S, pad)
+    if causal:
+        S = torch.where(torch.ones(Tq, Tk, dtype=torch.bool).tril()[None, None], S, pad)
+    A = torch.softmax(S, dim=-1)
+    A = torch.where((torch.arange(Tq)[None, :] < q_len[:, None])[:, None, :, None], A, pad)
+    O = (A @ V).transpose(1, 2).reshape(B, Tq, d) + q_in
+    mu = O.mean(-1, keepdim=True)
+    var = (O - mu).pow(2).mean(-1, keepdim=True)
+    return P[s + "ln/gamma"] * (O - mu) * torch.rsqrt(var + 1e-8) + P[s + "ln/beta"]
+
+
+@pytest.mark.parametrize("causal,sep_values", [(True, False), (False, True), (True, True)])
+def test_multihead_attention_causality_and_separate_values(cuda, causal, sep_values):
+    """The two signature options DMT's own graph never sets (TransformerModel.py:117, 165): causality=True (future blinding,
+    TransformerModel_util.py:34-36, 99-105) and values != keys -- forward and every gradient against the formulas restated above."""
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    rng = np.random.default_rng(7)
+    B, T, d = 5, 11, sp["d_model"]
+    x = rng.standard_normal((B, T, d)); v = rng.standard_normal((B, T, d)) if sep_values else x
+    lens = rng.integers(1, T + 1, size=B); lens[0] = T
+    pre = S.trans_prefix(0)
+    blk = pre + "num_blocks_0/"
+    a = blk + ("vanilla_attention/" if sep_values else "self-attention/")
+    st = inf.rt.store
+    st.zero_grad()
+    xd = torch.tensor(x, dtype=torch.float32, device=cuda, requires_grad=True)
+    vd = torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=True) if sep_values else xd
+    kd = xd.detach().clone().requires_grad_(True) if sep_values else xd          # (keys: a tensor of their own, so `queries is keys` is false)
+    ld = torch.tensor(lens, dtype=torch.int32, device=cuda)
+    w = rng.standard_normal((B, T, d))
+    with R.variable_scope(pre.rstrip("/")), R.variable_scope("num_blocks_0"):
+        out = TU.multihead_attention(xd, kd, vd if sep_values else kd, ld, ld, num_heads=4, dropout_rate=0, training=False, causality=causal,
+                                     scope="vanilla_attention" if sep_values else "self-attention")
+    (out * torch.tensor(w, dtype=torch.float32, device=cuda)).sum().backward()
+    Pt = {k: torch.tensor(val, dtype=torch.float64, requires_grad=True) for k, val in P.items() if k.startswith(a)}
+    xq = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    kq = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    vq = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    if sep_values:
+        ref = _mha_reference(xq, kq, vq, torch.tensor(lens), torch.tensor(lens), 4, Pt, a, causal)
+    else:
+        ref = _mha_reference(xq, xq, xq, torch.tensor(lens), torch.tensor(lens), 4, Pt, a, causal)
+    (ref * torch.tensor(w)).sum().backward()
+    valid = (np.arange(T)[None, :] < lens[:, None])[:, :, None]
+    got, want = _np(out), ref.detach().numpy()
+    assert (np.abs(got - want) * valid).max() < 1e-4 and (np.abs(got - want) / (np.abs(want) + 1.0)).max() < 1e-4
+    if causal:       # future blinding: query 0 attends to key 0 only -> its context is V[0]
+        assert np.isfinite(got).all()
+    assert np.abs(_np(xd.grad) - xq.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(xq.grad.numpy()).max())
+    if sep_values:
+        assert np.abs(_np(kd.grad) - kq.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(kq.grad.numpy()).max())
+        assert np.abs(_np(vd.grad) - vq.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(vq.grad.numpy()).max())
+    G = st.grad_dict()
+    for nm in ("dense/kernel", "dense_1/kernel", "dense_2/kernel", "dense_2/bias", "ln/gamma", "ln/beta"):
+        r = Pt[a + nm].grad.numpy()
+        assert np.abs(G[a + nm] - r).max() < 3e-4 * max(1.0, np.abs(r).max()), nm
+
+
+def test_sinusoidal_positions_and_masking_flags(cuda):
+    """positional_encoding (TransformerModel_util.py:238-279) and the masking=True branches (:271-272, 311-312)."""
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    B, T, E, maxlen = 3, 7, sp["d_model"], 50
+    x = torch.randn((B, T, E), device=cuda)
+    x[1, 3:, :] = 0.0
+    x[0, 0, 5] = 0.0
+    pe = TU.positional_encoding(x, maxlen)
+    enc = np.array([[pos / np.power(10000, (i - i % 2) / E) for i in range(E)] for pos in range(maxlen)])
+    enc[:, 0::2] = np.sin(enc[:, 0::2]); enc[:, 1::2] = np.cos(enc[:, 1::2])
+    want = np.broadcast_to(enc[None, :T].astype(np.float32), (B, T, E))
+    assert np.abs(_np(pe) - want).max() < 1e-6
+    pem = _np(TU.positional_encoding(x, maxlen, masking=True))
+    z = _np(x) == 0
+    assert np.abs(pem[z]).max() == 0.0 and np.abs(pem[~z] - want[~z]).max() < 1e-6
+    with R.variable_scope(S.trans_prefix(0).rstrip("/")):
+        pl = _np(TU.positional_encoding_learn(x, maxlen, masking=True, scope="positional_encoding_k_position_learn"))
+    tab = P[S.trans_prefix(0) + "positional_encoding_k_position_learn/embedding_position_learn"][:T]
+    wantl = np.broadcast_to(tab[None].astype(np.float32), (B, T, E))
+    assert np.abs(pl[z]).max() == 0.0 and np.abs(pl[~z] - wantl[~z]).max() < 1e-6
+    with pytest.raises(ValueError):
+        TU.positional_encoding(x, 3)
