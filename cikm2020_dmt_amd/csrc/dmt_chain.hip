@@ -6,9 +6,10 @@
 //   mode DMT_CHAIN_FFN_BWD   dx = ((ds W2^T) * [h > 0]) W1^T + ds         its input gradient (the relu gate is a bit mask the
 //                                                                          forward wrote: one bit per element of h)
 //
-// Shape of the computation (one workgroup = 4 wavefronts = 128 rows, one wavefront per SIMD, up to 512 registers):
-//   * a wavefront owns 32 rows.  Its input rows stay in REGISTERS as MFMA B fragments for the whole tile (KIN / 16 fragments), its
-//     output tile out^T [NOUT x 32] stays in the accumulators (NOUT / 32 tiles of 16 registers);
+// Shape of the computation (one workgroup = 8 wavefronts = 4 producer / consumer pairs = 128 rows, two wavefronts per SIMD):
+//   * a pair owns 32 rows.  The producer keeps the input rows in REGISTERS as MFMA B fragments for the whole tile (KIN / 16 fragments)
+//     and multiplies them with one 32-column slice of A1 per step; the consumer keeps the output tile out^T [NOUT x 32] in its
+//     accumulators (NOUT / 32 tiles of 16 registers) and multiplies the handed-over mid tile with the matching slice of A2;
 //   * the weights stream HBM/L2 -> LDS by DMA (buffer_load ... lds) as a ring of three stages; stage jt holds the 32 mid columns
 //     jt*32 .. +32: the A1 rows that produce them (32 x KIN) and the A2 columns that consume them (NOUT x 32).  Both lie in a
 //     prebuilt bf16 IMAGE (dmt_chain_image_build) in exactly the byte order of the LDS stage, row strides padded to an odd number of
@@ -147,7 +148,6 @@ struct ChainArgs {
   bf16_t* mid_out; long long ld_mid;
   unsigned short* mask;
   int tiles;
-  int relax;      // side-output stores per mid tile a producer may leave open across the stage wait (see top())
 };
 
 // LDS fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) while an LDS-DMA is in
@@ -249,10 +249,8 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
       const long long mc = mvalid ? m : (g.M - 1);
       const long long blk = row0 >> 5;
 
-      // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
-      // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
-      // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
-      // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
+      // top of an iteration, both roles: stage gs has landed (the consumers, which issued its pieces, have seen them retire) and
+      // everybody has left stage gs - 1
       auto top = [&](int u) {
         if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -397,10 +395,8 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
       const long long mc = mvalid ? m : (g.M - 1);
       const long long blk = row0 >> 5;
 
-      // top of an iteration, both roles: stage gs has landed for every wavefront, everybody has left stage gs - 1
-      // vmcnt retires in issue order (loads and stores alike: the compiler's own waits assume it), so "stage gs has landed" = at most
-      // the PER_WAVE pieces of stage gs + 1 and whatever was issued AFTER them are open: a producer's side-output stores of the
-      // previous mid tile (relax = 3: gate bits + two h pieces; 2 in the gradient pass) need not have reached the L2.
+      // top of an iteration, both roles: stage gs has landed (the consumers, which issued its pieces, have seen them retire) and
+      // everybody has left stage gs - 1
       auto top = [&](int u) {
         if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -590,14 +586,6 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
   a.mid_out = (bf16_t*)d->mid_out; a.ld_mid = d->ld_mid;
   a.mask = (unsigned short*)d->mask;
   a.tiles = (int)cdiv64(d->M, 128);
-  a.relax = 0;
-  {
-    const char* rl = getenv("DMT_CHAIN_RELAX");
-    if (!(rl && atoi(rl) == 0)) {
-      if (d->mode == DMT_CHAIN_FFN_LN && a.mid_out != nullptr && a.mask != nullptr) a.relax = 3;
-      if (d->mode == DMT_CHAIN_FFN_BWD && a.mid_out != nullptr) a.relax = 2;
-    }
-  }
   const int grid = a.tiles < 256 ? a.tiles : 256;
   if constexpr (G::KIN == 320) {
     const char* dbg = getenv("DMT_CHAIN_DEBUG");   // timing experiments (see DBG above); never set in production

@@ -6,7 +6,9 @@ tower gradients by run_dnn.py:203-207; learning rate = tf.train.piecewise_consta
 learning_rate) (run_dnn.py:125-126, dmt.conf:79-80).
 The reference densifies the IndexedSlices embedding gradients (run_dnn.py:45-80) so TF sweeps all 167 M table
 parameters every step; `dmt_adam_sparse_rows` reproduces that arithmetic bit-for-bit but only touches rows when
-they are next read (zero-gradient steps are replayed on the way in), see DESIGN.md §Adam.
+they are next read (zero-gradient steps are replayed on the way in), see DESIGN.md §Adam.  Exactness: p is bit-identical to the dense
+sweep for any gap; m and v are bit-identical for gaps up to ~150 + 64 steps and agree to ~1e-5 relative beyond (closed-form tail).
+The learning-rate schedule must be non-increasing (checked in __init__).
 """
 from __future__ import annotations
 
@@ -24,6 +26,13 @@ class TFAdam:
         self.store = store
         self.lrs = list(learning_rate) if isinstance(learning_rate, (list, tuple)) else [float(learning_rate)]
         self.bounds = list(step_boundary)[: len(self.lrs) - 1]
+        # The lazy rows' replay stops replaying p at the first zero-gradient step that no longer changes it and treats that as final
+        # (csrc/dmt_optim.hip:catch_up).  True while lr_t never grows by more than the bias correction does -- i.e. for a non-increasing
+        # piecewise schedule, which is what the reference runs (dmt.conf:79-80: 0.001 -> 0.0001).  A warm-up schedule could move p again
+        # after it stopped, and the lazy rows would then differ from the dense sweep: refuse it instead of being silently inexact.
+        if any(b > a for a, b in zip(self.lrs[:-1], self.lrs[1:])):
+            raise ValueError("TFAdam: learning_rate %s increases; the exact lazy-row replay needs a non-increasing piecewise-constant "
+                             "schedule (the reference's is: dmt.conf learning_rate = 0.001, 0.0001)" % (self.lrs,))
         self.b1, self.b2, self.eps = float(beta1), float(beta2), float(epsilon)
         dev = store.device
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)

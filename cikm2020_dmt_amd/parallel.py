@@ -34,7 +34,13 @@ def index_group():
     """The communicator of the INDEX PLANE (row ids, counts: Trainer.plan_exchange).  RCCL: a second communicator, hence its own
     stream -- the id exchange of batch i + 1 is not ordered behind the gradient collectives of batch i, so it can run (and its two
     host syncs can return) while step i computes.  Created collectively on first use (every rank reaches its first plan_exchange at
-    the same point of the program); other backends share the default group."""
+    the same point of the program); other backends share the default group.
+    Hazard (round-2 advice): two communicators issue their kernels from two streams, and NCCL / RCCL only guarantee progress when the
+    collectives of different communicators are launched in the same order on every rank or can co-reside on the device.  Here each
+    rank issues, per step, the index plane of batch i + 1 (this communicator) and the gradient collectives of step i (the default one)
+    from different host points, so the device-side order can differ between ranks; both kinds of kernels are small (a few workgroups) and
+    co-reside on a 256-CU device, which is what makes this work -- it has not been soak-tested on 8 GPUs.  DMT_INDEX_GROUP=0 puts
+    everything on the default communicator (one stream, one order: the id exchange then queues behind the gradient collectives)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or os.environ.get("DMT_INDEX_GROUP", "1") != "1":
         return None          # (DMT_INDEX_GROUP=0: everything on the default communicator -- the id exchange then queues behind gradient collectives)
     world_pg = dist.distributed_c10d._get_default_group()

@@ -19,6 +19,7 @@ rm -rf $O/prof/*/*_kernel_trace.csv $O/prof_L200/*/*_kernel_trace.csv
 python bench.py --no-cpu-baseline --long-seq 200 --attn-dtype fp8 2>/dev/null | grep '^{' > $O/bench_n1_L200_fp8.json
 python bench.py --no-cpu-baseline --long-seq 200 --attn-dtype fp8 --batch 8192 2>/dev/null | grep '^{' > $O/bench_n1_L200_fp8_b8192.json
 python bench.py --no-cpu-baseline --law uniform 2>/dev/null | grep '^{' > $O/bench_n1_uniform.json
+python bench.py --no-cpu-baseline --fresh-batches 4 --age-tables 0 2>/dev/null | grep '^{' > $O/bench_n1_round2_protocol.json
 DMT_DETERMINISTIC=1 python bench.py --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_n1_deterministic.json
 DMT_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_forced_dp.json
 DMT_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline --shard-tables --sku-rows 100000000 2>/dev/null | grep '^{' > $O/bench_forced_dp_sharded_100m.json

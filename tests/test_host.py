@@ -164,3 +164,11 @@ def test_index_group_is_the_default_group_without_rccl():
     uses the default one (None)."""
     from cikm2020_dmt_amd import parallel
     assert parallel.index_group() is None
+
+
+def test_tfadam_refuses_an_increasing_learning_rate_schedule():
+    """The exact lazy-row replay assumes a non-increasing piecewise schedule (cikm2020_dmt_amd/optim.py); a warm-up schedule is rejected
+    before any tensor is touched."""
+    from cikm2020_dmt_amd.optim import TFAdam
+    with pytest.raises(ValueError, match="non-increasing"):
+        TFAdam(object(), learning_rate=(1e-4, 1e-3), step_boundary=(100,))
