@@ -108,7 +108,7 @@ class MhsaDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [("A", c_vp), ("ld_a", c_i64), ("a_cols", c_i32), ("B", c_vp), ("ld_b", c_i64), ("M", c_i64), ("N", c_i32), ("C", c_vp),
-                ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32)]
+                ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32), ("det_ws", c_vp), ("det_ws_bytes", C.c_uint64)]
 
 
 class TableMap(C.Structure):
@@ -185,7 +185,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported", "dmt_proj_supported", "dmt_image_job_bytes",
-                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_reduce_det_ws_bytes", "dmt_route_trace", "dmt_route_count", "dmt_route_dump"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_reduce_det_ws_bytes", "dmt_wgrad320_det_ws_bytes", "dmt_route_trace", "dmt_route_count", "dmt_route_dump"])
 
 _lib = None
 
@@ -226,6 +226,8 @@ def load():
     lib.dmt_reduce_det_ws_bytes.argtypes = [c_i64, c_i32]
     lib.dmt_attn_long_supported.restype = c_i32
     lib.dmt_attn_long_supported.argtypes = [c_i32, c_i32, c_i32, c_i32]
+    lib.dmt_wgrad320_det_ws_bytes.restype = C.c_uint64
+    lib.dmt_wgrad320_det_ws_bytes.argtypes = [c_i64, c_i32]
     lib.dmt_route_trace.restype = c_i32
     lib.dmt_route_trace.argtypes = [c_i32]
     lib.dmt_route_count.restype = c_i64

@@ -51,6 +51,10 @@ struct DwArgs {
   int bias_of;           // 1: column sums of B -> bias[j]   2: column sums of A -> bias[i]
   int jblocks, splits;
   long long rows_per_split;   // multiple of DW_KS
+  float* ws;                  // ordered form: partial blocks ws[split][320][ws_ld] (+ bias partials behind them), else null
+  int ws_ld;                  // = jblocks * DW_BW
+  float* ws_bias;             // [splits][ws_nb]
+  int ws_nb;
 };
 
 template <int OFF> __device__ __forceinline__ void dw_tr(bf16x4_t& dst, unsigned addr) {
@@ -211,6 +215,39 @@ __global__ __launch_bounds__(DW_NT, 2) void wgrad320_kernel(const DwArgs g) {
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col (j) = lane & 31, row (i) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int jbase = jb * DW_BW + 64 * wj;
+  if (g.ws != nullptr) {
+    // ordered form: this split's partial block, untransposed, into its own slab of the workspace (no atomics)
+    float* W = g.ws + (long long)split * DW_AW * g.ws_ld;
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const int j = jbase + 32 * tj + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 160 * wi + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          W[(long long)i * g.ws_ld + j] = acc[ti][tj][r];
+        }
+      }
+    if constexpr (BIAS_OF == 1) {
+      if (wi == 0) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const float v = bsum[tj] + __shfl_xor(bsum[tj], 32, 64);
+          if (hi == 0) g.ws_bias[(long long)split * g.ws_nb + jbase + 32 * tj + (lane & 31)] = v;
+        }
+      }
+    } else if constexpr (BIAS_OF == 2) {
+      if (wj == 0 && jb == 0) {
+#pragma unroll
+        for (int ti = 0; ti < 5; ++ti) {
+          const float v = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+          if (hi == 0) g.ws_bias[(long long)split * g.ws_nb + 160 * wi + 32 * ti + (lane & 31)] = v;
+        }
+      }
+    }
+    return;
+  }
   if constexpr (!TRANSPOSED) {
 #pragma unroll
     for (int ti = 0; ti < 5; ++ti)
@@ -265,7 +302,53 @@ __global__ __launch_bounds__(DW_NT, 2) void wgrad320_kernel(const DwArgs g) {
   }
 }
 
+// ordered form, second launch: C (+)= sum over the splits, in split order, of their partial blocks; likewise the bias partials
+__global__ __launch_bounds__(256) void wgrad320_reduce_kernel(const DwArgs g) {
+  const long long n_c = (long long)DW_AW * g.N;
+  const long long n_all = n_c + (g.bias_of ? g.ws_nb : 0);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_all; e += (long long)gridDim.x * 256) {
+    if (e < n_c) {
+      const int i = (int)(e / g.N), j = (int)(e % g.N);
+      float s = 0.f;
+      for (int sp = 0; sp < g.splits; ++sp) s += g.ws[((long long)sp * DW_AW + i) * g.ws_ld + j];
+      float* dst = g.transposed ? g.C + (long long)j * g.ldc + i : g.C + (long long)i * g.ldc + j;
+      *dst += s;
+    } else {
+      const int k = (int)(e - n_c);
+      const int lim = g.bias_of == 1 ? g.N : DW_AW;
+      if (k < lim) {
+        float s = 0.f;
+        for (int sp = 0; sp < g.splits; ++sp) s += g.ws_bias[(long long)sp * g.ws_nb + k];
+        g.bias[k] += s;
+      }
+    }
+  }
+}
+
+static void dw_plan(long long M, int N, long long ld_max, int& jblocks, int& splits, long long& rps) {
+  jblocks = (N + DW_BW - 1) / DW_BW;
+  // one workgroup per CU: splits = the multiple of 8 that fills (at most) the 256 CUs, bounded by the work
+  splits = (256 / jblocks) / 8 * 8;
+  if (splits < 8) splits = 8;
+  const long long max_splits = (M + DW_KS - 1) / DW_KS;
+  if (splits > max_splits) splits = (int)max_splits;
+  // (the descriptor offsets of one split are 32-bit)
+  rps = (M + splits - 1) / splits;
+  rps = (rps + DW_KS - 1) / DW_KS * DW_KS;
+  while (rps * ld_max * 2 > 0x7FFFFFFFll) { splits *= 2; rps = ((M + splits - 1) / splits + DW_KS - 1) / DW_KS * DW_KS; }
+  splits = (int)((M + rps - 1) / rps);      // (rounding rows_per_split up may leave the last splits empty: every split below has rows)
+}
+
 }  // namespace
+
+extern "C" uint64_t dmt_wgrad320_det_ws_bytes(int64_t M, int32_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  int jblocks, splits; long long rps;
+  dw_plan(M, N, 4096, jblocks, splits, rps);            // (an upper bound on the splits for any row stride up to 4096 elements)
+  const int nb = jblocks * DW_BW > DW_AW ? jblocks * DW_BW : DW_AW;
+  const long long per = (long long)DW_AW * jblocks * DW_BW + nb;
+  return (uint64_t)(((splits + 7) / 8 * 8) * per * 4 + 256);
+}
 
 extern "C" int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream) {
   DMT_CHECK_ARG(d != nullptr, "dmt_wgrad320: null descriptor");
@@ -283,18 +366,18 @@ extern "C" int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream) {
   g.C = d->C; g.ldc = d->ldc;
   g.transposed = d->transposed ? 1 : 0;
   g.bias = d->bias; g.bias_of = d->bias_of;
-  g.jblocks = (d->N + DW_BW - 1) / DW_BW;
-  // one workgroup per CU: splits = the multiple of 8 that fills (at most) the 256 CUs, bounded by the work
-  int splits = (256 / g.jblocks) / 8 * 8;
-  if (splits < 8) splits = 8;
-  const long long max_splits = (d->M + DW_KS - 1) / DW_KS;
-  if (splits > max_splits) splits = (int)max_splits;
-  // (the descriptor offsets of one split are 32-bit)
-  long long rps = (d->M + splits - 1) / splits;
-  rps = (rps + DW_KS - 1) / DW_KS * DW_KS;
-  while (rps * (d->ld_b > d->ld_a ? d->ld_b : d->ld_a) * 2 > 0x7FFFFFFFll) { splits *= 2; rps = ((d->M + splits - 1) / splits + DW_KS - 1) / DW_KS * DW_KS; }
+  int splits; long long rps;
+  dw_plan(d->M, d->N, d->ld_b > d->ld_a ? d->ld_b : d->ld_a, g.jblocks, splits, rps);
   g.splits = splits;
   g.rows_per_split = rps;
+  g.ws = nullptr; g.ws_bias = nullptr; g.ws_ld = g.jblocks * DW_BW; g.ws_nb = g.ws_ld > DW_AW ? g.ws_ld : DW_AW;
+  if (d->det_ws != nullptr) {
+    const long long need = ((long long)splits * ((long long)DW_AW * g.ws_ld + g.ws_nb)) * 4;
+    DMT_CHECK_ARG((((uintptr_t)d->det_ws) & 15) == 0 && d->det_ws_bytes >= (uint64_t)need,
+                  "dmt_wgrad320: the ordered form needs a 16-byte aligned workspace of dmt_wgrad320_det_ws_bytes(M, N) bytes");
+    g.ws = (float*)d->det_ws;
+    g.ws_bias = g.ws + (long long)splits * DW_AW * g.ws_ld;
+  }
   const int grid = ((splits + 7) / 8) * 8 * g.jblocks;
   hipStream_t st = (hipStream_t)stream;
 #define DW_LAUNCH(BO, TR) hipLaunchKernelGGL((wgrad320_kernel<BO, TR>), dim3(grid), dim3(DW_NT), 0, st, g)
@@ -303,5 +386,10 @@ extern "C" int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream) {
   else { if (g.transposed) DW_LAUNCH(2, true); else DW_LAUNCH(2, false); }
 #undef DW_LAUNCH
   DMT_CHECK_LAUNCH("dmt_wgrad320");
+  if (g.ws != nullptr) {
+    const long long n_all = (long long)DW_AW * g.N + g.ws_nb;
+    hipLaunchKernelGGL(wgrad320_reduce_kernel, dim3((unsigned)cdiv64(n_all, 256)), dim3(256), 0, st, g);
+    DMT_CHECK_LAUNCH("dmt_wgrad320(ordered reduce)");
+  }
   return DMT_OK;
 }

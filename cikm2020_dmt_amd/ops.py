@@ -276,6 +276,16 @@ def wgrad320(A, B, C, transposed, bias=None, bias_of=0):
     d.C, d.ldc = C.data_ptr(), C.stride(0)
     d.transposed = 1 if transposed else 0
     d.bias, d.bias_of = (bias.data_ptr(), bias_of) if bias is not None else (None, 0)
+    if DETERMINISTIC:
+        # ordered form: the row splits' partial blocks go through a workspace and are added in split order (no fp32 atomics).  One
+        # workspace per stream: the sequence lanes run their weight gradients concurrently
+        need = int(L.load().dmt_wgrad320_det_ws_bytes(int(A.shape[0]), int(B.shape[1])))
+        key = ("wgrad320", str(A.device), int(torch.cuda.current_stream(A.device).cuda_stream))
+        ws = _det_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=A.device)
+            _det_ws[key] = ws
+        d.det_ws, d.det_ws_bytes = ws.data_ptr(), need
     if PROFILE is not None:
         PROFILE.setdefault("wgrad320_bytes", []).append(float((A.numel() + B.numel()) * 2 + C.numel() * 4))
     with _Timed("wgrad320", 2.0 * A.shape[0] * A.shape[1] * B.shape[1]):
@@ -298,7 +308,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     rows = K + 1 if want_bias else K
     tiles = ((rows + 127) // 128) * ((N + 127) // 128)
     split = _pick_split(tiles, M)
-    if (not DETERMINISTIC and gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
+    if (gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
             and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
             and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
         # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block

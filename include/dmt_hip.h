@@ -490,6 +490,9 @@ int dmt_image_build_batched(int32_t n_jobs, const void* jobs_dev, void* stream);
  *     transposed == 0:  C[i * ldc + j] += sum_m A[m, i] B[m, j]      (dW = X^T dY with X 320 wide:  A = X, B = dY)
  *     transposed == 1:  C[j * ldc + i] += sum_m A[m, i] B[m, j]      (dW = X^T dY with dY 320 wide: A = dY, B = X)
  *     bias_of == 1: bias[j] += sum_m B[m, j];   bias_of == 2: bias[i] += sum_m A[m, i]   (db = column sums of dY)
+ * Ordered form (bit-reproducible): with det_ws != NULL (dmt_wgrad320_det_ws_bytes(M, N) bytes, 16-byte aligned) every row split
+ * writes its partial [320, N] block (and its bias partials) to the workspace instead of adding it to C with atomics, and a second
+ * launch adds the splits in split order onto C / bias.  Launches that target the same C must be ordered by the caller (one stream).
  * Replaces: the kernel / bias gradients of tf.layers.dense at model/net/TransformerModel_util.py:188-190 (Q, K, V) and
  *           :224-228 (position-wise feed-forward), i.e. what dmt_gemm computes with a_ones_row for any shape.
  * ------------------------------------------------------------------------------------------------ */
@@ -502,8 +505,10 @@ typedef struct {
   int32_t transposed;
   float* bias;
   int32_t bias_of;
+  void* det_ws; uint64_t det_ws_bytes;           /* NULL / 0: fp32 atomics (default)                  */
 } dmt_wgrad_desc;
 int dmt_wgrad320(const dmt_wgrad_desc* d, void* stream);
+uint64_t dmt_wgrad320_det_ws_bytes(int64_t M, int32_t N);
 
 /* ------------------------------------------------------------------------------------------------
  * Self-attention block of the sequence encoder in ONE launch (bf16; built for d_model 320 = 4 heads x 80, T <= 64):
