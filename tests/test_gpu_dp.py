@@ -44,10 +44,19 @@ def _worker(rank, world, port, q, steps, bf16=False, dp_exchange="owner", wgrad_
     tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16 if bf16 else torch.float32, init=False, dp_exchange=dp_exchange, dropout=False)
     tr.store.load_state(P)
     losses = []
+    tr.diag = {}                            # HIP-event spans of the step's phases (bench.py: step_phases_ms)
     for s in range(steps):
         inputs, mask, _ = make_batch(sp, 6, seed=700 + 10 * s + rank, lengths="ragged", weights="random")
         losses.append(float(tr.train_step(tr.make_batch(inputs, mask))))
     assert tr.early_allreduce_used          # the MMoE / tower slice was reduced from the dL/dz hook, during backward
+    torch.cuda.synchronize()
+    want = {"index_plane_sort", "allreduce_head", "allreduce_tail", "optimizer", "exchange_ids", "exchange_rows_a2a",
+            "exchange_rows_allgather"} if dp_exchange == "owner" else {"index_plane_sort"}      # (the one-shot exchange form is not instrumented)
+    missing = want - set(tr.diag)
+    assert not missing, ("phases the data-parallel step must report", missing, sorted(tr.diag))
+    for key, ent in tr.diag.items():
+        assert all(e0.elapsed_time(e1) >= 0.0 for (e0, e1) in ent), key
+    tr.diag = None
     tr.opt.flush_tables()
     torch.cuda.synchronize()
     q.put((rank, losses, tr.store.state_dict()))
