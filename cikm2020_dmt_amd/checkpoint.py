@@ -5,8 +5,11 @@
   * where: `<model_path>/model.ckpt-<step>` + an empty marker `<model_path>/step-<step>.model.DONE` written after it;
   * resume: the step comes from the checkpoint NAME (`model.ckpt-N`), the optimizer restarts its slots (TFAdam.reset_slots).
 
-The container is an .npz (name -> fp32 array): TensorFlow's tensor-bundle files cannot be produced or read here (TF is absent);
-the names and shapes are the exchange surface -- a TF checkpoint dumped name by name loads with `restore_arrays`.
+Two containers.  The default is an .npz (name -> fp32 array).  `container="tf"` writes TensorFlow's own checkpoint V2 files
+(`model.ckpt-N.index` + `model.ckpt-N.data-00000-of-00001` + the `checkpoint` state file) with the format restated in
+`tf_bundle.py` -- what `saver.restore(sess, model_path + ckpt_name)` of the reference reads -- and `restore` reads either.  TensorFlow is
+absent here and the reference ships no checkpoint, so the TF container is pinned by its own invariants only (block checksums, footer
+magic, round trips: tests/test_host.py); the names and shapes are the exchange surface either way (`restore_arrays`).
 The lazy table optimizer is flushed first, so the saved embedding rows are exactly what a dense Adam sweep would hold.
 """
 from __future__ import annotations
@@ -51,12 +54,14 @@ def shard_name(step: int, rank: int, world: int) -> str:
     return "%s.shard-%05d-of-%05d" % (checkpoint_name(step), rank, world)
 
 
-def save(trainer, model_path: str, step: Optional[int] = None) -> str:
+def save(trainer, model_path: str, step: Optional[int] = None, container: str = "npz") -> str:
     """saver.save(sess, model_path + 'model.ckpt', global_step=step); create_file(model_path, 'step-%d.model.DONE' % step).
     More than one rank: every rank calls it (it ends in a barrier).  Replicated tables: rank 0 writes the one file (every replica
     holds the same values).  Row-sharded tables: NO table is gathered -- rank r writes the rows it owns to
     `model.ckpt-N.shard-r-of-W.npz` (local row l = global row l * W + r), rank 0 writes the dense variables and the shard count to
     `model.ckpt-N.npz`; the DONE marker appears after all shard files exist."""
+    if container not in ("npz", "tf"):
+        raise ValueError("container must be 'npz' or 'tf'")
     step = trainer.opt.global_step if step is None else int(step)
     dist, rank, world = _dist()
     os.makedirs(model_path, exist_ok=True)
@@ -64,6 +69,25 @@ def save(trainer, model_path: str, step: Optional[int] = None) -> str:
     store = trainer.store
     path = os.path.join(model_path, checkpoint_name(step) + ".npz")
     sharded = store.shard is not None and store.shard[1] > 1
+    if container == "tf":
+        if sharded:
+            raise NotImplementedError("the TensorFlow container holds whole variables: save row-sharded tables as .npz shards")
+        from . import tf_bundle
+        prefix = os.path.join(model_path, checkpoint_name(step))
+        if rank == 0:
+            arrays = {PREFIX + k: v for k, v in store.dense_state_dict().items()}
+            for name in store.tables:
+                arrays[PREFIX + name] = store.table[name].detach().float().cpu().numpy()[: store.tables[name].shape[0]]
+            tf_bundle.write_bundle(prefix, arrays)
+            done = sorted(int(m.group(1)) for m in (re.match(r"^model\.ckpt-(\d+)\.index$", fn) for fn in os.listdir(model_path)) if m)
+            tf_bundle.write_checkpoint_state(model_path, checkpoint_name(step), [checkpoint_name(n) for n in done])
+        if dist is not None and world > 1:
+            dist.barrier()
+        if rank == 0:
+            open(os.path.join(model_path, "step-%d.model.DONE" % step), "w").close()
+        if dist is not None and world > 1:
+            dist.barrier()
+        return prefix + ".index"
     if sharded:
         r, W = store.shard
         mine = {PREFIX + name: store.table[name].detach().float().cpu().numpy() for name in store.tables}
@@ -91,7 +115,7 @@ def latest(model_path: str) -> Optional[str]:
     if os.path.isdir(model_path):
         for fn in os.listdir(model_path):
             m = re.match(r"^step-(\d+)\.model\.DONE$", fn)
-            if m and os.path.exists(os.path.join(model_path, checkpoint_name(int(m.group(1))) + ".npz")):
+            if m and any(os.path.exists(os.path.join(model_path, checkpoint_name(int(m.group(1))) + ext)) for ext in (".npz", ".index")):
                 best = max(best, int(m.group(1)))
     return checkpoint_name(best) if best >= 0 else None
 
@@ -132,6 +156,10 @@ def restore(trainer, model_path: str, ckpt_name: Optional[str] = None) -> int:
     base = ckpt_name[:-4] if ckpt_name.endswith(".npz") else ckpt_name
     step = step_of(base)
     store = trainer.store
+    if not os.path.exists(os.path.join(model_path, base + ".npz")) and os.path.exists(os.path.join(model_path, base + ".index")):
+        from . import tf_bundle
+        restore_arrays(trainer, tf_bundle.read_bundle(os.path.join(model_path, base)), step)       # a TensorFlow checkpoint V2 bundle
+        return trainer.opt.global_step
     with np.load(os.path.join(model_path, base + ".npz")) as z:
         if "__table_shards__" not in z.files:
             restore_arrays(trainer, z, step)

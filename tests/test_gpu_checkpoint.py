@@ -59,3 +59,28 @@ def test_save_restore_and_resume_match_the_oracle(cuda, tmp_path):
     assert tr2.opt.global_step == 5
     with pytest.raises(KeyError):
         CK.restore_arrays(tr2, {"DnnModel/click/click-output/weights": np.zeros((4, 1), np.float32)})
+
+
+def test_tensorflow_container_round_trip(cuda, tmp_path):
+    """checkpoint.save(container="tf"): the reference's own checkpoint files (`model.ckpt-N.index` + `.data-00000-of-00001` + `checkpoint`,
+    tf.train.Saver at run_dnn.py:258-261) written without TensorFlow (cikm2020_dmt_amd/tf_bundle.py), restored into a fresh trainer:
+    every trainable variable back bit for bit, the step from the name, Adam restarted."""
+    so, sp = small_specs()
+    tr = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=5, dropout=False)
+    for i in range(2):
+        inputs, mask, _ = make_batch(sp, 8, seed=70 + i, lengths="ragged", weights="random")
+        tr.train_step(tr.make_batch(inputs, mask))
+    model_path = str(tmp_path / "model") + os.sep
+    path = CK.save(tr, model_path, container="tf")
+    assert sorted(os.listdir(model_path)) == ["checkpoint", "model.ckpt-2.data-00000-of-00001", "model.ckpt-2.index", "step-2.model.DONE"]
+    assert path.endswith("model.ckpt-2.index") and CK.latest(model_path) == "model.ckpt-2"
+    assert 'model_checkpoint_path: "model.ckpt-2"' in open(model_path + "checkpoint").read()
+    from cikm2020_dmt_amd import tf_bundle
+    names = set(tf_bundle.read_bundle(model_path + "model.ckpt-2"))
+    assert names == {"DnnModel/" + k for k in tr.store.state_dict()}               # the graph names of the trainable variables, nothing else
+    tr2 = Trainer(sp, device="cuda", compute_dtype=torch.float32, seed=99, dropout=False)
+    assert CK.restore(tr2, model_path) == 2
+    s1, s2 = tr.store.state_dict(), tr2.store.state_dict()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k]), k
+    assert float(tr2.store.adam_m.abs().max()) == 0.0
