@@ -72,15 +72,38 @@ __device__ __forceinline__ bf16x8_t row_frag(const bf16_t* __restrict__ row, int
   return (j0 + 8 <= DH) ? *reinterpret_cast<const bf16x8_t*>(row + j0) : zero8();
 }
 
-// Workgroup-cooperative copy of rows [0, n_rows) of a [.., dh] operand into an LDS tile of `rows_pad` rows (zero filled)
-template <int DH>
-__device__ __forceinline__ void stage_rows(bf16_t* __restrict__ dst, int ld, const bf16_t* __restrict__ src, long long rs, int n_rows,
-                                           int rows_pad, int tid) {
-  constexpr int CH = DH / 8;
-  for (int c = tid; c < rows_pad * CH; c += LNW * 64) {
-    const int row = c / CH, ch = c - row * CH;
-    const uint4 v = row < n_rows ? *reinterpret_cast<const uint4*>(src + (long long)row * rs + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(dst + row * ld + ch * 8) = v;
+// Workgroup-cooperative copy of rows [0, n_rows) of two [.., dh] operands into LDS tiles of `pad_a` / `pad_b` rows (zero filled).
+// All the 16-byte requests of a thread (MAXA, MAXB = compile-time bounds of the tile heights) are in flight together: rows past
+// n_rows re-read the last row (branch-free loads; replaced by zeros on the way into LDS).  (The rolled load -> wait -> store loop
+// this replaces paid one memory latency per 16 bytes and thread: 18 in a row at T = 200, most of the workgroup's lifetime.)
+template <int DH, int MAXA, int MAXB>
+__device__ __forceinline__ void stage_rows2(bf16_t* __restrict__ dst_a, int ld_a, const bf16_t* __restrict__ src_a, long long rs_a, int n_a,
+                                            int pad_a, bf16_t* __restrict__ dst_b, int ld_b, const bf16_t* __restrict__ src_b, long long rs_b,
+                                            int n_b, int pad_b, int tid) {
+  constexpr int CH = DH / 8, NT = LNW * 64;
+  constexpr int ITA = (MAXA * CH + NT - 1) / NT, ITB = (MAXB * CH + NT - 1) / NT;
+  uint4 va[ITA], vb[ITB];
+#pragma unroll
+  for (int i = 0; i < ITA; ++i) {
+    const int c = tid + i * NT, row = c / CH, ch = c - row * CH;
+    const int rr = row < n_a ? row : n_a - 1;
+    va[i] = *reinterpret_cast<const uint4*>(src_a + (long long)rr * rs_a + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < ITB; ++i) {
+    const int c = tid + i * NT, row = c / CH, ch = c - row * CH;
+    const int rr = row < n_b ? row : n_b - 1;
+    vb[i] = *reinterpret_cast<const uint4*>(src_b + (long long)rr * rs_b + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < ITA; ++i) {
+    const int c = tid + i * NT, row = c / CH, ch = c - row * CH;
+    if (row < pad_a) *reinterpret_cast<uint4*>(dst_a + row * ld_a + ch * 8) = row < n_a ? va[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < ITB; ++i) {
+    const int c = tid + i * NT, row = c / CH, ch = c - row * CH;
+    if (row < pad_b) *reinterpret_cast<uint4*>(dst_b + row * ld_b + ch * 8) = row < n_b ? vb[i] : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
@@ -140,7 +163,7 @@ __device__ __forceinline__ void store_direct(const f32x16_t& o, bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-template <int DH, int NTK>
+template <int DH, int NTK, bool DROP>
 __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_long_fwd_kernel(const LongArgs a) {
   typedef LongCfg<DH> CF;
   constexpr int NK = CF::NK, NDT = CF::NDT, RS = CF::RS, RSV = CF::RSV;
@@ -150,21 +173,22 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   __shared__ __attribute__((aligned(16))) bf16_t lds[KROWS * RS + NTK * 32 * RSV + 64];
   bf16_t* Kl = lds;
   bf16_t* Vl = lds + KROWS * RS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
   const bf16_t* Qg = a.Q + (long long)b * a.q_bs + h * DH;
   const bf16_t* Rg = a.resid ? a.resid + (long long)b * a.r_bs + h * DH : nullptr;
   bf16_t* Og = a.out + (long long)b * a.o_bs + h * DH;
-  stage_rows<DH>(Kl, RS, a.K + (long long)b * a.k_bs + h * DH, a.k_rs, Tk, Tk < KROWS ? (Tk + 7) & ~7 : KROWS, tid);
-  stage_rows<DH>(Vl, RSV, a.V + (long long)b * a.v_bs + h * DH, a.v_rs, Tk, NTK * 32, tid);
+  stage_rows2<DH, KROWS, NTK * 32>(Kl, RS, a.K + (long long)b * a.k_bs + h * DH, a.k_rs, Tk, Tk < KROWS ? (Tk + 7) & ~7 : KROWS,
+                                   Vl, RSV, a.V + (long long)b * a.v_bs + h * DH, a.v_rs, Tk, NTK * 32, tid);
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
   const float kscale = LOG2E / sqrtf((float)DH);
   const int kl0 = klen - 4 * half, tk0 = Tk - 4 * half;   // slot constant c: key = c + 4 half
   const int nqt = (Tq + 31) >> 5;
+  const int kfull = klen >> 5;                            // key tiles [0, kfull) hold valid keys only
   bool synced = false;
   for (int qt = wave; qt < nqt; qt += LNW) {
     const int q = qt * 32 + l31;
@@ -193,19 +217,31 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int kt = 0; kt < NTK; ++kt)
         acc[kt] = mma(row_frag<DH>(Kl + (kt * 32 + l31) * RS, s2 * 16 + 8 * half), bQ[s2], acc[kt]);
-    // ---- masked softmax over the keys of query column q
+    // ---- masked softmax over the keys of query column q.  The two key masks apply only from the first key tile that holds a key
+    // >= k_len (k_len is one number per workgroup: a scalar branch per tile), the query mask only in a query tile that holds a
+    // padded query; dropout is a compile-time variant.  Same arithmetic, in the same order, for every element either way.
     float m = -3.0e38f;
 #pragma unroll
-    for (int kt = 0; kt < NTK; ++kt)
+    for (int kt = 0; kt < NTK; ++kt) {
+      if (kt < kfull) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
-        float x = acc[kt][r] * kscale;
-        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
-        x = (c >= tk) ? -3.0e38f : x;
-        acc[kt][r] = x;
-        m = fmaxf(m, x);
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[kt][r] * kscale;
+          acc[kt][r] = x;
+          m = fmaxf(m, x);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          float x = acc[kt][r] * kscale;
+          x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+          x = (c >= tk) ? -3.0e38f : x;
+          acc[kt][r] = x;
+          m = fmaxf(m, x);
+        }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
@@ -218,18 +254,30 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv_sum = __builtin_amdgcn_rcpf(sum);
-    const bool qpad = (q >= qlen);
     const unsigned dbase = (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + 4u * half;
     bf16x8_t pB[2 * NTK];
 #pragma unroll
-    for (int kt = 0; kt < NTK; ++kt) {
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
-        float p = acc[kt][r] * inv_sum;
-        if (qpad) p = (c < tk) ? PADDING_NUM : 0.f;
-        if (a.drop_on) p = dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? p * a.drop_inv : 0.f;
-        acc[kt][r] = p;
+      for (int r = 0; r < 16; ++r) acc[kt][r] *= inv_sum;
+    if (qt * 32 + 32 > qlen) {             // (scalar) rows of padded queries: the constant on every key that exists
+      const bool qpad = (q >= qlen);
+#pragma unroll
+      for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (qpad) acc[kt][r] = (c < tk) ? PADDING_NUM : 0.f;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) {
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          acc[kt][r] = dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? acc[kt][r] * a.drop_inv : 0.f;
+        }
       }
       pB[2 * kt] = pack_half(acc[kt], 0);
       pB[2 * kt + 1] = pack_half(acc[kt], 1);
@@ -292,7 +340,7 @@ __device__ __forceinline__ f32x16_t mma8(f8x8_t a, f8x8_t b, const f32x16_t& c) 
   return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
 }
 
-template <int DH, int NTK>
+template <int DH, int NTK, bool DROP>
 __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_long_fwd_f8_kernel(const LongArgs a) {
   typedef LongCfg<DH> CF;
   constexpr int NK = CF::NK, NDT = CF::NDT, CH = DH / 8;
@@ -301,7 +349,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   constexpr int VDIMS = NDT * 32;
   __shared__ __attribute__((aligned(16))) unsigned char Kl[NTK * 32 * RS8];
   __shared__ __attribute__((aligned(16))) unsigned char Vt[VDIMS * VS8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
@@ -313,19 +361,34 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   // ---- stage K as e4m3 rows, V as e4m3 columns (keys past Tk: zeros -- 0 x anything finite)
   for (int i = tid; i < VDIMS * VS8 / 4; i += LNW * 64) reinterpret_cast<unsigned*>(Vt)[i] = 0u;
   __syncthreads();
-  for (int c = tid; c < NTK * 32 * CH; c += LNW * 64) {
-    const int row = c / CH, ch = c - row * CH;
-    uint2 k8 = make_uint2(0u, 0u);
-    if (row < Tk) {
-      k8 = bf16x8_to_f8(*reinterpret_cast<const uint4*>(Kg + (long long)row * a.k_rs + ch * 8));
-      const uint2 v8 = bf16x8_to_f8(*reinterpret_cast<const uint4*>(Vg + (long long)row * a.v_rs + ch * 8));
+  {
+    // (all of a thread's 16-byte requests in flight together, see stage_rows2)
+    constexpr int IT = (NTK * 32 * CH + LNW * 64 - 1) / (LNW * 64);
+    uint4 kraw[IT], vraw[IT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Vt[(ch * 8 + e) * VS8 + row] = (unsigned char)(v8.x >> (8 * e));
-        Vt[(ch * 8 + 4 + e) * VS8 + row] = (unsigned char)(v8.y >> (8 * e));
+    for (int i = 0; i < IT; ++i) {
+      const int c = tid + i * LNW * 64, row = c / CH, ch = c - row * CH;
+      const int rr = row < Tk ? row : Tk - 1;
+      kraw[i] = *reinterpret_cast<const uint4*>(Kg + (long long)rr * a.k_rs + ch * 8);
+      vraw[i] = *reinterpret_cast<const uint4*>(Vg + (long long)rr * a.v_rs + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = tid + i * LNW * 64, row = c / CH, ch = c - row * CH;
+      if (row < NTK * 32) {
+        uint2 k8 = make_uint2(0u, 0u);
+        if (row < Tk) {
+          k8 = bf16x8_to_f8(kraw[i]);
+          const uint2 v8 = bf16x8_to_f8(vraw[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            Vt[(ch * 8 + e) * VS8 + row] = (unsigned char)(v8.x >> (8 * e));
+            Vt[(ch * 8 + 4 + e) * VS8 + row] = (unsigned char)(v8.y >> (8 * e));
+          }
+        }
+        *reinterpret_cast<uint2*>(Kl + row * RS8 + ch * 8) = k8;
       }
     }
-    *reinterpret_cast<uint2*>(Kl + row * RS8 + ch * 8) = k8;
   }
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
@@ -333,6 +396,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   const float kscale = LOG2E / sqrtf((float)DH);
   const int kl0 = klen - 4 * half, tk0 = Tk - 4 * half;
   const int nqt = (Tq + 31) >> 5;
+  const int kfull = klen >> 5;
   bool synced = false;
   for (int qt = wave; qt < nqt; qt += LNW) {
     const int q = qt * 32 + l31;
@@ -344,14 +408,6 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
       const int j0 = s2 * 16 + 8 * half;
       bQ[s2] = (q < Tq && j0 + 8 <= DH) ? as_f8x8(bf16x8_to_f8(*reinterpret_cast<const uint4*>(Qg + (long long)q * a.q_rs + j0))) : 0L;
     }
-    uint2 rres[NDT][4];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j = dt * 32 + 8 * g + 4 * half;
-        rres[dt][g] = (Rg && q < Tq && j + 4 <= DH) ? *reinterpret_cast<const uint2*>(Rg + (long long)q * a.r_rs + j) : make_uint2(0u, 0u);
-      }
     if (!synced) { __syncthreads(); synced = true; }
     f32x16_t acc[NTK];
 #pragma unroll
@@ -365,18 +421,29 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         acc[kt] = mma8(kf, bQ[s2], acc[kt]);
       }
     }
+    // (masks per tile / query tile, dropout at compile time: see attn_long_fwd_kernel)
     float m = -3.0e38f;
 #pragma unroll
-    for (int kt = 0; kt < NTK; ++kt)
+    for (int kt = 0; kt < NTK; ++kt) {
+      if (kt < kfull) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
-        float x = acc[kt][r] * kscale;
-        x = (c >= kl) ? PADDING_NUM * LOG2E : x;
-        x = (c >= tk) ? -3.0e38f : x;
-        acc[kt][r] = x;
-        m = fmaxf(m, x);
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[kt][r] * kscale;
+          acc[kt][r] = x;
+          m = fmaxf(m, x);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          float x = acc[kt][r] * kscale;
+          x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+          x = (c >= tk) ? -3.0e38f : x;
+          acc[kt][r] = x;
+          m = fmaxf(m, x);
+        }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sum = 0.f;
 #pragma unroll
@@ -388,20 +455,42 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         sum += e;
       }
     sum += __shfl_xor(sum, 32, 64);
+    // the residual pieces of the epilogue (this lane's row q, dims dt*32 + 8g + 4 half + {0..3}), requested now: the normalisation,
+    // dropout and packing below cover their latency, and the Q fragments are dead (168 registers: three workgroups per CU)
+    uint2 rres[NDT][4];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j = dt * 32 + 8 * g + 4 * half;
+        rres[dt][g] = (Rg && q < Tq && j + 4 <= DH) ? *reinterpret_cast<const uint2*>(Rg + (long long)q * a.r_rs + j) : make_uint2(0u, 0u);
+      }
     const bool qpad = (q >= qlen);
     const float pscale = __builtin_amdgcn_rcpf(sum) * 256.f;          // P * 2^8 -> e4m3
     const float oscale = qpad ? PADDING_NUM : (1.f / 256.f);
     const unsigned dbase = (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + 4u * half;
     f8x8_t pB[2 * NTK];
 #pragma unroll
-    for (int kt = 0; kt < NTK; ++kt) {
+    for (int kt = 0; kt < NTK; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
-        float p = acc[kt][r] * pscale;
-        if (qpad) p = (c < tk) ? 1.f : 0.f;
-        if (a.drop_on) p = dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? p * a.drop_inv : 0.f;
-        acc[kt][r] = p;
+      for (int r = 0; r < 16; ++r) acc[kt][r] *= pscale;
+    if (qt * 32 + 32 > qlen) {
+#pragma unroll
+      for (int kt = 0; kt < NTK; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          if (qpad) acc[kt][r] = (c < tk) ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) {
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+          acc[kt][r] = dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? acc[kt][r] * a.drop_inv : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -431,7 +520,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ----------------------------------------------------------------------------------------------------------- backward
-template <int DH, int NTK>
+template <int DH, int NTK, bool DROP>
 __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_long_bwd_kernel(const LongArgs a) {
   typedef LongCfg<DH> CF;
   constexpr int NK = CF::NK, NDT = CF::NDT, RS = CF::RS;
@@ -444,7 +533,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * TR * RS + TAIL];
   bf16_t* XA = lds;                  // phase 1: K     phase 2: Q
   bf16_t* XB = lds + TR * RS;        // phase 1: V     phase 2: dO
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
   const int Tq = a.Tq, Tk = a.Tk;
   const int half = lane >> 5, l31 = lane & 31;
@@ -453,13 +542,13 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
   const bf16_t* Vg = a.V + (long long)b * a.v_bs + h * DH;
   const bf16_t* dOg = a.dout + (long long)b * a.do_bs + h * DH;
   const int nqt = (Tq + 31) >> 5, nkt = (Tk + 31) >> 5;
-  stage_rows<DH>(XA, RS, Kg, a.k_rs, Tk, TR, tid);
-  stage_rows<DH>(XB, RS, Vg, a.v_rs, Tk, TR, tid);
+  stage_rows2<DH, TR, TR>(XA, RS, Kg, a.k_rs, Tk, TR, XB, RS, Vg, a.v_rs, Tk, TR, tid);
   for (int i = tid; i < TAIL / 2; i += LNW * 64) reinterpret_cast<unsigned*>(lds + 2 * TR * RS)[i] = 0u;
   int klen = a.k_lens ? a.k_lens[b] : Tk;
   klen = klen < 0 ? 0 : (klen > Tk ? Tk : klen);
   const int qlen = a.q_lens ? a.q_lens[b] : Tq;
   const float kscale = LOG2E / sqrtf((float)DH), inv_sc = 1.0f / sqrtf((float)DH);
+  const int kfull = klen >> 5;                    // key tiles [0, kfull) hold valid keys only
 
   // ================= phase 1: wave = query tile.  dQ and the row statistics.
   {
@@ -485,18 +574,30 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int kt = 0; kt < NTK; ++kt)
           acc[kt] = mma(row_frag<DH>(XA + (kt * 32 + l31) * RS, s2 * 16 + 8 * half), bQ[s2], acc[kt]);
+      // (key masks from the first tile that holds a key >= k_len on, query mask per query tile, dropout at compile time: see
+      // attn_long_fwd_kernel)
       float m = -3.0e38f;
 #pragma unroll
-      for (int kt = 0; kt < NTK; ++kt)
+      for (int kt = 0; kt < NTK; ++kt) {
+        if (kt < kfull) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
-          float x = acc[kt][r] * kscale;
-          x = (c >= kl) ? PADDING_NUM * LOG2E : x;
-          x = (c >= tk) ? -3.0e38f : x;
-          acc[kt][r] = x;
-          m = fmaxf(m, x);
+          for (int r = 0; r < 16; ++r) {
+            const float x = acc[kt][r] * kscale;
+            acc[kt][r] = x;
+            m = fmaxf(m, x);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
+            float x = acc[kt][r] * kscale;
+            x = (c >= kl) ? PADDING_NUM * LOG2E : x;
+            x = (c >= tk) ? -3.0e38f : x;
+            acc[kt][r] = x;
+            m = fmaxf(m, x);
+          }
         }
+      }
       m = fmaxf(m, __shfl_xor(m, 32, 64));
       float sum = 0.f;
 #pragma unroll
@@ -521,9 +622,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
       // ---- D = sum_k P dP  (dP^T = V dO^T, gradient w.r.t. the pre-dropout weights); the keep bits are remembered for pass 3
       const unsigned dbase = (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + 4u * half;
-      unsigned keepb[(NTK + 1) / 2];
-#pragma unroll
-      for (int i = 0; i < (NTK + 1) / 2; ++i) keepb[i] = 0xFFFFFFFFu;
+      unsigned keepb[DROP ? (NTK + 1) / 2 : 1];
       float dot = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NTK; ++kt) {
@@ -531,27 +630,30 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int s2 = 0; s2 < NK; ++s2) dp = mma(row_frag<DH>(XB + (kt * 32 + l31) * RS, s2 * 16 + 8 * half), bD[s2], dp);
         unsigned bits = 0xFFFFu;
-        if (a.drop_on) {
+        if constexpr (DROP) {
           bits = 0u;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
             bits |= (dmt_drop_keep(a.drop_seed, dbase + (unsigned)c, a.drop_thr) ? 1u : 0u) << r;
           }
-          keepb[kt >> 1] = (kt & 1) ? ((keepb[kt >> 1] & 0xFFFFu) | (bits << 16)) : ((keepb[kt >> 1] & 0xFFFF0000u) | bits);
+          if (kt & 1) keepb[kt >> 1] |= bits << 16;
+          else keepb[kt >> 1] = bits;
         }
+        const bool edge = !(kt < kfull);                                     // (scalar) this tile holds keys past k_len
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
           float g = dp[r];
-          if (a.drop_on) g = ((bits >> r) & 1u) ? g * a.drop_inv : 0.f;
-          g = (c < tk) ? g : 0.f;                  // (rows past Tk of the V tile may be another tile's data)
+          if constexpr (DROP) g = ((bits >> r) & 1u) ? g * a.drop_inv : 0.f;
+          if (edge) g = (c < tk) ? g : 0.f;                                  // (rows past Tk of the V tile may be another tile's data)
           dot += unpack_at(Pp[2 * kt + (r >> 3)], r & 7) * g;
         }
       }
       dot += __shfl_xor(dot, 32, 64);
       if (half == 0) { s_m[q] = m; s_inv[q] = inv_sum; s_D[q] = dot; }
       // ---- dS = P (dP - D) / sqrt(dh)  -> packed B operands of dQ^T = K^T dS^T
+      const bool qpad_tile = qt * 32 + 32 > qlen;                            // (scalar) the tile holds a padded query
       const bool qpad = (q >= qlen);
       bf16x8_t dsB[2 * NTK];
 #pragma unroll
@@ -559,15 +661,21 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
         f32x16_t dp = zero16();
 #pragma unroll
         for (int s2 = 0; s2 < NK; ++s2) dp = mma(row_frag<DH>(XB + (kt * 32 + l31) * RS, s2 * 16 + 8 * half), bD[s2], dp);
-        const unsigned bits = (keepb[kt >> 1] >> (16 * (kt & 1))) & 0xFFFFu;
+        unsigned bits = 0xFFFFu;
+        if constexpr (DROP) bits = (keepb[kt >> 1] >> (16 * (kt & 1))) & 0xFFFFu;
+        const bool edge = !(kt < kfull);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = kt * 32 + (r & 3) + 8 * (r >> 2);
           float g = dp[r];
-          if (a.drop_on) g = ((bits >> r) & 1u) ? g * a.drop_inv : 0.f;
-          float ds = (c < kl) ? unpack_at(Pp[2 * kt + (r >> 3)], r & 7) * (g - dot) * inv_sc : 0.f;     // no gradient into masked keys
-          if (qpad) ds = 0.f;                                                // constant rows
+          if constexpr (DROP) g = ((bits >> r) & 1u) ? g * a.drop_inv : 0.f;
+          float ds = unpack_at(Pp[2 * kt + (r >> 3)], r & 7) * (g - dot) * inv_sc;
+          if (edge) ds = (c < kl) ? ds : 0.f;                                // no gradient into masked keys
           dp[r] = ds;
+        }
+        if (qpad_tile) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dp[r] = qpad ? 0.f : dp[r];           // constant rows
         }
         dsB[2 * kt] = pack_half(dp, 0);
         dsB[2 * kt + 1] = pack_half(dp, 1);
@@ -583,8 +691,7 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (!synced) __syncthreads();
   }
   __syncthreads();
-  stage_rows<DH>(XA, RS, Qg, a.q_rs, Tq, TR, tid);
-  stage_rows<DH>(XB, RS, dOg, a.do_rs, Tq, TR, tid);
+  stage_rows2<DH, TR, TR>(XA, RS, Qg, a.q_rs, Tq, TR, XB, RS, dOg, a.do_rs, Tq, TR, tid);
 
   // ================= phase 2: wave = key tile.  dK and dV.
   {
@@ -611,6 +718,8 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
           s = mma(row_frag<DH>(XA + (qt * 32 + l31) * RS, s2 * 16 + 8 * half), bK[s2], s);      // S = Q K^T: lane = key, registers = queries
           dp = mma(row_frag<DH>(XB + (qt * 32 + l31) * RS, s2 * 16 + 8 * half), bV[s2], dp);    // dP = dO V^T
         }
+        // (scalar) a tile pair of valid keys and live queries needs no select at all
+        const bool inner = (kt * 32 + 32 <= klen) && (qt * 32 + 32 <= qlen) && (qt * 32 + 32 <= Tq);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int q0 = qt * 32 + 8 * g + 4 * half;
@@ -618,24 +727,43 @@ __global__ __launch_bounds__(LNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
           const float4 i4 = *reinterpret_cast<const float4*>(s_inv + q0);
           const float4 d4 = *reinterpret_cast<const float4*>(s_D + q0);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+          if (inner) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e, q = q0 + e;
-            float x = s[r] * kscale;
-            x = kvalid ? x : PADDING_NUM * LOG2E;
-            float pv = kin ? __builtin_amdgcn_exp2f(x - mm[e]) * ii[e] : 0.f;
-            float gq = dp[r];
-            bool keep = true;
-            if (a.drop_on) {
-              keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + (unsigned)key, a.drop_thr);
-              gq = keep ? gq * a.drop_inv : 0.f;
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e, q = q0 + e;
+              const float x = s[r] * kscale;
+              float pv = __builtin_amdgcn_exp2f(x - mm[e]) * ii[e];
+              float gq = dp[r];
+              if constexpr (DROP) {
+                const bool keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + (unsigned)key, a.drop_thr);
+                gq = keep ? gq * a.drop_inv : 0.f;
+                dp[r] = pv * (gq - dd[e]) * inv_sc;
+                pv = keep ? pv * a.drop_inv : 0.f;
+              } else {
+                dp[r] = pv * (gq - dd[e]) * inv_sc;
+              }
+              s[r] = pv;
             }
-            float ds = kvalid ? pv * (gq - dd[e]) * inv_sc : 0.f;
-            if (q >= qlen) { ds = 0.f; pv = kin ? PADDING_NUM : 0.f; }
-            if (a.drop_on) pv = keep ? pv * a.drop_inv : 0.f;
-            if (q >= Tq) { ds = 0.f; pv = 0.f; }       // rows past Tq of the Q / dO tiles are not data
-            s[r] = pv;            // the weights as they multiply V (query mask and dropout applied)
-            dp[r] = ds;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e, q = q0 + e;
+              float x = s[r] * kscale;
+              x = kvalid ? x : PADDING_NUM * LOG2E;
+              float pv = kin ? __builtin_amdgcn_exp2f(x - mm[e]) * ii[e] : 0.f;
+              float gq = dp[r];
+              bool keep = true;
+              if constexpr (DROP) {
+                keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * a.H + h) * Tq + q) * (unsigned)Tk + (unsigned)key, a.drop_thr);
+                gq = keep ? gq * a.drop_inv : 0.f;
+              }
+              float ds = kvalid ? pv * (gq - dd[e]) * inv_sc : 0.f;
+              if (q >= qlen) { ds = 0.f; pv = kin ? PADDING_NUM : 0.f; }
+              if constexpr (DROP) pv = keep ? pv * a.drop_inv : 0.f;
+              if (q >= Tq) { ds = 0.f; pv = 0.f; }       // rows past Tq of the Q / dO tiles are not data
+              s[r] = pv;            // the weights as they multiply V (query mask and dropout applied)
+              dp[r] = ds;
+            }
           }
         }
 #pragma unroll
@@ -923,19 +1051,24 @@ extern "C" int dmt_attn_long_supported(int32_t dtype, int32_t dh, int32_t Tq, in
   return (dtype == DMT_BF16 && (dh == 16 || dh == 32 || dh == 64 || dh == 80) && Tq >= 1 && Tk >= 1 && Tq <= 256 && Tk <= 256) ? 1 : 0;
 }
 
-#define DMT_LONG_DISPATCH(KERNEL, ARGS)                                                                                   \
+#define DMT_LONG_DISPATCH_D(KERNEL, ARGS, DROP)                                                                           \
   do {                                                                                                                    \
-    const int ntk = ntk_of(d_->Tq > d_->Tk ? d_->Tq : d_->Tk);                                                                                       \
+    const int ntk = ntk_of(d_->Tq > d_->Tk ? d_->Tq : d_->Tk);                                                            \
     const dim3 grid((unsigned)((long long)d_->B * d_->H)), block(LNW * 64);                                               \
     switch (d_->dh) {                                                                                                     \
-      case 16: hipLaunchKernelGGL((KERNEL<16, 8>), grid, block, 0, st, ARGS); break;                                      \
-      case 32: hipLaunchKernelGGL((KERNEL<32, 8>), grid, block, 0, st, ARGS); break;                                      \
-      case 64: hipLaunchKernelGGL((KERNEL<64, 8>), grid, block, 0, st, ARGS); break;                                      \
+      case 16: hipLaunchKernelGGL((KERNEL<16, 8, DROP>), grid, block, 0, st, ARGS); break;                                \
+      case 32: hipLaunchKernelGGL((KERNEL<32, 8, DROP>), grid, block, 0, st, ARGS); break;                                \
+      case 64: hipLaunchKernelGGL((KERNEL<64, 8, DROP>), grid, block, 0, st, ARGS); break;                                \
       default:                                                                                                            \
-        if (ntk == 4) hipLaunchKernelGGL((KERNEL<80, 4>), grid, block, 0, st, ARGS);                                      \
-        else if (ntk == 7) hipLaunchKernelGGL((KERNEL<80, 7>), grid, block, 0, st, ARGS);                                 \
-        else hipLaunchKernelGGL((KERNEL<80, 8>), grid, block, 0, st, ARGS);                                               \
+        if (ntk == 4) hipLaunchKernelGGL((KERNEL<80, 4, DROP>), grid, block, 0, st, ARGS);                                \
+        else if (ntk == 7) hipLaunchKernelGGL((KERNEL<80, 7, DROP>), grid, block, 0, st, ARGS);                           \
+        else hipLaunchKernelGGL((KERNEL<80, 8, DROP>), grid, block, 0, st, ARGS);                                         \
     }                                                                                                                     \
+  } while (0)
+#define DMT_LONG_DISPATCH(KERNEL, ARGS)                                                                                   \
+  do {                                                                                                                    \
+    if ((ARGS).drop_on) DMT_LONG_DISPATCH_D(KERNEL, ARGS, true);                                                          \
+    else DMT_LONG_DISPATCH_D(KERNEL, ARGS, false);                                                                        \
   } while (0)
 
 extern "C" int dmt_attn_long_fwd(const dmt_attn_desc* d_, void* stream) {

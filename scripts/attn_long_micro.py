@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cikm2020_dmt_amd import ops
 
-def run(B, Tq, Tk, H, dh, fused, drop, iters=10):
-    ko = ops.KernelOptions(attn_long_fused=fused)
+def run(B, Tq, Tk, H, dh, fused, drop, iters=10, fp8=False):
+    ko = ops.KernelOptions(attn_long_fused=fused, attn_mma_fp8=fp8)
     d = H * dh
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -31,8 +31,8 @@ def run(B, Tq, Tk, H, dh, fused, drop, iters=10):
         torch.cuda.synchronize()
         tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
     fl = 4.0 * B * H * Tq * Tk * dh
-    print("B=%d Tq=%d Tk=%d H=%d dh=%d fused=%d drop=%d  fwd %.3f ms (%.1f TF/s)  bwd %.3f ms (%.1f TF/s)" %
-          (B, Tq, Tk, H, dh, fused, drop, tf / iters, fl / (tf / iters) / 1e9, tb / iters, 2.5 * fl / (tb / iters) / 1e9))
+    print("B=%d Tq=%d Tk=%d H=%d dh=%d fused=%d drop=%d fp8=%d  fwd %.3f ms (%.1f TF/s)  bwd %.3f ms (%.1f TF/s)" %
+          (B, Tq, Tk, H, dh, fused, drop, int(fp8), tf / iters, fl / (tf / iters) / 1e9, tb / iters, 2.5 * fl / (tb / iters) / 1e9))
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
