@@ -18,6 +18,8 @@ cp $O/prof/*/*_kernel_stats.csv $O/kernel_stats.csv; cp $O/prof_L200/*/*_kernel_
 rm -rf $O/prof/*/*_kernel_trace.csv $O/prof_L200/*/*_kernel_trace.csv
 python bench.py --no-cpu-baseline --long-seq 200 --attn-dtype fp8 2>/dev/null | grep '^{' > $O/bench_n1_L200_fp8.json
 python bench.py --no-cpu-baseline --long-seq 200 --attn-dtype fp8 --batch 8192 2>/dev/null | grep '^{' > $O/bench_n1_L200_fp8_b8192.json
+python bench.py --no-cpu-baseline --long-seq 200 2>/dev/null | grep '^{' > $O/bench_n1_L200_bf16.json
+python bench.py --no-cpu-baseline --long-seq 200 --batch 8192 2>/dev/null | grep '^{' > $O/bench_n1_L200_bf16_b8192.json
 python bench.py --no-cpu-baseline --law uniform 2>/dev/null | grep '^{' > $O/bench_n1_uniform.json
 python bench.py --no-cpu-baseline --fresh-batches 4 --age-tables 0 2>/dev/null | grep '^{' > $O/bench_n1_round2_protocol.json
 DMT_DETERMINISTIC=1 python bench.py --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_n1_deterministic.json
