@@ -89,6 +89,43 @@ __device__ __forceinline__ void catch_up(float& pv, float& mv, float& vv, int fr
   }
 }
 
+// The same replay for one ROW per wavefront (lane = element; `act`: this lane holds an element with non-zero moments).  The step sizes
+// lr_t of 64 steps arrive in ONE coalesced load (lane i holds step base + i) and reach the loop by v_readlane with a scalar index: the
+// element-wise form fetched lr_hist[s] inside the loop, one dependent trip to the L2 per replayed step.  Same operations per element,
+// in the same order, as catch_up(): bit-identical results.  Must be called by all 64 lanes.
+__device__ __forceinline__ void catch_up_wave(float& pv, float& mv, float& vv, bool act, int from_step, int to_step,
+                                              const float* __restrict__ lr_hist, float c1, float c2, float eps, int lane) {
+  int s_exit = to_step + 1;                       // first step this lane does NOT replay with adam_update()
+  bool moving = act;
+  for (int base = from_step; base <= to_step; base += 64) {
+    if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
+    const int n = (to_step - base + 1) < 64 ? (to_step - base + 1) : 64;
+    const float lrv = lane < n ? lr_hist[base + lane] : 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lrv), i));
+      if (moving) {
+        const float p0 = pv;
+        adam_update(pv, mv, vv, 0.f, lr, c1, c2, eps);
+        if (pv == p0) { moving = false; s_exit = base + i + 1; }      // p has stopped moving for good
+      }
+      if (__builtin_amdgcn_ballot_w64(moving) == 0ull) break;
+    }
+  }
+  if (!act) return;
+  int s = s_exit;
+  const int rem = to_step - s + 1;
+  if (rem <= 0) return;
+  if (rem <= DMT_ADAM_EXACT_TAIL) {
+    for (; s <= to_step; ++s) {
+      mv = fmaf(0.f - mv, c1, mv);
+      vv = fmaf(fmaf(0.f, 0.f, -vv), c2, vv);
+    }
+  } else {
+    mv *= pow_int(1.f - c1, rem);
+    vv *= pow_int(1.f - c2, rem);
+  }
+}
+
 // Row-sharded tables (tm.shard_w > 1): this rank holds the rows with global id % shard_w == shard_r, densely: local row
 // (row - row_base[t]) / shard_w of table t (every row_base is a multiple of shard_w), last_step index row / shard_w.
 __device__ __forceinline__ int tm_sw(const dmt_table_map& tm) { return tm.shard_w > 1 ? tm.shard_w : 1; }
@@ -188,7 +225,8 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
   const int step = to_step >= 0 ? to_step : reinterpret_cast<const int*>(state)[3];
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   const long long waves = (long long)gridDim.x * 4;
-  for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < n; u += waves) {
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (scalar: the row loop and the replay loop are wave-uniform)
+  for (long long u = (long long)blockIdx.x * 4 + wv; u < n; u += waves) {
     const int row = (int)uniq[u];
     if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables] || !tm_owned(tm, row)) continue;
     const int lsi = row / tm_sw(tm);
@@ -198,12 +236,13 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(const dmt_table_map t
     const int t = find_table(tm, row);
     const int dim = tm.dim[t];
     const long long base = tm_elem(tm, t, row, dim);
-    for (int j = lane; j < dim; j += 64) {
-      float pv = p[base + j], mv = m[base + j], vv = v[base + j];
-      if (mv != 0.f || vv != 0.f) {
-        catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
-        p[base + j] = pv; m[base + j] = mv; v[base + j] = vv;
-      }
+    for (int j0 = 0; j0 < dim; j0 += 64) {
+      const int j = j0 + lane;
+      float pv = 0.f, mv = 0.f, vv = 0.f;
+      if (j < dim) { pv = p[base + j]; mv = m[base + j]; vv = v[base + j]; }
+      const bool act = mv != 0.f || vv != 0.f;            // (zero moments: p does not move and the moments stay zero)
+      catch_up_wave(pv, mv, vv, act, last + 1, step, lr_hist, c1, c2, eps, lane);
+      if (act) { p[base + j] = pv; m[base + j] = mv; v[base + j] = vv; }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) last_step[lsi] = step;
@@ -230,7 +269,8 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm,
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   // grid-stride over the local rows: a 100 M-row table (BASELINE configs[3]) has 25 M four-row blocks = 6.4e9 threads, more than one
   // launch may carry (2^32); tests/test_gpu_configs.py::test_config3_* caught the one-block-per-four-rows form skipping rows
-  for (long long lsi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); lsi < n_local; lsi += (long long)gridDim.x * 4) {   // local row (= global row when not sharded)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (long long lsi = (long long)blockIdx.x * 4 + wv; lsi < n_local; lsi += (long long)gridDim.x * 4) {   // local row (= global row when not sharded)
     const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
     if (row >= tm.row_base[tm.n_tables]) break;
     // (a sharded layout pads every table to a multiple of shard_w rows; the padding rows have storage -- zeros -- and are skipped below)
@@ -238,13 +278,14 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(const dmt_table_map tm,
     if (last >= step) continue;
     const int t = find_table(tm, (int)row);
     const int dim = tm.dim[t];
-    for (int j = lane; j < dim; j += 64) {
+    for (int j0 = 0; j0 < dim; j0 += 64) {
+      const int j = j0 + lane;
       const long long off = tm_elem(tm, t, row, dim) + j;
-      float pv = p[off], mv = m[off], vv = v[off];
-      if (mv != 0.f || vv != 0.f) {
-        catch_up(pv, mv, vv, last + 1, step, lr_hist, c1, c2, eps);
-        p[off] = pv; m[off] = mv; v[off] = vv;
-      }
+      float pv = 0.f, mv = 0.f, vv = 0.f;
+      if (j < dim) { pv = p[off]; mv = m[off]; vv = v[off]; }
+      const bool act = mv != 0.f || vv != 0.f;
+      catch_up_wave(pv, mv, vv, act, last + 1, step, lr_hist, c1, c2, eps, lane);
+      if (act) { p[off] = pv; m[off] = mv; v[off] = vv; }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) last_step[lsi] = step;
