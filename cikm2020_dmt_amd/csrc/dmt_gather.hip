@@ -88,6 +88,11 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
   int* s_chunkfeat = s_colfeat + (g.d_model / VEC + 1);                // [npc]
   int* s_chunkcol = s_chunkfeat + (g.npc + 1);                         // [npc]
   float* s_red = reinterpret_cast<float*>(s_chunkcol + (g.npc + 1));   // [R][CP][VEC]
+  // per sequence-column chunk: where its table columns start and the table's row stride.  (Read from the descriptor inside the item
+  // loop these were VECTOR-addressed global loads -- g.f[f] with f per lane -- and vmcnt retires in order: the wait for item u's
+  // descriptor words also waited for item u - 1's table row, one memory latency per item instead of one per pass of four.)
+  const float** s_ctab = reinterpret_cast<const float**>(smem_raw + ((reinterpret_cast<unsigned char*>(s_red + GT * VEC) - smem_raw + 15) & ~15));   // [d_model / VEC]
+  int* s_cstr = reinterpret_cast<int*>(s_ctab + (g.d_model / VEC + 1));   // [d_model / VEC]
 
   // ---- stage indices and weights (coalesced over t)
   for (int i = tid; i < nf * Tmax; i += GT) {
@@ -115,7 +120,11 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
   if (tid < nf) {
     const GFeat& F = g.f[tid];
     if (F.seq_off >= 0)
-      for (int c = 0; c < F.dim / VEC; ++c) s_colfeat[F.seq_off / VEC + c] = tid;
+      for (int c = 0; c < F.dim / VEC; ++c) {
+        s_colfeat[F.seq_off / VEC + c] = tid;
+        s_ctab[F.seq_off / VEC + c] = F.table + c * VEC;
+        s_cstr[F.seq_off / VEC + c] = F.stride;
+      }
   }
   if (tid == 0) {
     int c = 0;
@@ -153,12 +162,11 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
         const int itc = it < items ? it : items - 1;
         const int t = itc / nch, c = itc - t * nch;
         const int f = s_colfeat[c];
-        const GFeat& F = g.f[f];
         const int col = c * VEC;
         const int id = (t < Tmax) ? s_idq[f * Tmax + t] : 0;
         tt[u] = t; cl[u] = col;
         keep[u] = (id > 0) ? g.scale : 0.f;
-        ld_row<VEC>(F.table + (long long)(id > 0 ? id - 1 : 0) * F.stride + (col - F.seq_off), v[u]);
+        ld_row<VEC>(s_ctab[c] + (long long)(id > 0 ? id - 1 : 0) * s_cstr[c], v[u]);
         ld_row<VEC>(posp + (g.pos ? (long long)t * g.d_model + col : 0ll), p[u]);   // (no positions: a dummy in-bounds read)
       }
 #pragma unroll
@@ -238,7 +246,7 @@ template <typename OutT>
 int launch_group(const GGroup& g, bool vec4, hipStream_t st) {
   const int VECc = vec4 ? 4 : 1;
   size_t lds = (size_t)g.nfeat * g.Tmax * 12 + MAX_GF * 4 + (g.d_model / VECc + 1) * 4 + (size_t)(g.npc + 1) * 8 +
-               (size_t)GT * VECc * 4 + 64;
+               (size_t)GT * VECc * 4 + 64 + (size_t)(g.d_model / VECc + 1) * 12 + 32;
   dim3 grid(g.B), block(GT);
   if (vec4)
     hipLaunchKernelGGL((gather_group_kernel<OutT, 4>), grid, block, lds, st, g);
