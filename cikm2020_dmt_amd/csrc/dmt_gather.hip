@@ -6,8 +6,15 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
+#include <utility>
+#include <stdlib.h>
 
 namespace {
+
+template <int... I, typename F>
+__device__ __forceinline__ void gfor_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void gfor(F&& f) { gfor_impl(std::make_integer_sequence<int, N>{}, f); }
 
 constexpr int GT = 256;          // threads per workgroup
 constexpr int MAX_GF = 8;        // features per group
@@ -345,13 +352,24 @@ __global__ __launch_bounds__(256) void finish_heads_kernel(const uint32_t* __res
 // DET (deterministic mode): the first / last run of a chunk go to a side buffer instead of meeting their neighbours in an atomicAdd;
 // boundary_fixup_kernel then sums the pieces of every such run in chunk order.
 //   part [chunk][2][max_dim] fp32, pseg [chunk][2] int (run id, -1: none); slot 0 = first run of the chunk, slot 1 = its last run
-template <typename GT_, bool DET>
+// DBG (timing experiments only, DMT_EMBGRAD_DEBUG; results are garbage): 1 no gradient-row loads, 2 no stores / atomics, 4 no weight loads
+template <typename GT_, bool DET, int DBG = 0>
 __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_desc d, const uint32_t* __restrict__ skeys,
                                                              const uint32_t* __restrict__ svals, const int* __restrict__ seg,
                                                              long long n, float* __restrict__ grad_rows, int max_dim,
                                                              float* __restrict__ part, int* __restrict__ pseg) {
+  // per-feature words of the descriptor, staged once per workgroup: read per LANE from the kernel argument they are vector-addressed
+  // global loads (a dependent round trip each) in front of every wavefront's work
   __shared__ int s_base[DMT_MAX_FEATURES + 1];
+  __shared__ int s_fT[DMT_MAX_FEATURES], s_fpo[DMT_MAX_FEATURES], s_fdim[DMT_MAX_FEATURES], s_fsid[DMT_MAX_FEATURES], s_fso[DMT_MAX_FEATURES];
+  __shared__ const float* s_fw[DMT_MAX_FEATURES];
+  __shared__ const float* s_fiw[DMT_MAX_FEATURES];
   if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
+  if (threadIdx.x < d.n_features) {
+    const dmt_gather_feature& F = d.feat[threadIdx.x];
+    s_fT[threadIdx.x] = F.T; s_fpo[threadIdx.x] = F.pooled_off; s_fdim[threadIdx.x] = F.dim; s_fsid[threadIdx.x] = F.seq_id;
+    s_fso[threadIdx.x] = F.seq_off; s_fw[threadIdx.x] = F.wts; s_fiw[threadIdx.x] = F.inv_wsum;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -371,31 +389,40 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
     if (key < (uint32_t)d.total_rows) {
       const uint32_t ev = svals[e];
       my_seg = seg[e];
+      // the feature of entry ev: the last f with entry_base[f] <= ev (binary search over <= 32 bases: five LDS reads)
       int f = 0;
-      while (f + 1 < d.n_features && (long long)ev >= s_base[f + 1]) ++f;
-      const dmt_gather_feature& F = d.feat[f];
-      long long r = (long long)ev - s_base[f];
-      const long long per = (long long)d.B * F.T;
+      {
+        int lo_ = 0, hi_ = d.n_features;               // invariant: base[lo_] <= ev < base[hi_]
+        while (hi_ - lo_ > 1) {
+          const int mid = (lo_ + hi_) >> 1;
+          if ((long long)ev >= s_base[mid]) lo_ = mid; else hi_ = mid;
+        }
+        f = lo_;
+      }
+      const int fT = s_fT[f], fpo = s_fpo[f], fsid = s_fsid[f], fso = s_fso[f];
+      uint32_t r = ev - (uint32_t)s_base[f];           // (entry indices are 32-bit: the sort's values)
+      const uint32_t per = (uint32_t)d.B * (uint32_t)fT;
       int kind = 0;
-      if (F.pooled_off >= 0) {
+      if (fpo >= 0) {
         if (r >= per) { kind = 1; r -= per; }
       } else {
         kind = 1;
       }
-      const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
-      my_dim = F.dim;
+      const int b = (int)(r / (uint32_t)fT), t = (int)(r - (uint32_t)b * (uint32_t)fT);
+      my_dim = s_fdim[f];
       if (kind == 0) {
-        const float w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
-        my_scale = w * F.inv_wsum[b];
-        my_src = reinterpret_cast<const GT_*>(d.dpooled) + (long long)b * d.ld_pooled + F.pooled_off;
+        const float* fw = s_fw[f];
+        const float w = (fw && !(DBG & 4)) ? fw[(long long)b * fT + t] : 1.f;
+        my_scale = (DBG & 4) ? w : w * s_fiw[f][b];
+        my_src = reinterpret_cast<const GT_*>(d.dpooled) + (long long)b * d.ld_pooled + fpo;
       } else {
         my_scale = d.seq_scale;
-        if (F.seq_id == DMT_SEQ_TARGET)
-          my_src = reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + F.seq_off;
+        if (fsid == DMT_SEQ_TARGET)
+          my_src = reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + fso;
         else {
-          const long long flat = ((long long)b * d.seq_T[F.seq_id] + t) * d.d_model + F.seq_off;
-          my_src = reinterpret_cast<const GT_*>(d.dseq[F.seq_id]) + flat;
-          if (drop_on) { my_dim |= 1 << 16; my_dseed = d.seq_drop_seed[F.seq_id]; my_flat = (uint32_t)flat; my_scale *= drop_inv; }
+          const long long flat = ((long long)b * d.seq_T[fsid] + t) * d.d_model + fso;
+          my_src = reinterpret_cast<const GT_*>(d.dseq[fsid]) + flat;
+          if (drop_on) { my_dim |= 1 << 16; my_dseed = d.seq_drop_seed[fsid]; my_flat = (uint32_t)flat; my_scale *= drop_inv; }
         }
       }
     }
@@ -419,6 +446,7 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
   }
   auto flush = [&]() {
     if (cur_seg < 0 || lane >= cur_dim) return;
+    if ((DBG & 2) && acc != 12345.678f) return;
     float* dst = &grad_rows[(long long)cur_seg * max_dim + lane];
     if (cur_seg == first_seg || cur_seg == last_seg) {
       if constexpr (DET) part[(wave * 2 + (cur_seg == first_seg ? 0 : 1)) * max_dim + lane] = acc;
@@ -427,38 +455,53 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
       *dst = acc;
     }
   };
-  constexpr int NBATCH = 4;   // gathers in flight per wave (8 measured the same)
-  for (int i0 = 0; i0 < cnt; i0 += NBATCH) {
-    float v[NBATCH], sc[NBATCH];
-    int sg[NBATCH], dm[NBATCH];
+  // ALL the rows of the chunk are requested before the first one is consumed (one register per entry: lane j holds element j of 64
+  // rows).  vmcnt retires loads and stores in issue order: with four gathers per batch every batch's wait also sat out the stores /
+  // atomics of the runs flushed before it (write latency under load: microseconds), a chain of ~16 such waits per wavefront.  Now the
+  // stores follow the last load and nothing waits for them but the end of the wavefront.
+  // (lane i's decoded entry reaches the other lanes through v_readlane with a scalar index -- an SGPR result; __shfl() is a
+  //  ds_bpermute_b32, and eight of those per entry kept the LDS pipe busy for 70 % of this kernel's time)
+  auto rl = [](unsigned x, int i) -> unsigned { return (unsigned)__builtin_amdgcn_readlane((int)x, i); };
+  constexpr int NBATCH = 64;
+  if (cnt > 0) {                 // (a chunk of padding entries only: nothing to read)
+    float v[NBATCH];
 #pragma unroll
     for (int k = 0; k < NBATCH; ++k) {
-      const int i = (i0 + k < cnt) ? i0 + k : cnt - 1;
-      const unsigned lo = __shfl(my_lo, i, 64), hi = __shfl(my_hi, i, 64);
-      sc[k] = __shfl(my_scale, i, 64);
-      sg[k] = __shfl(my_seg, i, 64);
-      const int dmf = __shfl(my_dim, i, 64);
-      dm[k] = dmf & 0xFFFF;
-      const GT_* src = reinterpret_cast<const GT_*>(((unsigned long long)hi << 32) | lo);
+      const int i = __builtin_amdgcn_readfirstlane((k < cnt) ? k : cnt - 1);
+      const unsigned lo = rl(my_lo, i), hi = rl(my_hi, i);
+      const int dmk = (int)rl((unsigned)my_dim, i) & 0xFFFF;
+      // (a GLOBAL pointer: rebuilt from two integers as a generic one the loads were flat_load, which hipcc orders with vmcnt(0)
+      //  against every later store)
+      typedef __attribute__((address_space(1))) const GT_* gsrc_t;
+      const gsrc_t src = (gsrc_t)(((unsigned long long)hi << 32) | lo);
       // branch-free on purpose: a predicated load (or a mask applied right behind it) makes the compiler wait for this row
-      // before it requests the next one, and the four gathers of a batch then pay four memory latencies instead of one
-      const int ln = lane < dm[k] ? lane : dm[k] - 1;
-      v[k] = ldf<GT_>(src + ln);
-      const uint32_t sd = __shfl(my_dseed, i, 64), fl = __shfl(my_flat, i, 64);
-      const bool dropped = drop_on && (dmf >> 16) && !dmt_drop_keep(sd, fl + lane, drop_thr);
-      sc[k] = (lane < dm[k] && !dropped) ? sc[k] : 0.f;
+      // before it requests the next one
+      const int ln = lane < dmk ? lane : dmk - 1;
+      if constexpr ((DBG & 1) != 0) { v[k] = (float)(lo & 3u); }
+      else {
+        const GT_ raw = src[ln];
+        if constexpr (sizeof(GT_) == 2) v[k] = bf2f(raw); else v[k] = raw;
+      }
     }
-#pragma unroll
-    for (int k = 0; k < NBATCH; ++k) {
-      if (i0 + k >= cnt) break;
-      if (sg[k] != cur_seg) {
+    // (a fold over compile-time k: as a loop hipcc keeps v[] in scratch and walks it)
+    gfor<NBATCH>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k >= cnt) return;        // (scalar)
+      float sck = __uint_as_float(rl(__float_as_uint(my_scale), k));
+      const int sgk = (int)rl((unsigned)my_seg, k);
+      const int dmf = (int)rl((unsigned)my_dim, k);
+      const int dmk = dmf & 0xFFFF;
+      const uint32_t sd = rl(my_dseed, k), fl = rl(my_flat, k);
+      const bool dropped = drop_on && (dmf >> 16) && !dmt_drop_keep(sd, fl + lane, drop_thr);
+      sck = (lane < dmk && !dropped) ? sck : 0.f;
+      if (sgk != cur_seg) {
         flush();
         acc = 0.f;
-        cur_seg = sg[k];
-        cur_dim = dm[k];
+        cur_seg = sgk;
+        cur_dim = dmk;
       }
-      acc += sc[k] * v[k];
-    }
+      acc += sck * v[k];
+    });
   }
   flush();
 }
@@ -510,9 +553,10 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const uint32_t* __rest
       int sg[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = (i0 + u < cnt) ? i0 + u : cnt - 1;
-        const uint32_t ev = __shfl(my_val, i, 64);
-        sg[u] = (i0 + u < cnt) ? __shfl(my_seg, i, 64) : -1;      // -1: past the end or an invalid (padding) key
+        // (v_readlane with a scalar index, not __shfl: a ds_bpermute per entry and value kept the LDS pipe busy, see embgrad_reduce_kernel)
+        const int i = __builtin_amdgcn_readfirstlane((i0 + u < cnt) ? i0 + u : cnt - 1);
+        const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)my_val, i);
+        sg[u] = (i0 + u < cnt) ? __builtin_amdgcn_readlane(my_seg, i) : -1;      // -1: past the end or an invalid (padding) key
         // branch-free (a predicated load would be waited for before the next one is requested): padding entries re-read
         // the row of entry 0, which is valid whenever the chunk has any valid entry, and are dropped below by sg < 0
         const uint32_t evs = sg[u] >= 0 ? ev : ev0;
@@ -781,9 +825,18 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
   if (d->grad_dtype == DMT_F32)
     hipLaunchKernelGGL((embgrad_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
                        (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
-  else
-    hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
-                       (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
+  else {
+    const char* dbg = getenv("DMT_EMBGRAD_DEBUG");     // timing experiments; never set in production
+    const int v = dbg ? atoi(dbg) : 0;
+#define DMT_EG_DBG(V) case V: hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false, V>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id, (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr); break;
+    switch (v) {
+      DMT_EG_DBG(1) DMT_EG_DBG(2) DMT_EG_DBG(3) DMT_EG_DBG(4) DMT_EG_DBG(7)
+      default:
+        hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                           (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
+    }
+#undef DMT_EG_DBG
+  }
   DMT_CHECK_LAUNCH("dmt_embgrad_reduce");
   return DMT_OK;
 }
