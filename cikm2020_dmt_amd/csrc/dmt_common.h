@@ -55,15 +55,26 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// Wavefront-wide reductions on the VALU: four DPP steps (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) leave
+// every lane with the result of its 16-lane row, four v_readlane combine the rows.  (__shfl_xor is a ds_bpermute_b32: six LDS
+// instructions per reduction -- the LayerNorm kernels, two reductions per 640-byte row, were bound by the LDS pipe, not by memory.)
+template <int CTRL> __device__ __forceinline__ float dmt_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dmt_lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dmt_dpp<0xB1>(v);
+  v += dmt_dpp<0x4E>(v);
+  v += dmt_dpp<0x141>(v);
+  v += dmt_dpp<0x140>(v);
+  return (dmt_lane_f(v, 0) + dmt_lane_f(v, 16)) + (dmt_lane_f(v, 32) + dmt_lane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dmt_dpp<0xB1>(v));
+  v = fmaxf(v, dmt_dpp<0x4E>(v));
+  v = fmaxf(v, dmt_dpp<0x141>(v));
+  v = fmaxf(v, dmt_dpp<0x140>(v));
+  return fmaxf(fmaxf(dmt_lane_f(v, 0), dmt_lane_f(v, 16)), fmaxf(dmt_lane_f(v, 32), dmt_lane_f(v, 48)));
 }
 
 // counter-based dropout mask shared by every kernel (and restated in oracle/dmt_oracle.py:dropout_mask)

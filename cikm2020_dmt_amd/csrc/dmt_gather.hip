@@ -275,17 +275,24 @@ __global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_des
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   int f = 0;
-  while (f + 1 < d.n_features && e >= s_base[f + 1]) ++f;
+  {
+    int lo_ = 0, hi_ = d.n_features;                 // the last f with entry_base[f] <= e (binary search: five LDS reads)
+    while (hi_ - lo_ > 1) {
+      const int mid = (lo_ + hi_) >> 1;
+      if (e >= s_base[mid]) lo_ = mid; else hi_ = mid;
+    }
+    f = lo_;
+  }
   const dmt_gather_feature& F = d.feat[f];
-  long long r = e - s_base[f];
-  const long long per = (long long)d.B * F.T;
+  uint32_t r = (uint32_t)(e - s_base[f]);            // (entry counts are below 2^31: entry_base is int32)
+  const uint32_t per = (uint32_t)d.B * (uint32_t)F.T;
   int kind = 0;
   if (F.pooled_off >= 0) {
     if (r >= per) { kind = 1; r -= per; }
   } else {
     kind = 1;
   }
-  const int b = (int)(r / F.T), t = (int)(r - (long long)b * F.T);
+  const int b = (int)(r / (uint32_t)F.T), t = (int)(r - (uint32_t)b * (uint32_t)F.T);
   int len = F.lens ? F.lens[b] : F.T;
   uint32_t key = (uint32_t)d.total_rows;
   if (t < len) {
