@@ -132,12 +132,28 @@ __device__ __forceinline__ Q1mLds q1m_carve(unsigned char* base, int T, int H, b
   return L;
 }
 
-// rows [k0, k0 + rows) of example b's memory -> LDS (rows past T: zeros)
+// rows [k0, k0 + rows) of example b's memory -> LDS (rows past T: zeros).  All of a thread's 16-byte requests (at most ten: rows <= CK)
+// are in flight together, branch-free (rows past T re-read row T - 1 and are replaced by zeros): the rolled load -> wait -> store loop
+// paid one memory latency per piece, ten in a row at T = 64 -- most of a workgroup's lifetime.
 __device__ __forceinline__ void stage_rows(bf16_t* __restrict__ s_mem, const bf16_t* __restrict__ mem_b, long long m_rs, int k0, int rows, int T, int tid) {
-  for (int c = tid; c < rows * NCH; c += 256) {
-    const int r = c / NCH, ch = c - r * NCH;
-    const uint4 v = (k0 + r < T) ? *reinterpret_cast<const uint4*>(mem_b + (long long)(k0 + r) * m_rs + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(s_mem + r * RS + ch * 8) = v;
+  constexpr int IT = (CK * NCH + 255) / 256;
+  uint4 v[IT];
+  const int n = rows * NCH;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256;
+    const int cc = c < n ? c : n - 1;
+    const int r = cc / NCH, ch = cc - r * NCH;
+    const int rr = (k0 + r < T) ? k0 + r : T - 1;
+    v[i] = *reinterpret_cast<const uint4*>(mem_b + (long long)rr * m_rs + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = tid + i * 256;
+    if (c < n) {
+      const int r = c / NCH, ch = c - r * NCH;
+      *reinterpret_cast<uint4*>(s_mem + r * RS + ch * 8) = (k0 + r < T) ? v[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 
