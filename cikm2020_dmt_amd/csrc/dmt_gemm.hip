@@ -1093,6 +1093,109 @@ void launch_gemm(const GemmArgs& g, dim3 grid, hipStream_t st) {
 #undef DMT_GEMM_CASE
 }
 
+// =====================================================================================================================
+// B-row GEMMs with a short reduction (the decoders' per-head products around the raw-memory attention, dmt_q1mem.hip: M = batch rows,
+// K <= 384, N <= 320, batch = heads; bf16, both operands k-contiguous, bf16 C; bias / relu / residual epilogue).  The tiled kernels
+// above are built for long reductions (a k-step pipeline, a persistent tile loop); on these shapes -- one or two k-steps, K not a
+// multiple of 64, batch strides -- they ran the generic path at ~25 us per launch, 14 launches per step.  Here a workgroup owns
+// [64 rows x all N columns] of one batch member: the A tile and the WHOLE B operand go to LDS in one round of 16-byte requests, all in
+// flight together (branch-free: rows past the end re-read the last row and are zeroed on the way in; the K tail is zero-filled to a
+// multiple of 16), then KP / 16 MFMA steps per 32 x 32 output tile, operands swapped (D^T = B A^T) so that a lane owns ONE output row
+// and four consecutive columns per register quad: the epilogue is 8-byte pieces per lane.
+constexpr int SG_BM = 64;
+constexpr int SG_IT = 28;                 // 16-byte pieces per thread (256 threads): (64 + NP) * KP / 8 <= 7168
+__host__ __device__ inline int sg_kp(int K) { return (K + 15) & ~15; }
+__host__ __device__ inline int sg_np(int N) { return (N + 31) & ~31; }
+__host__ __device__ inline size_t sg_lds(int N, int K) { return (size_t)(SG_BM + sg_np(N)) * (sg_kp(K) + 8) * 2; }
+
+__global__ __launch_bounds__(NT) void gemm_small_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sg_smem[];
+  const int KP = sg_kp(g.K), NP = sg_np(g.N), RS = KP + 8, CH = g.K / 8, CHP = KP / 8;
+  bf16_t* As = reinterpret_cast<bf16_t*>(sg_smem);      // [64][RS]
+  bf16_t* Bs = As + SG_BM * RS;                         // [NP][RS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bt = blockIdx.y, m0 = blockIdx.x * SG_BM;
+  const bf16_t* Ag = reinterpret_cast<const bf16_t*>(g.A) + (long long)bt * g.a_bs + (long long)m0 * g.a_rs;
+  const bf16_t* Bg = reinterpret_cast<const bf16_t*>(g.B) + (long long)bt * g.b_bs;
+  const int a_rows = (g.M - m0) < SG_BM ? (g.M - m0) : SG_BM;
+  const int total = (SG_BM + NP) * CHP;
+  uint4 v[SG_IT];
+#pragma unroll
+  for (int i = 0; i < SG_IT; ++i) {
+    int c = tid + i * NT;
+    c = c < total ? c : total - 1;
+    const int r = c / CHP, ch = c - r * CHP;
+    const int chc = ch < CH ? ch : CH - 1;
+    const bf16_t* src = r < SG_BM ? Ag + (long long)(r < a_rows ? r : a_rows - 1) * g.a_rs
+                                  : Bg + (long long)((r - SG_BM) < g.N ? (r - SG_BM) : g.N - 1) * g.b_cs;
+    v[i] = *reinterpret_cast<const uint4*>(src + chc * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < SG_IT; ++i) {
+    const int c = tid + i * NT;
+    if (c < total) {
+      const int r = c / CHP, ch = c - r * CHP;
+      const bool ok = ch < CH && (r < SG_BM ? r < a_rows : (r - SG_BM) < g.N);
+      *reinterpret_cast<uint4*>(As + (long long)r * RS + ch * 8) = ok ? v[i] : make_uint4(0u, 0u, 0u, 0u);   // (Bs follows As: row r >= 64)
+    }
+  }
+  __syncthreads();
+
+  const int wm = wave & 1, wn = wave >> 1;              // row block (32 rows), parity of the column blocks
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int ncb = NP / 32;                              // column blocks: this wave takes wn, wn + 2, ...
+  constexpr int MAXJ = 5;                               // N <= 320
+  f32x16_t acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const bf16_t* arow = As + (32 * wm + l31) * RS + 8 * hi;
+  const bf16_t* brow = Bs + (32 * wn + l31) * RS + 8 * hi;
+  for (int s = 0; s < KP / 16; ++s) {
+    const bf16x8_t ax = *reinterpret_cast<const bf16x8_t*>(arow + 16 * s);
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (wn + 2 * j < ncb) {                            // (scalar)
+        const bf16x8_t bw = *reinterpret_cast<const bf16x8_t*>(brow + (long long)(64 * j) * RS + 16 * s);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, ax, acc[j], 0, 0, 0);   // D^T[n, m]: lane = row m, registers = columns
+      }
+    }
+  }
+  // ---- epilogue: x = acc + bias; relu on the first act_ncols columns; + residual; one rounding (the order of gemm_kernel)
+  const long long m = (long long)m0 + 32 * wm + l31;
+  if (m < g.M) {
+    const float* bias = g.bias ? g.bias + (long long)bt * g.bias_bs : nullptr;
+    const bf16_t* rrow = g.resid ? reinterpret_cast<const bf16_t*>(g.resid) + (long long)bt * g.resid_bs + m * g.ldr : nullptr;
+    bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + (long long)bt * g.c_bs + m * g.ldc;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (wn + 2 * j >= ncb) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = 32 * (wn + 2 * j) + 8 * q + 4 * hi;
+        if (n0 >= g.N) continue;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x[i] = acc[j][4 * q + i] + (bias ? bias[n0 + i] : 0.f);
+          if (n0 + i < g.act_ncols) x[i] = fmaxf(x[i], 0.f);
+        }
+        if (rrow) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(rrow + n0);
+          x[0] += __uint_as_float(rv.x << 16); x[1] += __uint_as_float(rv.x & 0xFFFF0000u);
+          x[2] += __uint_as_float(rv.y << 16); x[3] += __uint_as_float(rv.y & 0xFFFF0000u);
+        }
+        uint2 ov;
+        ov.x = dmt_pack_bf16(x[0], x[1]);
+        ov.y = dmt_pack_bf16(x[2], x[3]);
+        *reinterpret_cast<uint2*>(crow + n0) = ov;
+      }
+    }
+  }
+}
+
 int pick_mode(const void* P, long long rs, long long cs, int esz, int epv) {
   const bool aligned = (((uintptr_t)P) % 16 == 0);
   if (cs == 1 && aligned && (rs % epv == 0)) return 0;
@@ -1161,6 +1264,21 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
                     (d->K % 64 == 0) && d->N <= GL_MAX_N;
   const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok &&
                        (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
+  // the B-row class (short reduction, any batch): one round of loads, whole B operand in LDS
+  const bool small = d->in_dtype == DMT_BF16 && !glds && !dw_glds && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && d->gate == nullptr &&
+                     d->K % 8 == 0 && d->K <= 384 && d->N % 4 == 0 && d->N <= 320 && d->M <= 65536 &&
+                     (long long)(SG_BM + sg_np(d->N)) * (sg_kp(d->K) / 8) <= (long long)SG_IT * NT && sg_lds(d->N, d->K) <= 120 * 1024 &&
+                     (d->resid == nullptr || d->ldr % 4 == 0);
+  if (small) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((d->M + SG_BM - 1) / SG_BM), (unsigned)batch), dim3(NT), sg_lds(d->N, d->K), st, g);
+    DMT_CHECK_LAUNCH("dmt_gemm(small)");
+    return DMT_OK;
+  }
   if (dw_glds) {
     const dim3 gd((unsigned)(nblk < GL_GRID ? nblk : GL_GRID));
     // long reductions (the 204800-row weight gradients) run three 16 KB stages ahead, short ones one 32 KB stage:
