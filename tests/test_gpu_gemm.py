@@ -94,6 +94,43 @@ def test_gemm_batched(cuda, dtype):
     assert (o.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < _tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K,Bt", [(4096, 320, 80, 4), (4096, 80, 328, 4), (4096, 80, 320, 4), (77, 36, 8, 3), (130, 64, 376, 1), (1, 4, 16, 2)])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu_resid"])
+def test_gemm_small_kernel_route(cuda, M, N, K, Bt, epi):
+    """The B-row kernel of the decoders' per-head products (gemm_small_kernel: bf16, both operands k-contiguous, K <= 384, N <= 320, any
+    batch): the step's own shapes and awkward ones (rows not a multiple of 64, a K tail of 8, a partial last 32-column block, batch strides
+    wider than the operands), with and without the bias / relu / residual epilogue; the launch route is asserted."""
+    from cikm2020_dmt_amd import _lib as L
+    dt = torch.bfloat16
+    lda, ldb, ldc = K + 16, K + 8, (N + 7) // 8 * 8 + 8         # padded leading dimensions (16-byte aligned rows)
+    xa = torch.zeros((Bt, M, lda), dtype=dt, device=cuda)
+    wb = torch.zeros((Bt, N, ldb), dtype=dt, device=cuda)       # B stored as [n][k]: k-contiguous
+    x, xr = _mk((Bt, M, K), dt, cuda, 21)
+    w, wr = _mk((Bt, N, K), dt, cuda, 22)
+    xa[:, :, :K] = x
+    wb[:, :, :K] = w
+    o = torch.full((Bt, M, ldc), 7.0, dtype=dt, device=cuda)
+    kw = dict(batch=Bt, a_bs=M * lda, b_bs=N * ldb, c_bs=M * ldc)
+    ref = torch.bmm(xr, wr.transpose(1, 2))
+    if epi != "plain":
+        b = torch.randn(Bt, N, device=cuda)
+        r, rr = _mk((Bt, M, N), dt, cuda, 23)
+        rp = torch.zeros((Bt, M, ldc), dtype=dt, device=cuda)
+        rp[:, :, :N] = r
+        nrelu = (N // 2) & ~3
+        kw.update(bias=b, bias_bs=N, act_ncols=nrelu, resid=rp, ldr=ldc, resid_bs=M * ldc)
+        ref = ref + b.double().cpu()[:, None, :]
+        ref[:, :, :nrelu] = ref[:, :, :nrelu].clamp_min(0)
+        ref = ref + rr
+    with L.route_trace() as rt:
+        ops.gemm(xa, lda, 1, wb, 1, ldb, M, N, K, o, ldc, **kw)
+        torch.cuda.synchronize()
+    assert rt.counts.get("dmt_gemm(small)", 0) == 1, rt.counts
+    got = o.double().cpu()
+    assert (got[:, :, :N] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6) < _tol(dt)
+    assert (got[:, :, N:] == 7.0).all()                         # nothing written past column N
+
+
 def test_gemm_rejects_bad_args(cuda):
     from cikm2020_dmt_amd._lib import DmtError
     x = torch.zeros((4, 4), device=cuda)
