@@ -257,6 +257,33 @@ def deferred_wgrads_pending():
     return len(_deferred[0]) if _deferred[0] is not None else 0
 
 
+# One-GPU backward: the B-row weight gradients of the MMoE / tower region (gradient arena at or behind `from_offset`) leave the compute
+# stream as they are met and run on an idle sequence lane.  That stretch of backward is ONE dependent chain of small kernels (layer-0
+# input gradient <- expert kernels <- heads <- loss) with the chip mostly idle; nothing on the chain reads a weight gradient, so the
+# seven GEMMs (one of them 51 GFLOP) only lengthened it.  The lanes' own work starts when dL/dz exists, i.e. after that chain.
+_fork = [None]
+
+
+def begin_fork_wgrads(stream, from_offset):
+    _fork[0] = dict(stream=stream, off=int(from_offset), n=0)
+
+
+def end_fork_wgrads():
+    """-> the state of begin_fork_wgrads() (n = how many launches went to the lane; the caller waits for the lane) or None."""
+    st, _fork[0] = _fork[0], None
+    return st
+
+
+def _fork_stream(M, *grad_views):
+    f = _fork[0]
+    if f is None or M >= WGRAD320_MIN_ROWS:
+        return None
+    for g in grad_views:
+        if g is not None and g.storage_offset() < f["off"]:
+            return None
+    return f["stream"]
+
+
 def _deferred_wgrad320(x, dz, gw, gb, k_is_320):
     cur = torch.cuda.current_stream(x.device)
     x.record_stream(cur)          # (operands of the side-lane sequences were allocated on their streams)
@@ -329,6 +356,16 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
                 gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
                      split_k=split, accumulate=True)
             _deferred[0].append(_later)
+            return None, None
+        side = _fork_stream(M, gw, gb)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(x.device))       # x, dz were produced on the current stream
+            with torch.cuda.stream(side):
+                x.record_stream(side)
+                dz.record_stream(side)
+                gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
+                     split_k=split, accumulate=True)
+            _fork[0]["n"] += 1
             return None, None
         gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
              split_k=split, accumulate=True)

@@ -74,6 +74,7 @@ class Trainer:
         # those kernels inside backward (10.8 against 10.4 ms), so there it is off unless asked for
         ov = os.environ.get("DMT_DP_OVERLAP_WGRADS", "auto")
         self.overlap_wgrads = (parallel.world()[1] > 1) if ov == "auto" else (ov == "1")
+        self.fork_mmoe_wgrads = os.environ.get("DMT_FORK_MMOE_WGRADS", "1") == "1"    # one-GPU backward: MMoE / tower weight gradients on an idle lane
         self.sparse_lane = os.environ.get("DMT_SPARSE_LANE", "0") == "1"     # one-GPU step: id-bound tail beside the deferred weight gradients (off: even at L=50, -3 % at L=200)
         self.index_stream, self._ix_stream = os.environ.get("DMT_INDEX_STREAM", "1") == "1", None    # index plane (id sort, exchange plan) on a side stream: sync_rows
         # lazy Adam: the pending zero-gradient updates of batch i + 1's rows can be replayed on the index lane WHILE step i runs
@@ -421,6 +422,12 @@ class Trainer:
                         self._early = (off, parallel.allreduce_dense_(self.store.grads[off:], async_op=True, force=self.force_dp))
                     return g
                 z.register_hook(_hook)
+        fork_lane = None
+        if (not dp) and self.fork_mmoe_wgrads and self.device.type == "cuda" and self.engine.seq_streams:
+            pool = [st for st in self.engine._seq_stream_pool(max(2, len(self.spec["attention_embed_pairs"]))) if st is not None]
+            if pool:
+                fork_lane = pool[-1]
+                ops.begin_fork_wgrads(fork_lane, self.store.leaves["mmoe_layers/l0_cat_weights"].offset)
         try:
             loss.backward()
         except BaseException:
@@ -429,6 +436,10 @@ class Trainer:
             raise
         finally:
             self.engine.defer_sparse = False
+            forked = ops.end_fork_wgrads()
+        if fork_lane is not None and forked is not None and forked["n"]:
+            torch.cuda.current_stream(self.device).wait_stream(fork_lane)     # the forked weight gradients are part of this backward
+        self.n_forked = forked["n"] if forked is not None else 0
         self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
         return loss.detach()
