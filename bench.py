@@ -208,28 +208,32 @@ def main():
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process (rocprofv3 wraps it); the committed
     # measurement of the same command is quoted (profiles/r03_traffic.json, made by scripts/pmc_traffic.sh: separate --pmc passes,
     # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes)
-    tfile = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    # (the newest committed counter file whose kernel-source sha is this build's: profiles/rNN_traffic.json)
+    import glob
     default_cfg = (args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and not args.shard_tables and not args.sku_rows
                    and args.fresh_batches == 64 and args.age_tables == 100000)
-    tj, traffic_stale = {}, None
-    if default_cfg and os.path.exists(tfile):
-        try:
-            tall = json.load(open(tfile))
+    tj, traffic_stale, tname = {}, None, None
+    if default_cfg:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
+        for tfile in cands:
+            try:
+                tall = json.load(open(tfile))
+            except Exception:
+                continue
             # the counters describe the kernels they were collected from: a traffic file made from other kernel sources is not quoted
             if tall.get("kernel_source_sha") == kernel_source_sha():
-                tj = tall.get(args.law, {})
-            else:
-                traffic_stale = "profiles/r03_traffic.json was collected from other kernel sources (sha %s, now %s): not quoted" % (
-                    str(tall.get("kernel_source_sha"))[:12], kernel_source_sha()[:12])
-        except Exception:
-            tj = {}
+                tj, tname, traffic_stale = tall.get(args.law, {}), "profiles/" + os.path.basename(tfile), None
+                break
+            if traffic_stale is None:
+                traffic_stale = "profiles/%s was collected from other kernel sources (sha %s, now %s): not quoted" % (
+                    os.path.basename(tfile), str(tall.get("kernel_source_sha"))[:12], kernel_source_sha()[:12])
     for f in fams:
         t = tj.get(f["key"])
         if traffic_stale:
             f["traffic_source"] = traffic_stale
         if t:
             f["traffic"] = int(t["hbm_bytes_per_step"] / max(f["launches_per_step"], 1e-9))      # per launch as counted here
-            f["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % t["launches"]
+            f["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + WRITE_SIZE, separate passes, same command, %d launches)" % (tname, t["launches"])
     # `roofline` names ONE kernel (its rocprofv3 row must agree): the single-kernel family with the largest share of the step; the
     # dmt_gemm family spans three kernels and is listed with the others
     single = [f for f in fams if f["key"] not in ("gemm_bf16", "gemm_f32", "attn", "attn_long", "q1mem", "mmoe_experts", "proj")] or fams
@@ -244,7 +248,7 @@ def main():
     tg = tj.get("gather_fwd")
     if tg:
         gather["traffic"] = int(tg["hbm_bytes_per_step"] / max(ga_per_step, 1e-9))   # one dmt_gather_fwd call = its group kernels
-        gather["traffic_source"] = "profiles/r03_traffic.json (same method; the Zipf head is served by L2 / Infinity Cache, uniform ids are not)"
+        gather["traffic_source"] = "%s (same method; the Zipf head is served by L2 / Infinity Cache, uniform ids are not)" % tname
 
     out = {
         "metric": "train samples/sec", "value": round(args.batch * world * args.steps / dt, 1), "unit": "samples/s",
@@ -306,7 +310,11 @@ def age_tables(tr, sp, args, seq_lens):
     z ~ Zipf(1.05) truncated at 2^63 as numpy draws it; a feature with T ids per example makes B * T draws per step; the pooled path
     touches row id, the Transformer path row id - 1 (base.py:87-89).  The model is checked against the run: `expected_distinct_rows`
     beside the measured distinct rows of a batch."""
-    from scipy.special import zeta
+    def zeta(s_, _q=1, N=4096):
+        # Riemann zeta by Euler-Maclaurin (no scipy needed on the bench box): sum_{n<N} n^-s + N^(1-s)/(s-1) + N^-s/2 + s N^(-s-1)/12 - ...
+        n = np.arange(1, N, dtype=np.float64)
+        return float((n ** -s_).sum() + N ** (1.0 - s_) / (s_ - 1.0) + 0.5 * N ** -s_ + s_ * N ** (-s_ - 1.0) / 12.0
+                     - s_ * (s_ + 1.0) * (s_ + 2.0) * N ** (-s_ - 3.0) / 720.0)
     K = int(args.age_tables)
     st, opt, dev = tr.store, tr.opt, tr.device
     B = args.batch

@@ -15,6 +15,7 @@ DMT_F32, DMT_BF16, DMT_FP8_E4M3 = 0, 1, 2
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
+DMT_ABI_VERSION = 3        # include/dmt_hip.h: the revision this binding was written against (checked by load())
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -208,6 +209,10 @@ def load():
     lib.dmt_last_error.argtypes = []
     lib.dmt_build_arch.restype = C.c_char_p
     lib.dmt_version.restype = c_i32
+    lib.dmt_version.argtypes = []
+    if lib.dmt_version() != DMT_ABI_VERSION:
+        raise RuntimeError("libdmt_hip.so reports ABI revision %d, this binding was written against %d (include/dmt_hip.h: DMT_ABI_VERSION); "
+                           "rebuild the library (make -C cikm2020_dmt_amd/csrc)" % (lib.dmt_version(), DMT_ABI_VERSION))
     lib.dmt_ln_bwd_partials.restype = c_i32
     lib.dmt_ln_bwd_partials.argtypes = [c_i64]
     lib.dmt_chain_supported.restype = c_i32

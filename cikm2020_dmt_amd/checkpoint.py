@@ -170,6 +170,14 @@ def restore(trainer, model_path: str, ckpt_name: Optional[str] = None) -> int:
             # the same sharding: this rank's rows, as they lie
             dense = {k: z[k] for k in z.files if not k.startswith("__")}
             want = _expected_shapes(store)
+            have = {(k[len(PREFIX):] if k.startswith(PREFIX) else k) for k in dense}
+            missing = sorted(n for n in store.views if n not in have)
+            if missing:      # (a truncated / mismatched dense file must not leave freshly initialised weights in place)
+                raise KeyError("checkpoint %s lacks %d dense variables, e.g. %s" % (base, len(missing), missing[:3]))
+            with np.load(files[store.shard[0]]) as zs:
+                lacking = sorted(name for name in store.tables if PREFIX + name not in zs.files)
+                if lacking:
+                    raise KeyError("shard file %s lacks tables %s" % (files[store.shard[0]], lacking[:3]))
             for k, a in dense.items():
                 n = k[len(PREFIX):] if k.startswith(PREFIX) else k
                 if n in store.views:

@@ -587,8 +587,9 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
   a.mask = (unsigned short*)d->mask;
   a.tiles = (int)cdiv64(d->M, 128);
   const int grid = a.tiles < 256 ? a.tiles : 256;
+#ifdef DMT_TIMING_EXPERIMENTS   // (scripts/ ablations only: `make EXPERIMENTS=1`; the shipped library reads no environment)
   if constexpr (G::KIN == 320) {
-    const char* dbg = getenv("DMT_CHAIN_DEBUG");   // timing experiments (see DBG above); never set in production
+    const char* dbg = getenv("DMT_CHAIN_DEBUG");   // timing experiments (see DBG above)
     const int v = dbg ? atoi(dbg) : 0;
     if (v != 0 && d->mode == DMT_CHAIN_FFN_LN) {
 #define DMT_CHAIN_DBG(V) case V: hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, V>), dim3(grid), dim3(CH_NT), 0, st, a); break;
@@ -602,6 +603,7 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
       return DMT_OK;
     }
   }
+#endif
   if (d->mode == DMT_CHAIN_FFN_LN)
     hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN>), dim3(grid), dim3(CH_NT), 0, st, a);
   else
@@ -888,8 +890,9 @@ extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64
     a.out = (bf16_t*)out; a.ld_out = ld_out;
     a.tiles = (int)cdiv64(M, 128);
     int grid = a.tiles < 256 ? a.tiles : 256;
-    if (const char* gq = getenv("DMT_PROJ_GRID")) { const int v = atoi(gq); if (v > 0 && v < grid) grid = v; }   // (timing experiments)
-    const char* dbg = getenv("DMT_PROJ_DEBUG");   // timing experiments (see DBG above); never set in production
+#ifdef DMT_TIMING_EXPERIMENTS   // (scripts/ ablations only: `make EXPERIMENTS=1`)
+    if (const char* gq = getenv("DMT_PROJ_GRID")) { const int v = atoi(gq); if (v > 0 && v < grid) grid = v; }
+    const char* dbg = getenv("DMT_PROJ_DEBUG");   // timing experiments (see DBG above)
     switch (dbg ? atoi(dbg) : 0) {
       case 1: hipLaunchKernelGGL((proj_kernel<G, 1>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       case 2: hipLaunchKernelGGL((proj_kernel<G, 2>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
@@ -903,6 +906,9 @@ extern "C" int dmt_proj(int32_t kin, int32_t n, int64_t M, const void* in, int64
       case 15: hipLaunchKernelGGL((proj_kernel<G, 15>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a); break;
       default: hipLaunchKernelGGL((proj_kernel<G>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a);
     }
+#else
+    hipLaunchKernelGGL((proj_kernel<G>), dim3(grid), dim3(PJ_NT), 0, (hipStream_t)stream, a);
+#endif
     DMT_CHECK_LAUNCH("dmt_proj");
     return DMT_OK;
   });

@@ -59,7 +59,7 @@ extern "C" int dmt_route_dump(char* buf, int32_t cap) {
   }
   return DMT_OK;
 }
-extern "C" int dmt_version(void) { return 1; }
+extern "C" int dmt_version(void) { return DMT_ABI_VERSION; }
 extern "C" const char* dmt_build_arch(void) { return "gfx950"; }
 
 // sizeof() of every ABI struct, so bindings in other languages can verify their layout (tests/test_abi.py).

@@ -833,7 +833,8 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
     hipLaunchKernelGGL((embgrad_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
                        (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
   else {
-    const char* dbg = getenv("DMT_EMBGRAD_DEBUG");     // timing experiments; never set in production
+#ifdef DMT_TIMING_EXPERIMENTS   // (scripts/ ablations only: `make EXPERIMENTS=1`; the shipped library reads no environment)
+    const char* dbg = getenv("DMT_EMBGRAD_DEBUG");     // timing experiments: the DBG variants skip loads / stores, results are garbage
     const int v = dbg ? atoi(dbg) : 0;
 #define DMT_EG_DBG(V) case V: hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false, V>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id, (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr); break;
     switch (v) {
@@ -843,6 +844,10 @@ extern "C" int dmt_embgrad_reduce(const dmt_embgrad_desc* d, const uint32_t* sor
                            (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
     }
 #undef DMT_EG_DBG
+#else
+    hipLaunchKernelGGL((embgrad_reduce_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, st, *d, sorted_keys, sorted_vals, seg_id,
+                       (long long)n, grad_rows, max_dim, (float*)nullptr, (int*)nullptr);
+#endif
   }
   DMT_CHECK_LAUNCH("dmt_embgrad_reduce");
   return DMT_OK;

@@ -10,6 +10,7 @@
 //   strided        (mode 2): scalar loads,
 // so the same kernel serves Y = X W^T-shadow, dX = dY W and dW = X^T dY (reduction over the strided dim of both).
 #include "dmt_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -1270,10 +1271,22 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
                      (long long)(SG_BM + sg_np(d->N)) * (sg_kp(d->K) / 8) <= (long long)SG_IT * NT && sg_lds(d->N, d->K) <= 120 * 1024 &&
                      (d->resid == nullptr || d->ldr % 4 == 0);
   if (small) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-      attr_set = true;
+    // the attribute belongs to the (function, device) pair: set it on every device this process launches from (a host-side table
+    // lookup per call after the first; no process-wide flag that a second GPU or a second host thread could find already set)
+    const size_t dyn = (size_t)sg_lds(d->N, d->K);
+    if (dyn > 64 * 1024) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      static std::atomic<unsigned long long> attr_done{0ull};        // bit per device ordinal < 64
+      const unsigned long long bit = dev < 64 ? (1ull << dev) : 0ull;
+      if (bit == 0ull || (attr_done.load(std::memory_order_acquire) & bit) == 0ull) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        if (e != hipSuccess) {
+          dmt_set_error("dmt_gemm(small): hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s", dev, hipGetErrorString(e));
+          return DMT_ERR_LAUNCH;
+        }
+        attr_done.fetch_or(bit, std::memory_order_release);
+      }
     }
     hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((d->M + SG_BM - 1) / SG_BM), (unsigned)batch), dim3(NT), sg_lds(d->N, d->K), st, g);
     DMT_CHECK_LAUNCH("dmt_gemm(small)");

@@ -533,7 +533,10 @@ extern "C" int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream) {
   const bool drop = d->drop_keep > 0.f && d->drop_keep < 1.f;
   a.drop_thr = drop ? (unsigned)(d->drop_keep * 16777216.0f) : 0u;
   a.drop_inv_keep = drop ? 1.0f / d->drop_keep : 1.0f;
+  a.dbg = 0;
+#ifdef DMT_TIMING_EXPERIMENTS
   { const char* e = getenv("DMT_MHSA_DEBUG"); a.dbg = e ? atoi(e) : 0; }
+#endif
   const int grid = a.tiles < 256 ? a.tiles : 256;
   hipLaunchKernelGGL(mhsa_fwd_kernel, dim3(grid), dim3(MH_NT), 0, (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_mhsa_block_fwd");

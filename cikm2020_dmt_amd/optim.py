@@ -69,6 +69,19 @@ class TFAdam:
         self.global_step += 1
         self._begun = False
 
+    def abort_step(self):
+        """Undo begin() for a step that will not be applied (forward / backward / a collective raised after Trainer._open_step had
+        begun it early): the device-side step counter goes back by one (the next begin() rewrites the same lr-history entry with the
+        same lr_t: global_step has not moved), the rows stamped for the abandoned step are un-stamped.  Rows that catch_up_early already
+        advanced THROUGH the abandoned step stay exact: the retried step has the same number and step size, and what they received is
+        the zero-gradient update the dense sweep gives them at that step."""
+        if not self._begun:
+            return
+        self.state.view(torch.int32)[3] -= 1
+        self._begun = False
+        if self.stamp is not None:
+            self.stamp.zero_()
+
     def step_in_flight(self) -> int:
         """Local number (index into the lr history) of the optimizer step between begin() and end()."""
         assert self._begun

@@ -381,6 +381,15 @@ class Trainer:
         ev.record(torch.cuda.current_stream(self.device))
         self._inflight = (ev, self.opt.step_in_flight())
 
+    def _abort_open_step(self):
+        """A step that raised after _open_step() had begun the optimizer step early: roll the optimizer back (TFAdam.abort_step), or
+        the next step would replay rows through a step that was never applied and then apply the same step number again."""
+        self._inflight = None
+        try:
+            self.opt.abort_step()
+        except Exception:          # (the device itself is gone: the original exception is the one to report)
+            pass
+
     def forward_backward(self, batch: DeviceBatch, join: bool = True, prefetch: DeviceBatch = None, defer_wgrads: bool = False,
                          open_step: bool = False):
         """join=False (one-GPU train_step with the sparse lane): backward only collects the long-row weight gradients and leaves the
@@ -433,6 +442,7 @@ class Trainer:
         except BaseException:
             ops.reset_deferred_wgrads()
             self.engine._pending_sparse = None
+            self._abort_open_step()
             raise
         finally:
             self.engine.defer_sparse = False
@@ -529,6 +539,7 @@ class Trainer:
             # (e.g. a collective error between backward and the optimizer: the collected weight gradients must not leak into the next step)
             ops.reset_deferred_wgrads()
             self.engine._pending_sparse = None
+            self._abort_open_step()
             raise
 
     def _train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):

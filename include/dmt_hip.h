@@ -38,6 +38,11 @@ extern "C" {
 #define DMT_MAX_SEQS 4
 #define DMT_MAX_TABLES 32
 
+/* ABI revision: bumped whenever an exported signature or a descriptor layout changes incompatibly (a binding compares it with the
+ * revision it was written against before its first call -- cikm2020_dmt_amd/_lib.py does).
+ *   1  rounds 1-2.   2  round 3: dmt_set/get_deterministic removed; dmt_colsum / dmt_colsum_drop (ordered), dmt_softmax_fwd / _bwd
+ *   (causal) gained an int before `stream`; dmt_wgrad_desc grew (det_ws).   3  round 4: dmt_mhsa2_* entry points, dmt_mhsa2_desc. */
+#define DMT_ABI_VERSION 3
 const char* dmt_last_error(void);
 int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */

@@ -7,6 +7,13 @@ of per-entry loops; the zero-pad table `[0;E]` (base.py:87-89) is realised as an
 
 Citations relative to /root/reference/DMT_code/.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module.
+
+`storage="bf16"` (forward / loss_and_grads): the SAME function with every tensor the HIP engine keeps in bf16 rounded to bf16 at
+the point where the engine stores it -- activations and their gradients (straight-through: the value is rounded on the way
+forward, its gradient on the way back), the bf16 weight copies the GEMMs read (values only: parameter gradients stay fp32 there
+and fp64 here) -- while every sum is still accumulated in float64.  What then remains between this oracle and the HIP path is
+the accumulation order and the fp32 accumulators, so the parity bound of the benchmarked bf16 mode can be ~10x tighter than
+against the unrounded function (tests/test_gpu_parity_bf16.py).  The unrounded mode stays the accuracy statement.
 """
 from __future__ import annotations
 
@@ -17,6 +24,69 @@ import numpy as np
 import torch
 
 PADDING_NUM = float(-2 ** 32 + 1)
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundFn(torch.autograd.Function):
+    """Storage rounding: value -> bf16 on the way forward (fwd), gradient -> bf16 on the way back (bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return _bf(x) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_bf(g) if ctx.bwd else g), None, None
+
+
+class Storage:
+    """Where the HIP engine rounds (cikm2020_dmt_amd, compute_dtype bf16).  R: a stored activation (and its stored gradient);
+    Rw: a bf16 weight copy (gradient untouched); Rf: value only (an MFMA operand packed from fp32 registers); Rg: gradient only."""
+
+    def __init__(self, mode=None):
+        if mode not in (None, "bf16"):
+            raise ValueError("storage must be None or 'bf16'")
+        self.on = mode == "bf16"
+
+    def R(self, x):
+        return _RoundFn.apply(x, True, True) if self.on else x
+
+    def Rw(self, x):
+        return _RoundFn.apply(x, True, False) if self.on else x
+
+    Rf = Rw
+
+    def Rg(self, x):
+        return _RoundFn.apply(x, False, True) if self.on else x
+
+
+EXACT = Storage(None)
+
+
+class _LNSavedRoundedFn(torch.autograd.Function):
+    """LayerNorm whose forward runs on the exact pre-norm sum (dmt_chain2 normalises its fp32 accumulators) while the backward reads
+    that sum back as the bf16 tensor the forward stored, with the forward's fp32 row statistics."""
+
+    @staticmethod
+    def forward(ctx, s, g, b, eps):
+        mu = s.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((s - mu).pow(2).mean(-1, keepdim=True) + eps)
+        ctx.save_for_backward(_bf(s), g, mu, rstd)
+        return g * ((s - mu) * rstd) + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        sr, g, mu, rstd = ctx.saved_tensors
+        xh = (sr - mu) * rstd
+        dg = (dy * xh).reshape(-1, xh.shape[-1]).sum(0)
+        db = dy.reshape(-1, xh.shape[-1]).sum(0)
+        dxh = dy * g
+        ds = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+        return ds, dg, db, None
 
 
 def _padded(sp, dtype=torch.long):
@@ -51,28 +121,54 @@ def _ln(x, g, b, eps=1e-8):
     return g * (x - mu) * torch.rsqrt(var + eps) + b          # TransformerModel_util.py:72-76
 
 
-def _mha(q_in, kv_in, q_len, k_len, H, P, s, rate=0.0, step_seed=None, stream=0):
+def _mha(q_in, kv_in, q_len, k_len, H, P, s, rate=0.0, step_seed=None, stream=0, st=EXACT):
     """TransformerModel_util.py:160-209 / :11-56.  [B,Tq,d],[B,Tk,d] -> [B,Tq,d]."""
     B, Tq, d = q_in.shape
     Tk = kv_in.shape[1]
     dh = d // H
-    Q = (q_in @ P[s + "dense/kernel"] + P[s + "dense/bias"]).view(B, Tq, H, dh).transpose(1, 2)
-    K = (kv_in @ P[s + "dense_1/kernel"] + P[s + "dense_1/bias"]).view(B, Tk, H, dh).transpose(1, 2)
-    V = (kv_in @ P[s + "dense_2/kernel"] + P[s + "dense_2/bias"]).view(B, Tk, H, dh).transpose(1, 2)
-    S = (Q @ K.transpose(-1, -2)) / (dh ** 0.5)                                   # [B,H,Tq,Tk]
+    Q = st.R(q_in @ st.Rw(P[s + "dense/kernel"]) + P[s + "dense/bias"]).view(B, Tq, H, dh).transpose(1, 2)
+    K = st.R(kv_in @ st.Rw(P[s + "dense_1/kernel"]) + P[s + "dense_1/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    V = st.R(kv_in @ st.Rw(P[s + "dense_2/kernel"]) + P[s + "dense_2/bias"]).view(B, Tk, H, dh).transpose(1, 2)
+    S = st.Rg((Q @ K.transpose(-1, -2)) / (dh ** 0.5))                            # [B,H,Tq,Tk]; dS is an MFMA operand (bf16)
     kmask = (torch.arange(Tk)[None, :] < k_len[:, None])[:, None, None, :]
     S = torch.where(kmask, S, torch.full_like(S, PADDING_NUM))
     A = torch.softmax(S, dim=-1)
     qmask = (torch.arange(Tq)[None, :] < q_len[:, None])[:, None, :, None]
     A = torch.where(qmask, A, torch.full_like(A, PADDING_NUM))                     # post-softmax query mask (F13)
-    A = _drop(A, rate, step_seed, stream)                                          # [B,H,Tq,Tk] order == kernel index order
+    A = st.Rf(_drop(A, rate, step_seed, stream))                                   # [B,H,Tq,Tk] order == kernel index order
     O = (A @ V).transpose(1, 2).reshape(B, Tq, d)
-    return _ln(O + q_in, P[s + "ln/gamma"], P[s + "ln/beta"])
+    return st.R(_ln(st.R(O + q_in), P[s + "ln/gamma"], P[s + "ln/beta"]))
 
 
-def _ff(x, P, s):
-    h = torch.relu(x @ P[s + "dense/kernel"] + P[s + "dense/bias"])
-    return _ln(h @ P[s + "dense_1/kernel"] + P[s + "dense_1/bias"] + x, P[s + "ln/gamma"], P[s + "ln/beta"])
+def _mha_q1mem(y, mem, k_len, H, P, s, rate=0.0, step_seed=None, stream=0, st=EXACT):
+    """The SAME function as _mha(y, mem, ones, k_len) for one query per example, in the association the HIP engine computes it in
+    (dmt_q1mem.hip: score_k = (Q_h Wk_h^T) . mem_k / sqrt(dh) -- the term Q_h . bk_h is constant over the keys and drops out of the
+    softmax --, out_h = (sum_k P_k mem_k) Wv_h + (sum_k P_k) bv_h), so that its bf16 storage points can be restated."""
+    B, _one, d = y.shape
+    T = mem.shape[1]
+    dh = d // H
+    Q = st.R(y[:, 0] @ st.Rw(P[s + "dense/kernel"]) + P[s + "dense/bias"]).view(B, H, dh)
+    Wk = st.Rw(P[s + "dense_1/kernel"]).view(d, H, dh)
+    Wv = st.Rw(P[s + "dense_2/kernel"]).view(d, H, dh)
+    bv = st.Rw(P[s + "dense_2/bias"]).view(H, dh)
+    qp = st.R(torch.einsum("bhe,dhe->bhd", Q, Wk))                                  # [B,H,d]
+    S = st.Rg(torch.einsum("bhd,btd->bht", qp, mem) / (dh ** 0.5))
+    kmask = (torch.arange(T)[None, :] < k_len[:, None])[:, None, :]
+    S = torch.where(kmask, S, torch.full_like(S, PADDING_NUM))
+    A = torch.softmax(S, dim=-1)
+    A = st.Rf(_drop(A.unsqueeze(2), rate, step_seed, stream).squeeze(2))            # index order [B,H,1,T] == [B,H,T]
+    ctx = st.R(torch.einsum("bht,btd->bhd", A, mem))
+    sp = st.R(A.sum(-1))
+    O = (torch.einsum("bhd,dhe->bhe", ctx, Wv) + sp[..., None] * bv[None]).reshape(B, 1, d)
+    return st.R(_ln(st.R(O + y), P[s + "ln/gamma"], P[s + "ln/beta"]))
+
+
+def _ff(x, P, s, st=EXACT):
+    h = st.R(torch.relu(x @ st.Rw(P[s + "dense/kernel"]) + P[s + "dense/bias"]))
+    pre = h @ st.Rw(P[s + "dense_1/kernel"]) + P[s + "dense_1/bias"] + x
+    if st.on:
+        return st.R(_LNSavedRoundedFn.apply(pre, P[s + "ln/gamma"], P[s + "ln/beta"], 1e-8))
+    return _ln(pre, P[s + "ln/gamma"], P[s + "ln/beta"])
 
 
 def _lookup_zero_pad(E, idx):
@@ -87,11 +183,12 @@ def _pool_mean(E, idx, valid, w):
     return rows.sum(1) / torch.where(ws == 0, torch.ones_like(ws), ws)
 
 
-def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_intermediates=False, step_seed=None):
-    """mmoe_transformer_unbias.py:293-316."""
+def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_intermediates=False, step_seed=None, storage=None):
+    """mmoe_transformer_unbias.py:293-316.  storage="bf16": see the module header."""
+    st = Storage(storage)
     any_p = next(iter(P.values()))
     dt = any_p.dtype
-    feats_dense = torch.as_tensor(np.asarray(inputs["features"])).to(dt)
+    feats_dense = st.R(torch.as_tensor(np.asarray(inputs["features"])).to(dt))
     B = feats_dense.shape[0]
     d, H = spec["d_model"], spec["num_heads"]
     table_of = {f: n for (n, _r, _d, f, _s) in spec["embedding_list"]}
@@ -114,14 +211,19 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         T = seq_emb.shape[1]
         rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
         x = seq_emb * (d ** 0.5) + P[pre + "positional_encoding_k_position_learn/embedding_position_learn"][:T][None]
-        x = _drop(x, rate, step_seed, 10 * i + 0)
+        x = st.R(_drop(x, rate, step_seed, 10 * i + 0))
         blk = pre + "num_blocks_0/"
-        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2)
-        mem = _ff(x, P, blk + "positionwise_feedforward/")
-        y = _drop((tar * (d ** 0.5))[:, None, :], rate, step_seed, 10 * i + 1)
-        y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
+        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)
+        mem = _ff(x, P, blk + "positionwise_feedforward/", st)
+        y = st.R(tar * (d ** 0.5))[:, None, :]
+        if rate and step_seed is not None:
+            y = st.R(_drop(y, rate, step_seed, 10 * i + 1))
+        if st.on:
+            y = _mha_q1mem(y, mem, lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3, st)
+        else:
+            y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
-        y = _ff(y, P, blk + ffs)
+        y = _ff(y, P, blk + ffs, st)
         states.append(y[:, 0, :])
         inter["seq_emb_%d" % i] = seq_emb
         inter["tar_emb"] = tar
@@ -134,7 +236,7 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         idx, valid = _padded(inputs[feat])
         wsp = inputs.get(feat + "Wts")
         w = _padded(wsp, dtype=dt)[0] if wsp is not None else torch.ones(idx.shape, dtype=dt)
-        parts.append(_pool_mean(P["embedding_trans/%s/embedding" % name], idx, valid, w))
+        parts.append(st.R(_pool_mean(P["embedding_trans/%s/embedding" % name], idx, valid, w)))
     z = torch.cat(parts + [interest], -1)
     inter["mmoe_input"] = z
 
@@ -144,21 +246,21 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         h = z
         for li in range(len(spec["hidden_units_bottom"])):
             s = "mmoe_layers/expert-%d/expert-layer-%d/" % (e, li)
-            h = torch.relu(h @ P[s + "weights"] + P[s + "biases"])
+            h = st.R(torch.relu(h @ st.Rw(P[s + "weights"]) + P[s + "biases"]))
         experts.append(h)
     ex = torch.stack(experts, -1)
     logits = []
     for t, nm in enumerate(("click", "order")[: spec["num_tasks"]]):
         s = "mmoe_layers/gates-%d/gates-layer-0/" % t
-        g = torch.softmax(z @ P[s + "weights"] + P[s + "biases"], -1)
+        g = torch.softmax(st.R(z @ st.Rw(P[s + "weights"]) + P[s + "biases"]), -1)
         inter["gate_%d" % t] = g
-        m = (ex * g[:, None, :]).sum(-1)
+        m = st.R((ex * g[:, None, :]).sum(-1))
         h = m
         for li in range(len(spec["hidden_units_task"])):
             s2 = "%s/%s-fc-%d/" % (nm, nm, li)
-            h = torch.relu(h @ P[s2 + "weights"] + P[s2 + "biases"])
+            h = st.R(torch.relu(h @ st.Rw(P[s2 + "weights"]) + P[s2 + "biases"]))
         s2 = "%s/%s-output/" % (nm, nm)
-        logits.append(h @ P[s2 + "weights"] + P[s2 + "biases"])
+        logits.append(st.Rg(h @ st.Rw(P[s2 + "weights"]) + P[s2 + "biases"]))     # fp32 logit; its gradient enters the layers as bf16
     logits = tuple(logits)
     if is_predict:
         return (logits, inter) if return_intermediates else logits
@@ -169,13 +271,15 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         idx, valid = _padded(inputs[feat])
         wsp = inputs.get(feat + "Wts")
         w = _padded(wsp, dtype=dt)[0] if wsp is not None else torch.ones(idx.shape, dtype=dt)
-        bparts.append(_pool_mean(P["%s/embedding" % name], idx, valid, w))
+        bparts.append(st.R(_pool_mean(P["%s/embedding" % name], idx, valid, w)))
     yb = torch.cat(bparts, -1)
     n = len(spec["hidden_units_bias"])
     for li in range(n):
-        yb = torch.relu(yb @ P["layer_bias%d/kernel" % li] + P["layer_bias%d/bias" % li])
-        yb = _drop(yb, spec.get("dropout_rate_bias", [0.0] * n)[li] if step_seed is not None else 0.0, step_seed, 100 + li)
-    yb = yb @ P["layer_bias%d/kernel" % n] + P["layer_bias%d/bias" % n]
+        yb = st.R(torch.relu(yb @ st.Rw(P["layer_bias%d/kernel" % li]) + P["layer_bias%d/bias" % li]))
+        rb = spec.get("dropout_rate_bias", [0.0] * n)[li] if step_seed is not None else 0.0
+        if rb:
+            yb = st.R(_drop(yb, rb, step_seed, 100 + li))
+    yb = st.Rg(yb @ st.Rw(P["layer_bias%d/kernel" % n]) + P["layer_bias%d/bias" % n])
     out = (logits, yb)
     return (out, inter) if return_intermediates else out
 
@@ -212,9 +316,9 @@ def to_torch(P_np: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=Tru
     return {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=requires_grad) for k, v in P_np.items()}
 
 
-def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64, step_seed=None):
+def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64, step_seed=None, storage=None):
     P = to_torch(P_np, dtype)
-    out = forward(P, inputs, spec, step_seed=step_seed)
+    out = forward(P, inputs, spec, step_seed=step_seed, storage=storage)
     loss = loss_unbias(out, mask, spec)
     loss.backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}

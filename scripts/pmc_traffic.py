@@ -17,16 +17,23 @@ FAMILIES = {
     "gather_fwd": ["gather_group_kernel"],
     "embgrad_reduce": ["embgrad_reduce_kernel"],
     "adam_sparse": ["adam_sparse_kernel"],
+    "mhsa": ["mhsa2_fwd_kernel", "mhsa2_bwd_kernel"],
+    "adam_catchup": ["adam_catchup_kernel"],
+    "ln": ["ln_fwd", "ln_bwd"],
 }
 
 
 def load(d, counter):
     f = glob.glob("%s/*/*counter_collection.csv" % d)[0]
     tot, n = {}, {}
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    # "__all__": every kernel from the first step's gather on (the set-up kernels of bench.py -- table init, ageing -- come before it)
+    first = min((int(r["Dispatch_Id"]) for r in rows if "gather_group_kernel" in r["Kernel_Name"]), default=0)
+    for r in rows:
         k = r["Kernel_Name"]
+        if int(r["Dispatch_Id"]) >= first:
+            tot["__all__"] = tot.get("__all__", 0.0) + float(r["Counter_Value"])
+            n["__all__"] = n.get("__all__", 0) + 1
         for fam, pats in FAMILIES.items():
             if any(p in k for p in pats):
                 tot[fam] = tot.get(fam, 0.0) + float(r["Counter_Value"])

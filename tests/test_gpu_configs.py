@@ -202,15 +202,24 @@ def test_auc_of_bf16_and_fp8_scores_against_fp32_on_a_large_evaluation_set(cuda,
         el, bl = _auc_pair(y, pl.astype(np.float32), cuda)
         out.append((name, e32, el, abs(el - e32), b32, bl, abs(bl - b32), float(np.abs(xl - x32).max() / sd)))
     print("AUC %s (n = %d): task, exact fp32, exact low, |d|, 200-bin fp32, 200-bin low, |d|, max |dlogit| / std:" % (cfg, nb * B), out)
-    # measured on MI355X (this test prints them): L = 50 bf16 (the benchmarked mode) 3e-5 / 2e-5 exact, 4e-5 / 2e-5 200-bin: inside the
-    # 1e-4 bar of north_star; L = 200 bf16 1e-5 / 1.0e-4; L = 200 with the fp8 attention forward 1.1e-4 / 1.8e-4 -- e4m3 attention
-    # does NOT meet 1e-4, stated bound 5e-4.  (The labels here follow the scores far more sharply -- AUC 0.92 -- than the reference's
-    # data does -- AUC 0.69 --, so a given score perturbation moves these AUCs more than it would there.)
-    tol = {"configs1_L50_bf16": 1e-4, "configs4_L200_bf16": 2e-4, "configs4_L200_fp8": 5e-4}[cfg]
+    # north_star's bar is |d AUC| <= 1e-4 per task, for EVERY configuration: no configuration gets a bar of its own.  Measured on
+    # MI355X (this test prints them): L = 50 bf16 (the benchmarked mode) 3e-5 / 2e-5 exact, 4e-5 / 2e-5 200-bin: inside; L = 200 bf16
+    # 1e-5 / 1.0e-4: AT the bar; L = 200 with the e4m3 attention forward 1.1e-4 / 1.8e-4: OUTSIDE -- configs[4]'s fp8 path does not
+    # meet north_star and this test reports it as an expected failure (XFAIL) instead of
+    # passing under a relaxed bound.  The `guard` numbers below are regression guards for the kernels (a broken kernel moves the AUC by
+    # 1e-2), not parity claims.  (The labels here follow the scores far more sharply -- AUC 0.92 -- than the reference's data does --
+    # AUC 0.69 --, so a given score perturbation moves these AUCs more than it would there.)
+    BAR = 1e-4
+    guard = {"configs1_L50_bf16": 1e-4, "configs4_L200_bf16": 3e-4, "configs4_L200_fp8": 6e-4}[cfg]
+    worst = 0.0
     for (name, e32, el, de, b32, bl, db, _ds) in out:
         assert e32 > 0.7
-        assert de < tol, (cfg, name, "exact AUC", de)
-        assert db < tol, (cfg, name, "200-bin AUC", db)
+        assert de < guard, (cfg, name, "exact AUC (regression guard)", de)
+        assert db < guard, (cfg, name, "200-bin AUC (regression guard)", db)
+        worst = max(worst, de, db)
+    if worst >= BAR:
+        assert cfg != "configs1_L50_bf16"          # the benchmarked configuration must meet the bar outright
+        pytest.xfail("%s: |d AUC| = %.2e does not meet north_star's 1e-4 bar" % (cfg, worst))
 
 
 # ---------------------------------------------------------------------------------------------------------------- configs[3]
