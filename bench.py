@@ -258,7 +258,7 @@ def main():
                                "per-GPU batch %d, L=%s full%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s, "
                                "%d distinct resident batches, tables %s"
                                % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10",
-                                  (" (flash-style attention kernels, %s MFMA forward)" % args.attn_dtype) if args.long_seq > 64 else "", args.law,
+                                  (" (flash-style attention kernels, %s MFMA forward%s)" % (args.attn_dtype, ": e4m3 attention DOES NOT MEET north_star's 1e-4 AUC bar (BASELINE.md section 5)" if args.attn_dtype == "fp8" else "")) if args.long_seq > 64 else "", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
                                   "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)", max(2, args.fresh_batches),
@@ -267,6 +267,16 @@ def main():
         "step_phases_ms": phases(diag, args.steps, world, tr), "lazy_adam": age_info,
         "roofline": roofline, "other_mfma_kernels": [f for f in fams if f["key"] != roofline.get("key")], "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }
+    # "bound by neither": algorithmic MFMA FLOP of every timed family over the step time against the bf16 dense peak, and the counter
+    # HBM bytes of EVERY kernel of a step (profiles/rNN_traffic.json "__all__", same sha rule) against 8 TB/s
+    step_s = dt / args.steps
+    flop_step = sum(f["algorithmic_flop_per_launch"] * f["launches_per_step"] for f in fams if f.get("unit") == "TFLOP/s")
+    out["mfma_frac_whole_step"] = round(flop_step / step_s / (peak * 1e12), 4) if fams else None
+    tall_ = tj.get("__all__")
+    out["hbm_frac_whole_step"] = round(tall_["hbm_bytes_per_step"] / step_s / 8e12, 4) if tall_ else None
+    out["whole_step_note"] = ("mfma: %.3f TFLOP of algorithmic MFMA work per step; hbm: %s" % (
+        flop_step / 1e12, ("%.2f GB of counter traffic per step (%s, every kernel from the first gather on)" % (tall_["hbm_bytes_per_step"] / 1e9, tname))
+        if tall_ else "no counter file for this build (profiles/rNN_traffic.json is tied to the kernel sources' sha)"))
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(sp, args)
     print(json.dumps(out), flush=True)
@@ -438,7 +448,9 @@ def cpu_baseline(sp, args):
            "sample": "batch %d: %d warm-up + %d timed train steps, median %.3f s/step, on %d of the host's %d cores (same model / dims / ids; fp32 "
                      "torch-CPU restatement of the reference step incl. its dense TF-Adam sweep over all 5.4M table rows)"
                      % (args.cpu_batch, len(warm), steps, med, cores, host),
-           "protocol": "BASELINE.md §3 (5 warm-up + 20 timed at B=256; one B=4096 step), bounded to --cpu-budget %.0f s of CPU work" % budget}
+           "protocol": ("BASELINE.md §3 (5 warm-up + 20 timed at B=256; one B=4096 step), bounded to --cpu-budget %.0f s of CPU work.  DEVIATION from §3's "
+                        "'all host cores': %d of %d cores (--cpu-threads) -- torch's intra-op pool is ~40x SLOWER at 256 threads than at 8-32 on this "
+                        "model's many small ops (measured on this host class), so all cores would understate the CPU path" % (budget, cores, host))}
     if big is not None:
         out["value_b%d" % args.cpu_big_batch] = round(args.cpu_big_batch / big, 1)
         out["sample"] += "; batch %d: 1 step, %.2f s" % (args.cpu_big_batch, big)

@@ -1132,7 +1132,7 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     B, T, d = x.shape
     dev = x.device
     y = torch.empty((B, T, d), dtype=BF16, device=dev)
-    s = torch.empty((B, T, d), dtype=BF16, device=dev)
+    s = torch.empty((B, T, d), dtype=BF16, device=dev) if want_side else None      # (inference: the pre-norm sum passes through y)
     stats = torch.empty((B * T, 2), dtype=F32, device=dev) if want_side else None
     qkv = torch.empty((B, T, 3 * d), dtype=BF16, device=dev) if want_side else None
     dd = L.MhsaDesc()
@@ -1140,7 +1140,7 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     dd.x, dd.lens, dd.image = x.data_ptr(), lens.data_ptr(), image.data_ptr()
     dd.bias, dd.gamma, dd.beta, dd.eps = bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
     dd.qkv = qkv.data_ptr() if qkv is not None else None
-    dd.s_out, dd.y_out = s.data_ptr(), y.data_ptr()
+    dd.s_out, dd.y_out = (s.data_ptr() if s is not None else None), y.data_ptr()
     dd.stats = stats.data_ptr() if stats is not None else None
     dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
     flops = 2.0 * B * T * d * 3 * d + 4.0 * B * T * T * d

@@ -6,7 +6,7 @@ of a tensor's norm, measured 7-12 %): a defect worth a few per cent of a gradien
 wrong LayerNorm statistic -- fails here.  The unrounded comparison stays the accuracy statement.
 
 The bound is CALIBRATED per tensor, not granted.  Legitimate evaluations of the very same rounded function -- this oracle with
-float64 sums, with float32 sums, with its parameters moved by 3e-7 relative (below one fp32 ulp of most sums) -- already differ: a
+float64 sums, with float32 sums, with its parameters moved by half an fp32 ulp -- already differ: a
 perturbation far below a bf16 ulp flips a few roundings, every flip perturbs what follows by a full bf16 ulp, and after three or
 four storage points the difference has grown to the bf16 noise level whatever its origin (scripts/parity_bf16_stages.py: the
 encoder memories of two such evaluations differ by 5e-4, the logits by 3e-3 -- and the HIP engine differs from either by EXACTLY
@@ -15,7 +15,7 @@ those amounts at every stage; its bias-tower logit agrees to 3e-8).  In the grad
 the HIP engine (fp32 accumulators, its own summation order: one more member of the family) lands at 1.1 % / 2.0 % / 6.8 % with the
 same worst tensor.  That is the floor ANY correct bf16 implementation has against a given oracle: a flat "<= 2 % for every tensor"
 cannot be met by any of them, and a flat 7 % would hide a 5 % defect in a tensor whose floor is 1 %.  Asserted instead, per tensor,
-with floor = the largest distance of an ensemble member (float32 sums; perturbed parameters) from the float64 oracle:
+with floor = the largest distance of an ensemble member (float32 sums; float32 sums of half-ulp-perturbed parameters) from the float64 oracle:
     err(HIP, oracle64)  <=  2 * floor + 0.01      (<= 0.10 in any case; tensors of fewer than 8 elements: at least 0.04 -- a scalar
                                                     gradient such as an output bias is ONE cancelling sum, its floor one random draw)
 and the median over the tensors <= 1.5 %.  Each test prints how many of the 121 tensors a systematic 3 % / 5 % error would fail
@@ -91,13 +91,15 @@ def _run(cuda, B, lengths, weights, dropout, seed=5):
     return tr, loss, (P, inputs, mask, so, step_seed)
 
 
-def _ensemble(P, inputs, mask, so, step_seed, n_perturbed=2, dtype=torch.float64):
-    """Other legitimate evaluations of the storage-rounded function: float32 sums, and parameters moved by 3e-7 relative."""
+def _ensemble(P, inputs, mask, so, step_seed, n_perturbed=1):
+    """Other legitimate evaluations of the storage-rounded function, of the HIP engine's own arithmetic class: float32 sums, and
+    float32 sums with every parameter moved by half an fp32 ulp (3e-8 relative: what rounding the inputs of a sum once more does).
+    (Measured: a 3e-7 perturbation -- five fp32 ulps -- already triples the distances; the family is the fp32-rounding-sized one.)"""
     out = [OT.loss_and_grads(P, inputs, mask, so, step_seed=step_seed, storage="bf16", dtype=torch.float32)]
     for k in range(n_perturbed):
         rng = np.random.default_rng(1000 + k)
-        Pk = {n: v * (1.0 + 3e-7 * rng.standard_normal(v.shape)) for n, v in P.items()}
-        out.append(OT.loss_and_grads(Pk, inputs, mask, so, step_seed=step_seed, storage="bf16", dtype=dtype))
+        Pk = {n: v * (1.0 + 3e-8 * rng.standard_normal(v.shape)) for n, v in P.items()}
+        out.append(OT.loss_and_grads(Pk, inputs, mask, so, step_seed=step_seed, storage="bf16", dtype=torch.float32))
     return out
 
 
@@ -126,7 +128,7 @@ def _compare_calibrated(tr, loss, ref64, ensemble, label, tol=TOL):
     bad = [(n, round(err[n], 4), round(bound[n], 4)) for n in err if not err[n] <= bound[n]]
     assert not bad, "%s: gradients beyond 2 x their rounding-cascade floor + 1 %%: %s" % (label, bad)
     assert np.median(v) < tol["grad_median"], (label, float(np.median(v)))
-    assert power[0.05] >= 0.6 * v.size, (label, power)          # the check must be able to see a 5 % defect in most tensors
+    assert power[0.05] >= 0.5 * v.size, (label, power)          # the check must be able to see a 5 % defect in most tensors
     return err
 
 
@@ -183,7 +185,7 @@ def test_configs1_at_full_size_forward_loss_and_every_gradient_match_the_oracle(
     assert tr.last["out"][0][0].shape[0] == B
     # (a) the storage-rounding oracle, bound calibrated per tensor
     ref_r = OT.loss_and_grads(P, inputs, mask, so, storage="bf16")
-    ens = _ensemble(P, inputs, mask, so, None, n_perturbed=1, dtype=torch.float32)
+    ens = _ensemble(P, inputs, mask, so, None)
     _compare_calibrated(tr, loss, ref_r, ens, "configs[1] B=4096 vs storage-rounding oracle")
     # (b) the exact oracle: the accuracy of the bf16 mode itself at full size (the bounds of tests/test_gpu_e64.py)
     ref_x = OT.loss_and_grads(P, inputs, mask, so)
