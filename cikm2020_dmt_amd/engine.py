@@ -331,10 +331,11 @@ class DMTEngine:
         self.w_ecvr = torch.tensor(spec["weight_ecvr"], dtype=F32, device=dev)
         self.intermediates = {}
         self.dropout_step_seed = None    # int: dropout active with this per-step seed (is_train); None: off
-        # fused self-attention block (dmt_mhsa_block_fwd: one launch).  Off by default: measured slower than the three-launch path in
-        # training; DMT_FUSED_MHSA=1 or Trainer(..., fused_mhsa=True) selects it
+        # fused self-attention block (dmt_mhsa_block_fwd: QKV projection + masked softmax attention + residual + LayerNorm in one
+        # launch, T <= 64).  On by default since round 4; DMT_FUSED_MHSA=0 or Trainer(..., fused_mhsa=False) selects the
+        # three-launch path (dmt_proj, dmt_attn_fwd, dmt_ln_fwd)
         self._use_mhsa = False
-        self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "0") == "1"
+        self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "1") == "1"
         self.defer_sparse, self._pending_sparse = False, None     # GatherFn.backward leaves its work to finish_sparse_backward()
         self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") != "0"        # side streams for the behaviour sequences
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)

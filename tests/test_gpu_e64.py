@@ -1,6 +1,7 @@
 """The BENCHMARKED configuration (BASELINE.json configs[1]: E64 = every id field 64 wide, d_model 320, d_ff 1280, 4 heads of 80, bf16)
 against the CPU oracle END TO END, with every default switch on -- so the kernels that are only dispatched at these dims run inside a
-model-level oracle comparison: dmt_proj (320 -> 960 streamed-weight QKV projection), attn_fwd/bwd_co_kernel<80>, chain2<320,1280,320>,
+model-level oracle comparison: dmt_mhsa_block_fwd (the fused self-attention block; with it off: dmt_proj, the 320 -> 960 streamed-weight
+QKV projection, and attn_fwd_co_kernel<80>), attn_bwd_co_kernel<80>, chain2<320,1280,320>,
 dmt_wgrad320, dmt_q1mem_fwd/bwd, the fused MMoE expert kernels and the fused heads.  Each test records the launch routes the library
 took (dmt_route_trace) and asserts them: a silent fall back to the generic kernels would fail the test, not pass it.
 
@@ -29,9 +30,11 @@ pytestmark = pytest.mark.gpu
 
 E64_ROWS = {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120, "Cid2": 50}
 # routes the E64 bf16 step must take (labels of DMT_CHECK_LAUNCH in csrc/)
-E64_ROUTES = ("dmt_gather_fwd", "dmt_proj", "dmt_attn_fwd(mfma, coalesced)", "dmt_attn_bwd(mfma, coalesced)", "dmt_chain2", "dmt_wgrad320",
+# (fused self-attention block on, the default; E64_ROUTES_UNFUSED: Trainer(fused_mhsa=False), the three-launch self-attention forward)
+E64_ROUTES = ("dmt_gather_fwd", "dmt_mhsa_block_fwd", "dmt_attn_bwd(mfma, coalesced)", "dmt_chain2", "dmt_wgrad320",
               "dmt_q1mem_fwd", "dmt_q1mem_bwd", "dmt_mmoe_experts_fwd", "dmt_mmoe_experts_bwd", "dmt_heads_fwd", "dmt_heads_bwd",
               "dmt_embgrad_reduce")
+E64_ROUTES_UNFUSED = tuple(r for r in E64_ROUTES if r != "dmt_mhsa_block_fwd") + ("dmt_proj", "dmt_attn_fwd(mfma, coalesced)")
 BF16_MAX_ULPS, BF16_TAIL_ULPS, BF16_TAIL_FRAC = 256.0, 16.0, 0.12
 BF16_FAR_ULPS, BF16_FAR_FRAC = 64.0, 0.003
 TOL = {torch.float32: dict(logit=3e-4, loss=1e-5, grad=3e-3, floor=1e-6), torch.bfloat16: dict(logit=6e-2, loss=3e-2, grad=0.2, floor=3e-3)}
@@ -54,11 +57,11 @@ def _params(so, seed=11):
     return P
 
 
-def _setup(cuda, dtype, B, seed=5, lengths="ragged", weights="random", dropout=False, dropout_seed=1):
+def _setup(cuda, dtype, B, seed=5, lengths="ragged", weights="random", dropout=False, dropout_seed=1, fused_mhsa=None):
     so, sp = e64_specs()
     P = _params(so)
     inputs, mask, label = make_batch(sp, B, seed=seed, lengths=lengths, weights=weights)
-    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=dropout, dropout_seed=dropout_seed)
+    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=dropout, dropout_seed=dropout_seed, fused_mhsa=fused_mhsa)
     tr.store.load_state(P)
     return so, sp, P, inputs, mask, tr, tr.make_batch(inputs, mask, label)
 
@@ -100,14 +103,15 @@ def _assert_routes(counts, wanted=E64_ROUTES):
     assert not missing, "kernels this test claims to cover were not dispatched: %s (took: %s)" % (missing, sorted(counts))
 
 
-@pytest.mark.parametrize("B,lengths,weights", [(24, "ragged", "random"), (24, "full", "ones"), (352, "ragged", "random")])
-def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch, B, lengths, weights):
+@pytest.mark.parametrize("B,lengths,weights,fused", [(24, "ragged", "random", True), (24, "full", "ones", True), (352, "ragged", "random", True),
+                                                     (24, "ragged", "random", False), (352, "ragged", "random", False)])
+def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch, B, lengths, weights, fused):
     """B = 352: the L = 50 sequences have M = 17600 >= WGRAD320_MIN_ROWS rows, so every dispatch rule is the benchmark's own;
     B = 24: the row threshold of the wide-block weight-gradient kernel is lowered so it still runs."""
     if B * 50 < ops.WGRAD320_MIN_ROWS:
         monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 1024)
     dtype = torch.bfloat16
-    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype, B, lengths=lengths, weights=weights)
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype, B, lengths=lengths, weights=weights, fused_mhsa=fused)
     loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
     if B <= 24:        # the literal numpy restatement agrees with the torch one (the two oracles, at these dims)
         (c2, o2), yb2 = O.inference(inputs, P, so)
@@ -115,7 +119,7 @@ def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch
     with L.route_trace() as rt:
         loss = tr.forward_backward(batch)
         torch.cuda.synchronize()
-    _assert_routes(rt.counts)
+    _assert_routes(rt.counts, E64_ROUTES if fused else E64_ROUTES_UNFUSED)
     (c, o), yb = tr.last["out"]
     t = TOL[dtype]
     errs = [np.abs(x.detach().float().cpu().numpy() - r).max() for x, r in ((c, c_ref), (o, o_ref), (yb, yb_ref))]
