@@ -101,3 +101,30 @@ def slice_batch(spec: dict, inputs: dict, mask: np.ndarray, a: int, b: int):
         else:
             out[k] = np.asarray(v)[a:b]
     return out, mask[a:b]
+
+
+def write_records_file(job):
+    """(dims, sku_rows, batch, seed, law, path) -> number of bytes written.  One file of `batch` synthetic tf.Example records of the
+    model's TFRecord schema (data_feed/tfrecord_mask.py:23-84: every id feature a bytes list + its ...Wts float list, `features`,
+    `mask`, `label`), the same id law as make_batch.  A top-level function: bench.py runs it in spawned worker processes (the Python
+    protobuf encoder does ~1 ms per 10 KB record)."""
+    import os
+    from .. import spec as S
+    from . import tfrecord
+    dims, sku_rows, batch, seed, law, path = job
+    sp = S.e64_spec() if dims == "e64" else S.default_spec()
+    if sku_rows:
+        sp = S.scaled_spec(sp, {"Sku": sku_rows})
+    emb = list(sp["embedding_list"]) + list(sp["embedding_list_bias"])
+    feats = list(dict.fromkeys(e[3] for e in emb))
+    inputs, mask, label = make_batch(sp, batch, seed=seed, lengths="full", law=law)
+    rows = {f: inputs[f].rows() for f in feats}
+    recs = []
+    for b in range(batch):
+        ex = {"features": inputs["features"][b].astype(np.float32), "mask": mask[b].astype(np.float32), "label": np.array([label[b]], np.float32)}
+        for f in feats:
+            ex[f] = [("%d" % int(i)).encode() for i in rows[f][b]]
+            ex[f + "Wts"] = np.ones(len(rows[f][b]), np.float32)
+        recs.append(tfrecord.encode_example(ex))
+    tfrecord.write_records(path, recs)
+    return os.path.getsize(path)

@@ -342,6 +342,7 @@ class DMTEngine:
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
+        self.step_state = ops.StepState()  # collected weight gradients / fork lane / long-row threshold of the step in flight (ops.StepState)
         self.kopts = ops.KernelOptions()  # attention / projection kernel choices of THIS engine (fp8 MFMA forward, long fused form, dmt_proj)
 
     @property

@@ -195,16 +195,46 @@ def _grad_view(leaf):
     return g
 
 
-WGRAD320_MIN_ROWS = 16384
+WGRAD320_MIN_ROWS = 16384      # default row threshold of the "long-row" weight gradients (a StepState may carry its own)
+
+
+class StepState:
+    """What ONE training step in flight keeps between its forward / backward and the point where the Trainer collects it: the long-row
+    weight gradients backward only collected (deferred), the lane the MMoE / tower weight gradients fork to, the row threshold.  Every
+    engine owns one (DMTEngine.step_state); Trainer.forward_backward activates its engine's for the duration of the step, so two
+    Trainers with different deferral needs in one process do not see each other's (round-3 review: these were module globals).  The
+    autograd engine runs backward on its own thread: the active state is a module-level pointer, not a thread-local -- steps of
+    different Trainers may alternate in one process, they may not run concurrently."""
+    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows")
+
+    def __init__(self, wgrad320_min_rows=None):
+        self.deferred = None          # list of closures while the step collects its long-row weight gradients
+        self.deferred_limit = None    # only gradients that end before this element offset of the gradient arena may be collected
+        self.fork = None              # dict(stream, off, n): B-row weight gradients at / behind `off` run on an idle lane
+        self.wgrad320_min_rows = wgrad320_min_rows      # None: the module default above (tests lower it)
+
+    def min_rows(self):
+        return WGRAD320_MIN_ROWS if self.wgrad320_min_rows is None else self.wgrad320_min_rows
+
+
+_state = StepState()        # the active one (a direct caller of the Functions, outside any Trainer, gets this default)
+
+
+def activate(state):
+    """Make `state` the active StepState; -> the one it replaces (hand it back to activate() when the step is over)."""
+    global _state
+    prev, _state = _state, (state if state is not None else StepState())
+    return prev
+
+
+def wgrad320_min_rows():
+    return _state.min_rows()
+
 
 # Weight gradients of the long (B x T)-row GEMMs can leave the backward critical path: nothing in backward reads them (only the
 # optimizer does).  begin_deferred_wgrads() makes backward COLLECT them; the Trainer launches them where they hide something -- beside
 # the gradient-row exchange of a data-parallel step (train_step), or beside the id-bound tail of a one-GPU step (DMT_SPARSE_LANE).
 # (Tried and dropped: side streams per compute stream for them -- 1 %, and their queues collide with the lanes, streams.py.)
-_deferred = [None]      # list of closures while a Trainer step collects its long-row weight gradients (begin_deferred_wgrads)
-_deferred_limit = [None]  # only gradients that end before this element offset of the gradient arena may be collected
-
-
 def begin_deferred_wgrads(limit=None):
     """From now on the long-row weight gradients of backward are COLLECTED instead of launched: nothing in backward reads them, so
     the dX chain -- the critical path to the embedding gradients -- runs through first; run_deferred_wgrads() launches them afterwards
@@ -212,20 +242,20 @@ def begin_deferred_wgrads(limit=None):
     limit: element offset into the flat gradient arena.  In a data-parallel step the arena's tail [limit:] (MMoE, towers, bias tower)
     is all-reduced from a hook DURING backward (Trainer.forward_backward): a gradient of that region must be complete when the hook
     fires, so only gradients that lie entirely before `limit` (the Transformers') are collected; the others run in place."""
-    _deferred[0] = []
-    _deferred_limit[0] = None if limit is None else int(limit)
+    _state.deferred = []
+    _state.deferred_limit = None if limit is None else int(limit)
 
 
 def reset_deferred_wgrads():
     """Drop whatever a step that did not finish left collected (an exception between backward and run_deferred_wgrads)."""
-    _deferred[0] = None
-    _deferred_limit[0] = None
+    _state.deferred = None
+    _state.deferred_limit = None
 
 
 def _may_defer(M, *grad_views):
-    if _deferred[0] is None or M < WGRAD320_MIN_ROWS:
+    if _state.deferred is None or M < _state.min_rows():
         return False
-    lim = _deferred_limit[0]
+    lim = _state.deferred_limit
     if lim is None:
         return True
     for g in grad_views:
@@ -240,43 +270,40 @@ def _may_defer(M, *grad_views):
 def run_deferred_wgrads(upto=None):
     """Launch what begin_deferred_wgrads() collected, on the current stream, in backward order; -> how many.  upto: only the first
     `upto` of them now (the rest stays collected for the next call)."""
-    todo = _deferred[0]
+    todo = _state.deferred
     if todo is None:
         return 0
     if upto is not None and upto < len(todo):
-        now, _deferred[0] = todo[:upto], todo[upto:]
+        now, _state.deferred = todo[:upto], todo[upto:]
     else:
-        now, _deferred[0] = todo, None
-        _deferred_limit[0] = None
+        now, _state.deferred = todo, None
+        _state.deferred_limit = None
     for fn in now:
         fn()
     return len(now)
 
 
 def deferred_wgrads_pending():
-    return len(_deferred[0]) if _deferred[0] is not None else 0
+    return len(_state.deferred) if _state.deferred is not None else 0
 
 
 # One-GPU backward: the B-row weight gradients of the MMoE / tower region (gradient arena at or behind `from_offset`) leave the compute
 # stream as they are met and run on an idle sequence lane.  That stretch of backward is ONE dependent chain of small kernels (layer-0
 # input gradient <- expert kernels <- heads <- loss) with the chip mostly idle; nothing on the chain reads a weight gradient, so the
 # seven GEMMs (one of them 51 GFLOP) only lengthened it.  The lanes' own work starts when dL/dz exists, i.e. after that chain.
-_fork = [None]
-
-
 def begin_fork_wgrads(stream, from_offset):
-    _fork[0] = dict(stream=stream, off=int(from_offset), n=0)
+    _state.fork = dict(stream=stream, off=int(from_offset), n=0)
 
 
 def end_fork_wgrads():
     """-> the state of begin_fork_wgrads() (n = how many launches went to the lane; the caller waits for the lane) or None."""
-    st, _fork[0] = _fork[0], None
+    st, _state.fork = _state.fork, None
     return st
 
 
 def _fork_stream(M, *grad_views):
-    f = _fork[0]
-    if f is None or M >= WGRAD320_MIN_ROWS:
+    f = _state.fork
+    if f is None or M >= _state.min_rows():
         return None
     for g in grad_views:
         if g is not None and g.storage_offset() < f["off"]:
@@ -335,12 +362,12 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     rows = K + 1 if want_bias else K
     tiles = ((rows + 127) // 128) * ((N + 127) // 128)
     split = _pick_split(tiles, M)
-    if (gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= WGRAD320_MIN_ROWS
+    if (gw is not None and (gb is not None or not want_bias) and x.dtype == BF16 and dz.dtype == BF16 and M >= _state.min_rows()
             and (K == 320 or N == 320) and K % 8 == 0 and N % 8 == 0 and _wgrad320_operand_ok(x) and _wgrad320_operand_ok(dz)
             and gw.dim() == 2 and (gw.shape[1] == 1 or gw.stride(1) == 1)):
         # the wide-block reduction kernel: the 320-wide operand is the stationary side of the [320 x 256] block
         if _may_defer(M, gw, gb if want_bias else None):
-            _deferred[0].append(lambda: _deferred_wgrad320(x, dz, gw, gb if want_bias else None, K == 320))
+            _state.deferred.append(lambda: _deferred_wgrad320(x, dz, gw, gb if want_bias else None, K == 320))
             return None, None
         if K == 320:
             wgrad320(x, dz, gw, False, gb if want_bias else None, 1)
@@ -355,7 +382,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
                 dz.record_stream(cur)
                 gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
                      split_k=split, accumulate=True)
-            _deferred[0].append(_later)
+            _state.deferred.append(_later)
             return None, None
         side = _fork_stream(M, gw, gb)
         if side is not None:
@@ -365,7 +392,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
                 dz.record_stream(side)
                 gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
                      split_k=split, accumulate=True)
-            _fork[0]["n"] += 1
+            _state.fork["n"] += 1
             return None, None
         gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
              split_k=split, accumulate=True)

@@ -41,12 +41,14 @@ def index_group():
     from different host points, so the device-side order can differ between ranks; both kinds of kernels are small (a few workgroups) and
     co-reside on a 256-CU device, which is what makes this work -- it has not been soak-tested on 8 GPUs.  DMT_INDEX_GROUP=0 puts
     everything on the default communicator (one stream, one order: the id exchange then queues behind the gradient collectives)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or os.environ.get("DMT_INDEX_GROUP", "1") != "1":
+    mode = os.environ.get("DMT_INDEX_GROUP", "1")
+    if not (dist.is_available() and dist.is_initialized()) or mode not in ("1", "force") or (dist.get_backend() != "nccl" and mode != "force"):
         return None          # (DMT_INDEX_GROUP=0: everything on the default communicator -- the id exchange then queues behind gradient collectives)
+    # ("force": a second group on ANY backend -- the soak test of tests/test_gpu_dp.py runs the two-communicator schedule over gloo)
     world_pg = dist.distributed_c10d._get_default_group()
     if _index_group["world"] is not world_pg:          # (a new default group after destroy_process_group + init_process_group)
         _index_group["world"] = world_pg
-        _index_group["group"] = dist.new_group(backend="nccl")
+        _index_group["group"] = dist.new_group(backend=dist.get_backend())
     return _index_group["group"]
 
 

@@ -37,7 +37,8 @@ def _record_stream(obj, stream):
 class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
-                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None):
+                 dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None,
+                 wgrad320_min_rows=None):
         """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
         same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
         back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
@@ -51,6 +52,8 @@ class Trainer:
         shard = parallel.world() if table_layout == "sharded" else None
         self.store = VariableStore(spec, self.device, compute_dtype, seed=seed, init=init, table_shard=shard)
         self.engine = DMTEngine(spec, self.store)
+        # what a step in flight keeps (collected weight gradients, their lane, the long-row threshold) belongs to THIS trainer's engine
+        self.engine.step_state = ops.StepState(wgrad320_min_rows)
         # BASELINE configs[4]: the long-sequence (64 < T <= 256) attention forward of THIS trainer multiplies in OCP e4m3
         self.engine.kopts = ops.KernelOptions(attn_mma_fp8=(attn_dtype == "fp8"))
         self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
@@ -394,6 +397,7 @@ class Trainer:
                          open_step: bool = False):
         """join=False (one-GPU train_step with the sparse lane): backward only collects the long-row weight gradients and leaves the
         embedding-gradient tail to the caller.  prefetch: the NEXT batch -- its index plane is issued once this step's forward is queued."""
+        ops.activate(self.engine.step_state)
         ops.reset_deferred_wgrads()       # (closures a step that raised half-way left behind reference that step's tensors)
         self.engine._pending_sparse = None
         self.sync_rows(batch)
@@ -533,6 +537,7 @@ class Trainer:
         return (uniq2, n_uniq2, out_rows, capm)
 
     def train_step(self, batch: DeviceBatch, prefetch: DeviceBatch = None):
+        ops.activate(self.engine.step_state)       # (stays the active one until another Trainer steps)
         try:
             return self._train_step(batch, prefetch)
         except BaseException:

@@ -1,6 +1,7 @@
 #!/bin/bash
 # 1 / 2 / 4 / 8-GPU weak-scaling sweep of bench.py on ONE node (the driver's own launch line), with the per-phase spans of every N:
-#   scripts/scale_sweep.sh [steps] [warmup] [extra bench.py flags...]      -> gpurun_out/scale/bench_n<N>.json + a summary table
+#   scripts/scale_sweep.sh [steps] [warmup] [extra bench.py flags...]      -> gpurun_out/scale/bench_n<N>.json, gpurun_out/scale/sweep.jsonl
+#   (one JSON line per N: ms/step, samples/s, speed-up, step_phases_ms) + a summary table
 # Needs as many visible GPUs as the largest N (the round's GPU boxes have one: the driver runs the real sweep at round end).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 steps=${1:-50}; warm=${2:-10}; shift 2 2>/dev/null
@@ -9,7 +10,7 @@ ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
 for N in 1 2 4 8; do
   [ "$N" -gt "$ngpu" ] && { echo "skip N=$N: $ngpu GPU(s) visible"; continue; }
   if [ "$N" = 1 ]; then
-    python $R/bench.py --gpus 1 --steps $steps --warmup $warm --no-cpu-baseline "$@" 2>$O/bench_n$N.err | grep '^{' > $O/bench_n$N.json
+    python $R/bench.py --gpus 1 --steps $steps --warmup $warm --no-cpu-baseline --record-files 0 "$@" 2>$O/bench_n$N.err | grep '^{' > $O/bench_n$N.json
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + N)) \
       $R/bench.py --gpus $N --steps $steps --warmup $warm --no-cpu-baseline "$@" 2>$O/bench_n$N.err | grep '^{' > $O/bench_n$N.json
@@ -27,4 +28,8 @@ for N in (1, 2, 4, 8):
     ph = {k: v for k, v in d.get("step_phases_ms", {}).items() if k.endswith("_ms")}
     print("N=%d  %.3f ms/step  %.0f samples/s  x%.2f of N=1  world=%s  phases(ms): %s"
           % (N, d["ms_per_step"], d["value"], d["value"] / base, d.get("step_phases_ms", {}).get("world_size_seen_by_torch_distributed"), ph))
+    # one JSON line per N (the whole sweep as ONE artefact: gpurun_out/scale/sweep.jsonl)
+    line = {"n_gpus": N, "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "speedup_vs_n1": round(d["value"] / base, 3),
+            "step_phases_ms": d.get("step_phases_ms", {}), "config": d.get("config", {})}
+    open("$O/sweep.jsonl", "a" if N > 1 else "w").write(json.dumps(line) + "\n")
 PY

@@ -209,6 +209,43 @@ def test_two_trainers_with_different_kernel_options_in_one_process(cuda):
     assert abs(outs["fp8"][0] - outs["bf16"][0]) < 5e-2 * abs(outs["bf16"][0])
 
 
+def test_two_trainers_deferring_differently_in_one_process(cuda):
+    """The state of a step in flight (collected long-row weight gradients, their lane, the long-row threshold) belongs to the engine
+    (ops.StepState), not to the module: trainer A counts every weight gradient of >= 64 rows as long-row (dmt_wgrad320 runs), trainer B
+    keeps the default threshold (no dmt_wgrad320 at this batch); used alternately in one process each takes its own route, and each
+    ends where it ends when it runs alone."""
+    from cikm2020_dmt_amd import _lib as L
+    from cikm2020_dmt_amd import ops
+    from cikm2020_dmt_amd import spec as S
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120})
+    batches = [make_batch(sp, 8, seed=40 + i, lengths="ragged") for i in range(3)]
+    ops.set_deterministic(False)
+
+    def fresh(min_rows):
+        return Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=7, dropout=False, wgrad320_min_rows=min_rows)
+
+    def run_alone(min_rows):
+        tr = fresh(min_rows)
+        return [float(tr.train_step(tr.make_batch(i, m))) for (i, m, _l) in batches]
+
+    alone_a, alone_b = run_alone(64), run_alone(None)
+    ta, tb = fresh(64), fresh(None)
+    assert ta.engine.step_state is not tb.engine.step_state
+    got_a, got_b = [], []
+    for (i, m, _l) in batches:
+        with L.route_trace() as rt:
+            got_a.append(float(ta.train_step(ta.make_batch(i, m))))
+            torch.cuda.synchronize()
+        assert rt.counts.get("dmt_wgrad320", 0) > 0, sorted(rt.counts)
+        with L.route_trace() as rt:
+            got_b.append(float(tb.train_step(tb.make_batch(i, m))))
+            torch.cuda.synchronize()
+        assert rt.counts.get("dmt_wgrad320", 0) == 0, sorted(rt.counts)
+        assert ops.deferred_wgrads_pending() == 0
+    # (fp32 atomics: the same run twice agrees to rounding, not bitwise)
+    assert np.allclose(got_a, alone_a, rtol=2e-3) and np.allclose(got_b, alone_b, rtol=2e-3), (got_a, alone_a, got_b, alone_b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_early_catch_up_of_the_next_batch_changes_nothing(cuda, monkeypatch, dtype):
     """train_step(batch, prefetch=next): the pending zero-gradient Adam updates of the next batch's rows are replayed on the index lane

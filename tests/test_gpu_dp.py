@@ -397,3 +397,62 @@ def test_bench_two_ranks_torchrun_on_one_device(cuda):
     assert out2.returncode == 0, out2.stderr[-3000:]
     j2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
     assert "row-sharded" in j2["config"]["parallelism"] and np.isfinite(j2["final_loss"])
+
+
+def _soak_worker(rank, world, port, q, steps):
+    import torch.distributed as dist
+    from cikm2020_dmt_amd import parallel
+    from cikm2020_dmt_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["DMT_INDEX_GROUP"] = "force"            # the index plane of batch i + 1 on its own communicator, inside step i
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    so, sp = small_specs()
+    P = O.init_params(so, seed=5)
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16, init=False, dropout=True, dropout_seed=3)
+    tr.store.load_state(P)
+    assert parallel.index_group() is not None          # (a second communicator really is in use)
+    rng = np.random.default_rng(100 + rank)
+    batches = []
+    for s in range(8):                                  # ragged sizes differ per rank and step: the exchanged counts never repeat in lock step
+        inputs, mask, _ = make_batch(sp, int(rng.integers(3, 9)), seed=900 + 10 * s + rank, lengths="ragged", weights="random")
+        batches.append(tr.make_batch(inputs, mask))
+    losses = []
+    for s in range(steps):
+        cur, nxt = batches[s % 8], batches[(s + 1) % 8]
+        nxt._prep = None                                # a fresh index plane every step, prefetched while step s runs
+        losses.append(float(tr.train_step(cur, prefetch=nxt)))
+    tr.opt.flush_tables()
+    torch.cuda.synchronize()
+    sd = tr.store.state_dict()
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    q.put((rank, losses[-5:], h.hexdigest(), bool(np.all(np.isfinite(losses)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_soak_three_ranks_two_communicators_200_steps(cuda):
+    """DESIGN.md section 6 risk: the id exchange of batch i + 1 runs on a SECOND communicator while step i's gradient collectives are in
+    flight on the first.  200 prefetching steps on three ranks (gloo over the one GPU; ragged per-rank batch sizes so the two planes'
+    message sizes drift against each other): no hang or reordering (the test has a hard timeout), every loss finite, and the three
+    replicas bit-identical at the end -- a collective matched against the wrong partner would break exactly that."""
+    world, steps = 3, 200
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_soak_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p_ in procs:
+            p_.join(60)
+            if p_.is_alive():
+                p_.kill()
+    assert all(p_.exitcode == 0 for p_ in procs)
+    assert all(r[3] for r in res)
+    assert res[0][2] == res[1][2] == res[2][2], "replicas diverged"

@@ -146,17 +146,24 @@ def test_deferred_weight_gradient_queue_semantics():
     """ops.begin_deferred_wgrads / run_deferred_wgrads: closures run once, in collection order, in one or several batches (the
     data-parallel step launches half of them beside the all_to_all and the rest beside the all-gather)."""
     from cikm2020_dmt_amd import ops
+    st, other = ops.StepState(), ops.StepState()
+    ops.activate(st)
     assert ops.run_deferred_wgrads() == 0 and ops.deferred_wgrads_pending() == 0
     seen = []
     ops.begin_deferred_wgrads()
     for i in range(5):
-        ops._deferred[0].append(lambda i=i: seen.append(i))
+        st.deferred.append(lambda i=i: seen.append(i))
+    ops.activate(other)                         # another engine's state: sees nothing of the first one's collection
+    assert ops.deferred_wgrads_pending() == 0 and ops.run_deferred_wgrads() == 0 and seen == []
+    ops.activate(st)
     assert ops.deferred_wgrads_pending() == 5
     assert ops.run_deferred_wgrads(upto=3) == 3 and seen == [0, 1, 2] and ops.deferred_wgrads_pending() == 2
     assert ops.run_deferred_wgrads() == 2 and seen == [0, 1, 2, 3, 4]
-    assert ops._deferred[0] is None and ops.run_deferred_wgrads() == 0      # collection is off again: backward launches at once
+    assert st.deferred is None and ops.run_deferred_wgrads() == 0      # collection is off again: backward launches at once
     ops.begin_deferred_wgrads()
-    assert ops.run_deferred_wgrads(upto=4) == 0 and ops._deferred[0] is None
+    assert ops.run_deferred_wgrads(upto=4) == 0 and st.deferred is None
+    assert ops.StepState(64).min_rows() == 64 and ops.StepState().min_rows() == ops.WGRAD320_MIN_ROWS
+    ops.activate(None)
 
 
 def test_index_group_is_the_default_group_without_rccl():
