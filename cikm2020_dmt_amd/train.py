@@ -400,6 +400,12 @@ class Trainer:
         ops.activate(self.engine.step_state)
         ops.reset_deferred_wgrads()       # (closures a step that raised half-way left behind reference that step's tensors)
         self.engine._pending_sparse = None
+        if batch.ready is not None and self.device.type == "cuda":
+            # a batch uploaded on another stream (an input thread's): the compute stream waits for the copy, and the allocator learns
+            # that this stream reads the buffer (a no-op for a batch made on this stream)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(batch.ready)
+            batch.dense.record_stream(cur)
         self.sync_rows(batch)
         if open_step:
             self._open_step(batch)

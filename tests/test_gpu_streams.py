@@ -53,7 +53,7 @@ def test_sparse_lane_with_deferred_weight_gradients_default_mode(cuda):
         for s in range(3):
             inputs, mask, _ = make_batch(sp, 2048, seed=80 + s, lengths="full")     # 2048 x 50 rows: the wgrad320 path, deferred
             tr.train_step(tr.make_batch(inputs, mask))
-        assert ops._deferred[0] is None and tr.engine._pending_sparse is None
+        assert tr.engine.step_state.deferred is None and tr.engine._pending_sparse is None
         tr.opt.flush_tables()
         torch.cuda.synchronize()
         states.append(tr.store.state_dict())
