@@ -224,24 +224,39 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   const float scale = 0.11180339887498948f;          // 1 / sqrt(80)
   int gs = 0;                                        // stages consumed so far by this workgroup
 
+  // row info of a lane -- local row -> (example, position), validity, global row -- is RECOMPUTED where it is used (a handful of VALU
+  // operations) instead of living in registers across the tile: with the 80 registers of input fragments resident, every value kept
+  // is a value spilled, and a reload from scratch waits (vmcnt is in order) behind every side-output store issued before it.
+  // Global rows are 32-bit: every address is (uniform base) + (32-bit offset).
+  struct RowInfo { int t_pos, ex; bool rvalid; unsigned grow, growc, row640; };
+  auto rowinfo_t = [&](int tl) -> RowInfo {
+    const int r_loc = 32 * rb + (mh_here(lane) & 31);
+    RowInfo r;
+    r.t_pos = r_loc & (Tp - 1);
+    r.ex = tl * epw + (r_loc >> lg);
+    r.rvalid = (r.ex < g.B) && (r.t_pos < T);
+    r.grow = (unsigned)r.ex * (unsigned)T + (unsigned)r.t_pos;
+    r.growc = r.rvalid ? r.grow : 0u;
+    r.row640 = r.rvalid ? r.grow * (unsigned)(MH_D * 2) : OOB;      // byte offset of the row in x / s / y, or out of range
+    return r;
+  };
+  // the raw input rows of a tile: requested one tile ahead (before the LayerNorm pass of the tile in flight, whose latency they share)
+  // (ONE set of 80 registers: the raw rows land in the fragment registers and are swapped into fragment order in place)
+  bf16x8_t X[MH_KC];
+  auto request_x = [&](int tl) {
+    const RowInfo ri = rowinfo_t(tl);
+    const unsigned xo = ri.row640 + 16u * (unsigned)hi_;
+#pragma unroll
+    for (int c = 0; c < MH_KC; ++c) X[c] = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+    if (!(dbg & 128)) {
+#pragma unroll
+      for (int c = 0; c < MH_KC; ++c) X[c] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rx, xo + 32u * c, 0, 0));
+    }
+  };
+  request_x((int)blockIdx.x);
+
   for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
-    // ---- this lane's row: local row r -> (example, position)
-    // row info of a lane -- local row -> (example, position), validity, global row -- is RECOMPUTED where it is used (a handful of VALU
-    // operations) instead of living in registers across the tile: with the 80 registers of input fragments resident, every value kept
-    // is a value spilled, and a reload from scratch waits (vmcnt is in order) behind every side-output store issued before it.
-    // Global rows are 32-bit: every address is (uniform base) + (32-bit element offset), the scalar-base addressing form.
-    struct RowInfo { int t_pos, ex; bool rvalid; unsigned grow, growc, row640; };
-    auto rowinfo = [&]() -> RowInfo {
-      const int r_loc = 32 * rb + (mh_here(lane) & 31);
-      RowInfo r;
-      r.t_pos = r_loc & (Tp - 1);
-      r.ex = tile * epw + (r_loc >> lg);
-      r.rvalid = (r.ex < g.B) && (r.t_pos < T);
-      r.grow = (unsigned)r.ex * (unsigned)T + (unsigned)r.t_pos;
-      r.growc = r.rvalid ? r.grow : 0u;
-      r.row640 = r.rvalid ? r.grow * (unsigned)(MH_D * 2) : OOB;      // byte offset of the row in x / s / y, or out of range
-      return r;
-    };
+    auto rowinfo = [&]() -> RowInfo { return rowinfo_t(tile); };
     int len;
     { const RowInfo ri = rowinfo(); len = (ri.ex < g.B) ? g.lens[ri.ex] : 0; }
     float rsum = 0.f, rsq = 0.f;                               // row statistics of s
@@ -250,25 +265,13 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
     //      loaded ONCE per row tile and kept for the four heads' projections and their residual adds.  (A lane reads its own row in
     //      16-byte pieces -- 32 rows x 32 bytes per instruction --: reloading them per head to free their 80 registers during the
     //      attention cost 150 of 450 us.)
-    bf16x8_t X[MH_KC];
-    {
-      // (loaded and swapped IN PLACE: a second 80-register copy would spill; rows past the end read row 0 and are zeroed by the mask)
-      const RowInfo ri = rowinfo();
-      const unsigned xo = ri.row640 + 16u * (unsigned)hi_;
-      u32x4_t raw[MH_KC];
 #pragma unroll
-      for (int c = 0; c < MH_KC; ++c) raw[c] = u32x4_t{0u, 0u, 0u, 0u};
-      if (!(dbg & 128)) {
-#pragma unroll
-        for (int c = 0; c < MH_KC; ++c) raw[c] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + 32u * c, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < MH_KC; ++c) {
-        unsigned a0 = raw[c][0], a1 = raw[c][1], a2 = raw[c][2], a3 = raw[c][3];
-        mh_swap(a0, a2);
-        mh_swap(a1, a3);
-        X[c] = __builtin_bit_cast(bf16x8_t, u32x4_t{a0, a1, a2, a3});
-      }
+    for (int c = 0; c < MH_KC; ++c) {     // (swapped in place: rows past the end were out-of-range loads, i.e. zeros)
+      const u32x4_t rw = __builtin_bit_cast(u32x4_t, X[c]);
+      unsigned a0 = rw[0], a1 = rw[1], a2 = rw[2], a3 = rw[3];
+      mh_swap(a0, a2);
+      mh_swap(a1, a3);
+      X[c] = __builtin_bit_cast(bf16x8_t, u32x4_t{a0, a1, a2, a3});
     }
 
 #pragma unroll 1
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
       // (no barrier here: the next head's first stage barrier comes before any wavefront overwrites K / V^T)
     }
 
+    if (tile + G_ < g.tiles) request_x(tile + G_);      // (the fragments' registers are free from here on)
     // ================= LayerNorm over the row: re-read this lane's own pieces of s =================
     {
       rsum += __shfl_xor(rsum, 32, 64);

@@ -469,7 +469,7 @@ class DMTEngine:
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "self-attention/"
         img = self.store.mhsa.get(a) if x.dtype == torch.bfloat16 else None
-        if img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1]):
+        if img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1], x.shape[0]):
             seed, keep = self._attn_drop(stream)
             return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
                                          self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8)

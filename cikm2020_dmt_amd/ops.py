@@ -1140,8 +1140,9 @@ class SelfAttnBlockFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ fused self-attention block
-def mhsa_supported(d_model, num_heads, T):
-    return d_model == 320 and num_heads == 4 and 1 <= T <= 64
+def mhsa_supported(d_model, num_heads, T, B=1):
+    """The one-launch block is built for the E64 geometry, T <= 64, and 32-bit byte offsets into the [B * T, 960] side output."""
+    return d_model == 320 and num_heads == 4 and 1 <= T <= 64 and B * T * 1920 < 0x7FFF0000
 
 
 def mhsa_image_bytes():

@@ -5,7 +5,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp
 for law in zipf uniform; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${law}_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --law $law > $R/gpurun_out/${tag}_${law}_$c.log 2>&1 || echo "pass $law $c failed"
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${tag}_${law}_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --record-files 0 --law $law > $R/gpurun_out/${tag}_${law}_$c.log 2>&1 || echo "pass $law $c failed"
   done
 done
 cd $R
