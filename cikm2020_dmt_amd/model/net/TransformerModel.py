@@ -6,7 +6,7 @@ import torch
 
 from ... import ops
 from .. import runtime as R
-from .TransformerModel_util import ff, multihead_attention, _leaf, _seq_index
+from .TransformerModel_util import ff, multihead_attention, positional_encoding, _leaf, _seq_index
 
 
 class TransformerModel():
@@ -28,8 +28,16 @@ class TransformerModel():
 
     def position_encode(self, seq_k, seq_k_ts, seq_max_len, scale):
         method = self._get("position_encoding_method", "position_learn")
+        if method == "position_sin_cos":
+            # TransformerModel.py:61-64: seq_k += positional_encoding(seq_k, maxlen) -- the sinusoid table is a constant, no variable
+            pe = positional_encoding(seq_k, seq_max_len, masking=False, scope="positional_encoding_k_position_sin_cos")
+            return ops.ScaleAddPosFn.apply(seq_k, None, scale) + pe.to(seq_k.dtype)
+        if method in ("time_add", "time_concat"):
+            # (:70-78: a dense layer over the time-stamp embedding, `dense_trans_seq_time_*`: variables the DMT inventory -- SURVEY.md
+            #  Appendix B, dmt.conf -- does not hold)
+            raise NotImplementedError("position_encoding_method=%s needs the dense_trans_seq_%s variables, which dmt.conf's model does not create" % (method, method))
         if method != "position_learn":
-            raise NotImplementedError("position_encoding_method=%s (dmt.conf uses position_learn)" % method)
+            return ops.ScaleAddPosFn.apply(seq_k, None, scale)       # (:59-82: no branch matches, the scaled embedding passes through)
         with R.variable_scope("positional_encoding_k_position_learn"):
             pos, _ = _leaf("embedding_position_learn")
         return ops.ScaleAddPosFn.apply(seq_k, pos, scale)
@@ -50,13 +58,13 @@ class TransformerModel():
         return enc, seqlens
 
     def decode(self, ys, name="decoder", training=True):
-        if self._get("is_decoder_add_pos_emb", False):
-            raise NotImplementedError("is_decoder_add_pos_emb=true")
         with R.variable_scope(name):
             query_emb, query_length, key_emb, key_length = ys
             rate = float(self._get("dropout_rate", 0.0) or 0.0) if training else 0.0
             eng = R.get_default().engine
             dec = ops.ScaleAddPosFn.apply(query_emb, None, float(self._d_model()) ** 0.5)
+            if self._get("is_decoder_add_pos_emb", False):       # TransformerModel.py:148-150: sinusoid positions of the query
+                dec = dec + positional_encoding(dec, self._get("maxlen_q", dec.shape[1]), masking=False, scope="positional_encoding").to(dec.dtype)
             dec = ops.dropout(dec, rate, eng.dropout_step_seed if rate else None, 10 * _seq_index() + 1)     # TransformerModel.py:151
             for i in range(self._get("num_blocks_decode", 1)):
                 with R.variable_scope("num_blocks_{}".format(i)):

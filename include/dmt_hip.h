@@ -41,7 +41,8 @@ extern "C" {
 /* ABI revision: bumped whenever an exported signature or a descriptor layout changes incompatibly (a binding compares it with the
  * revision it was written against before its first call -- cikm2020_dmt_amd/_lib.py does).
  *   1  rounds 1-2.   2  round 3: dmt_set/get_deterministic removed; dmt_colsum / dmt_colsum_drop (ordered), dmt_softmax_fwd / _bwd
- *   (causal) gained an int before `stream`; dmt_wgrad_desc grew (det_ws).   3  round 4: dmt_mhsa2_* entry points, dmt_mhsa2_desc. */
+ *   (causal) gained an int before `stream`; dmt_wgrad_desc grew (det_ws).   3  round 4: dmt_mhsa_block_fwd re-implemented (a new weight-image layout: images of revision 2 are not
+ *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31). */
 #define DMT_ABI_VERSION 3
 const char* dmt_last_error(void);
 int dmt_version(void);
@@ -522,8 +523,11 @@ uint64_t dmt_wgrad320_det_ws_bytes(int64_t M, int32_t N);
  * intermediate travelling back from memory.
  * Replaces: multihead_attention(queries, keys, values, ...) with queries == keys == values (the encoder's self-attention,
  *           model/net/TransformerModel.py:103-115 -> TransformerModel_util.py:160-209, 11-56, 80-108, 58-78).
- * image: dmt_mhsa_image_build(Wqkv fp32 [320, 960] packed dense | dense_1 | dense_2 kernels).
- * Side outputs for the backward pass: qkv [B*T, 960] (or NULL: inference), s_out = pre-LN sum, stats [B*T, 2] = (mean, rstd).
+ * image: dmt_mhsa_image_build(Wqkv fp32 [320, 960] packed dense | dense_1 | dense_2 kernels); dmt_mhsa_image_bytes() bytes; rebuilt after
+ *        every optimizer step (the layout is private to the library: 64 stages of 32 head-major columns x 160 k).
+ * Side outputs for the backward pass: qkv [B*T, 960] (or NULL: inference), s_out = pre-LN sum (or NULL: inference; the sum then passes
+ * through y_out), stats [B*T, 2] = (mean, rstd) (or NULL).  Limits: B * T * 1920 < 2^31 (32-bit byte offsets).
+ * One workgroup of 8 wavefronts per CU, persistent over tiles of 256 rows.
  * drop_keep in (0, 1): attention-weight dropout with the library's counter mask, element index ((b*H + h)*T + q)*T + k.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -537,7 +541,7 @@ typedef struct {
   const float* beta;
   float eps;
   void* qkv;              /* bf16 [B*T, 3 * d_model] or NULL             */
-  void* s_out;            /* bf16 [B*T, d_model]                         */
+  void* s_out;            /* bf16 [B*T, d_model] or NULL                 */
   void* y_out;            /* bf16 [B*T, d_model]                         */
   float* stats;           /* fp32 [B*T, 2] or NULL                       */
   uint32_t drop_seed;

@@ -323,7 +323,7 @@ def loss_and_grads(P_np, inputs, mask, spec, dtype=torch.float64, step_seed=None
     loss.backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in P.items()}
     (c, o), yb = out
-    return float(loss), (c.detach().numpy(), o.detach().numpy(), yb.detach().numpy()), grads
+    return float(loss.detach()), (c.detach().numpy(), o.detach().numpy(), yb.detach().numpy()), grads
 
 
 class TorchTrainer:

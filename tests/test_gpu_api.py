@@ -205,3 +205,32 @@ def test_sinusoidal_positions_and_masking_flags(cuda):
     assert np.abs(pl[z]).max() == 0.0 and np.abs(pl[~z] - wantl[~z]).max() < 1e-6
     with pytest.raises(ValueError):
         TU.positional_encoding(x, 3)
+
+
+def test_transformer_model_position_options(cuda):
+    """TransformerModel.position_encode (TransformerModel.py:59-82) with position_sin_cos and the decoder's is_decoder_add_pos_emb
+    (:148-150): the block input is sqrt(d) * x + PE[0:T]; the time_* methods need variables dmt.conf's model does not create."""
+    from cikm2020_dmt_amd.model.net.TransformerModel import TransformerModel
+    so, sp, P, inf, inputs, mask = _make(cuda)
+    E = sp["d_model"]
+    B, T = 3, 9
+    x = torch.randn((B, T, E), device=cuda)
+    enc = np.array([[pos / np.power(10000, (i - i % 2) / E) for i in range(E)] for pos in range(50)])
+    enc[:, 0::2] = np.sin(enc[:, 0::2]); enc[:, 1::2] = np.cos(enc[:, 1::2])
+    tm = TransformerModel(dict(sp, position_encoding_method="position_sin_cos"))
+    got = _np(tm.position_encode(x, None, 50, float(E) ** 0.5))
+    assert np.abs(got - (_np(x) * np.sqrt(E) + enc[None, :T])).max() < 1e-5
+    tm2 = TransformerModel(dict(sp, position_encoding_method="none_of_them"))
+    assert np.abs(_np(tm2.position_encode(x, None, 50, float(E) ** 0.5)) - _np(x) * np.sqrt(E)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        TransformerModel(dict(sp, position_encoding_method="time_add")).position_encode(x, None, 50, 1.0)
+    # decoder with sinusoid positions on the single query: differs from the default decoder by exactly PE[0] on its input
+    lens = torch.tensor([9, 1, 4], dtype=torch.int32, device=cuda)
+    q = torch.randn((B, 1, E), device=cuda)
+    mem = torch.randn((B, T, E), device=cuda)
+    with R.variable_scope("/".join(S.trans_prefix(0).rstrip("/").split("/")[:-1])):      # (decode opens the innermost scope itself)
+        base_out = _np(TransformerModel(dict(sp)).decode((q, None, mem, lens), "encode_decode_sequence_0", training=False))
+        shifted = q + torch.tensor(enc[None, :1].astype(np.float32), device=cuda) / float(E) ** 0.5
+        want = _np(TransformerModel(dict(sp)).decode((shifted, None, mem, lens), "encode_decode_sequence_0", training=False))
+        got = _np(TransformerModel(dict(sp, is_decoder_add_pos_emb=True, maxlen_q=1)).decode((q, None, mem, lens), "encode_decode_sequence_0", training=False))
+    assert np.abs(got - want).max() < 1e-4 and np.abs(got - base_out).max() > 1e-3

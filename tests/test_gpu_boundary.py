@@ -282,3 +282,42 @@ def test_early_catch_up_of_the_next_batch_changes_nothing(cuda, monkeypatch, dty
     assert torch.equal(a[5], b[5])
     # the early pass leaves rows of the prefetched batch at a LATER last-touch step than the lazy form (they are already up to date)
     assert bool((a[4] >= b[4]).all()) and bool((a[4] > b[4]).any())
+
+
+def test_a_step_that_raises_after_its_early_begin_is_rolled_back(cuda):
+    """Round-3 advice: with the early catch-up on, train_step begins the optimizer step (device step counter, lr history, row stamps)
+    BEFORE forward / backward.  A step that then raises must leave the optimizer as if it had never begun (TFAdam.abort_step): the
+    retried step and everything after it end bit-identical to a run in which nothing failed."""
+    from cikm2020_dmt_amd import ops
+    so, sp = small_specs()
+    P = O.init_params(so, seed=3)
+    batches = [make_batch(sp, 9, seed=60 + (i % 4), lengths="ragged", weights="random") for i in range(6)]
+    res = []
+    ops.set_deterministic(True)
+    try:
+        for fail in (True, False):
+            tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False, dropout=True, dropout_seed=5)
+            tr.early_catchup = True
+            tr.store.load_state(P)
+            bs = [tr.make_batch(i, m) for (i, m, _l) in batches]
+            for s in range(5):
+                if fail and s == 2:
+                    real = tr.engine.loss_unbias
+
+                    def boom(*a, **k):
+                        raise RuntimeError("injected")
+                    tr.engine.loss_unbias = boom
+                    with pytest.raises(RuntimeError, match="injected"):
+                        tr.train_step(bs[s], prefetch=bs[s + 1])
+                    tr.engine.loss_unbias = real
+                    assert not tr.opt._begun and tr.opt.global_step == 2
+                tr.train_step(bs[s], prefetch=bs[s + 1])
+            tr.opt.flush_tables()
+            torch.cuda.synchronize()
+            res.append((tr.store.tab_p.clone(), tr.store.tab_m.clone(), tr.store.tab_v.clone(), tr.store.params.clone(), tr.opt.global_step))
+    finally:
+        ops.set_deterministic(False)
+    a, b = res
+    assert a[4] == b[4] == 5
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
