@@ -60,6 +60,13 @@ def main():
     ap.add_argument("--record-steps", type=int, default=30)
     ap.add_argument("--parser-threads", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--inline-events", default="chain2",
+                    help="kernel families timed with HIP events INSIDE the timed region: a comma list of ops._Timed keys, 'all' or 'none'.  Every "
+                         "pair of events costs the launch stream ~3 us (all families: ~90 pairs, +0.3 ms per step, measured); the default times the "
+                         "dominant kernel there and every family in the serialised steps right after the region")
+    ap.add_argument("--inline-every", type=int, default=10,
+                    help="the in-region events are recorded on every n-th timed step (an event between two long kernels drains the stream: ~8 us "
+                         "each around chain2, 0.2 ms per step if every step is timed)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,15 +136,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    ops.PROFILE = {}
-    tr.diag = {}
+    inline = "all" if not tr.engine.seq_streams else args.inline_events        # (no serialised leg without sequence lanes: time everything here)
+    ops.PROFILE = None if inline == "none" else {}
+    keys_on = None if inline in ("all", "none") else set(inline.split(",")) | {"gather_fwd"}
+    every = max(1, args.inline_every) if tr.engine.seq_streams else 1
+    steps_k = len(range(0, args.steps, every))          # timed steps that carry events
+    diag = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ops.PROFILE_KEYS = keys_on if i % every == 0 else set()
+        tr.diag = diag if i % every == 0 else None            # (the phase spans of step_phases_ms: the same sampled steps)
         loss = step(args.warmup + i)
+    host_dt = time.perf_counter() - t0          # the host has ENQUEUED the timed steps (it runs ahead of the GPU when the step is GPU-bound)
     barrier()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    diag, tr.diag = tr.diag, None
+    prof, ops.PROFILE = (ops.PROFILE or {}), None
+    ops.PROFILE_KEYS = None
+    tr.diag = None
     # the same kernels with the chip to themselves: a few extra steps (outside the timed region) with the sequences' streams serialised
     prof_x, steps_x = None, 4
     if tr.engine.seq_streams:
@@ -189,13 +204,18 @@ def main():
 
     for key, desc_ in fam_desc.items():
         n_k, t_k, fl_k = agg(key)
-        if n_k == 0 or t_k <= 0:
-            continue
-        byts = prof.get(key + "_bytes", prof.get("gemm_bytes", []) if key.startswith("gemm") else [])
-        in_step = {"avg_launch_us": round(t_k / n_k * 1e6, 2), "achieved": round(fl_k / t_k / 1e12, 2), "frac": round(fl_k / t_k / 1e12 / peak, 4),
-                   "note": "HIP events around the launch INSIDE the timed region: with three sequence lanes in flight this includes the time the "
-                           "launch queues behind, and shares the chip with, kernels of the other lanes"}
         n_x, t_x, fl_x = agg_x(key)
+        if (n_k == 0 or t_k <= 0) and (n_x == 0 or t_x <= 0):
+            continue
+        src = prof if n_k > 0 else prof_x
+        byts = src.get(key + "_bytes", src.get("gemm_bytes", []) if key.startswith("gemm") else [])
+        if n_k > 0:
+            in_step = {"avg_launch_us": round(t_k / n_k * 1e6, 2), "achieved": round(fl_k / t_k / 1e12, 2), "frac": round(fl_k / t_k / 1e12 / peak, 4),
+                       "note": "HIP events around the launch INSIDE the timed region (every %s timed step): with three sequence lanes in flight this includes "
+                               "the time the launch queues behind, and shares the chip with, kernels of the other lanes" % ("%d-th" % every if every > 1 else "single")}
+        else:
+            in_step = None          # (--inline-events: this family is timed in the serialised steps only)
+            n_k, fl_k = n_x * steps_k / steps_x, fl_x * steps_k / steps_x       # launches / work of the event-carrying steps, from the same step
         if n_x > 0 and t_x > 0:
             # the kernel's own duration: the same launches, same process, lanes serialised (steps_x extra steps right after the timed region)
             n_m, t_m, fl_m, how = n_x, t_x, fl_x, ("HIP events on the launch stream, %d steps of the same workload run right after the timed region with "
@@ -203,11 +223,11 @@ def main():
         else:
             n_m, t_m, fl_m, how = n_k, t_k, fl_k, "HIP events on the launch stream over the timed region"
         fams.append({"key": key, "kernel": desc_, "bound": "mfma", "achieved": round(fl_m / t_m / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(fl_m / t_m / 1e12 / peak, 4), "traffic": None, "launches_per_step": round(n_k / max(args.steps, 1), 1),
+                     "frac": round(fl_m / t_m / 1e12 / peak, 4), "traffic": None, "launches_per_step": round(n_k / max(steps_k, 1), 1),
                      "avg_launch_us": round(t_m / n_m * 1e6, 2), "measured": how,
-                     "time_share": round((t_m / n_m) * (n_k / max(args.steps, 1)) / (dt / args.steps), 3),
+                     "time_share": round((t_m / n_m) * (n_k / max(steps_k, 1)) / (dt / args.steps), 3),
                      "algorithmic_flop_per_launch": int(fl_k / n_k),
-                     "algorithmic_bytes_per_launch": int(sum(byts) / n_k) if byts else None,
+                     "algorithmic_bytes_per_launch": int(sum(byts) / len(byts)) if byts else None,
                      "in_step": in_step})
     fams.sort(key=lambda f: -f["time_share"])
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process (rocprofv3 wraps it); the committed
@@ -245,7 +265,7 @@ def main():
     roofline = dict(single[0]) if fams else {"kernel": None, "bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
     ga_x = bool((prof_x or {}).get("gather_fwd"))
     n_ga, t_ga, by_ga = agg_x("gather_fwd") if ga_x else agg("gather_fwd")
-    ga_per_step = n_ga / max(steps_x if ga_x else args.steps, 1)
+    ga_per_step = n_ga / max(steps_x if ga_x else steps_k, 1)
     gather = {"kernel": "gather_group_kernel (embedding gather+concat+pool fwd)", "bound": "hbm",
               "achieved": round(by_ga / t_ga / 1e9, 1) if t_ga > 0 else None, "peak": 8000.0, "unit": "GB/s",
               "frac": round(by_ga / t_ga / 8e12, 4) if t_ga > 0 else None, "avg_launch_us": round(t_ga / max(n_ga, 1) * 1e6, 2),
@@ -269,11 +289,12 @@ def main():
                                   "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)", max(2, args.fresh_batches),
                                   ("pre-aged to step %d (per-row last-touch gaps from the id law: the lazy Adam replays them)" % args.age_tables) if args.age_tables > 0 else "fresh (nothing for the lazy Adam to replay)"),
                    "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" + row-sharded tables" if args.shard_tables else "") + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
-        "step_phases_ms": phases(diag, args.steps, world, tr), "lazy_adam": age_info,
+        "step_phases_ms": phases(diag, steps_k, world, tr), "lazy_adam": age_info,
         "roofline": roofline, "other_mfma_kernels": [f for f in fams if f["key"] != roofline.get("key")], "gather_roofline": gather, "final_loss": round(float(loss), 5),
     }
     # "bound by neither": algorithmic MFMA FLOP of every timed family over the step time against the bf16 dense peak, and the counter
     # HBM bytes of EVERY kernel of a step (profiles/rNN_traffic.json "__all__", same sha rule) against 8 TB/s
+    out["host_enqueue_ms_per_step"] = round(host_dt / args.steps * 1e3, 3)   # < ms_per_step: the host runs ahead, the step is GPU-bound
     step_s = dt / args.steps
     flop_step = sum(f["algorithmic_flop_per_launch"] * f["launches_per_step"] for f in fams if f.get("unit") == "TFLOP/s")
     out["mfma_frac_whole_step"] = round(flop_step / step_s / (peak * 1e12), 4) if fams else None
@@ -314,7 +335,7 @@ def phases(diag, steps, world, tr):
     import torch.distributed as dist
     out = {"world_size_seen_by_torch_distributed": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
            "data_parallel_path": bool(tr._dp_active()), "table_layout": tr.table_layout,
-           "note": "HIP-event spans on the stream that issues / waits for the phase, mean over the timed steps; phases overlap each other and the step's compute"}
+           "note": "HIP-event spans on the stream that issues / waits for the phase, mean over the event-carrying timed steps (--inline-every); phases overlap each other and the step's compute"}
     for key, ent in sorted((diag or {}).items()):
         ms = [e0.elapsed_time(e1) for (e0, e1) in ent]
         if ms:

@@ -570,8 +570,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 }
 
 // =====================================================================================================================
-// Direct-to-LDS variant for the forward / input-gradient GEMMs: bf16, BOTH operands k-contiguous, K % 64 == 0, bf16 C,
-// no split-K.  ds_write_b128 moves only ~79 B/clk/CU, so staging a 32 KB k-step through VGPRs costs more LDS time than
+// Direct-to-LDS variant for the forward / input-gradient GEMMs: bf16, BOTH operands k-contiguous, K % 8 == 0, bf16 C,
+// no split-K (a last k-step shorter than 64: the 16-byte chunks at k >= K are requested out of the descriptor's range and arrive as zeros).  ds_write_b128 moves only ~79 B/clk/CU, so staging a 32 KB k-step through VGPRs costs more LDS time than
 // its 16 MFMAs per wave take; here `buffer_load_dwordx4 ... lds` writes the operand tiles into LDS without a VGPR pass.
 //   * LDS image per operand: [128 rows][64 k] bf16, 128-byte rows, NO padding (the DMA destination is wave-uniform base
 //     + lane * 16); the 16-byte slot s of row r holds logical k chunk s ^ ((r >> 1) & 7).  The swizzle is applied on the
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 //   * MFMA operands are swapped (D^T = B A^T), so a lane ends up with 4 CONSECUTIVE columns of one row per register
 //     quad: the epilogue adds bias / relu in registers and stages packed bf16 (ds_write_b64) -- or fp32 quads when a
 //     residual must be added before the single rounding -- then finishes rows with 16-byte gate loads and stores.
-//   * the whole bias vector (N <= 2048) is put in LDS once per (persistent) workgroup.
+//   * the whole bias vector (N <= 2304; wider outputs only without a bias) is put in LDS once per (persistent) workgroup.
 // Tried and rejected (measured on the 204800-row shapes): a 256 x 128 tile with 8 waves and THREE DMA stages (two k-steps in
 // flight, 25 % less operand traffic per FLOP) is 5-20 % slower -- the k-step is not DMA-latency bound; hand-ordered fragment
 // double buffering in compute() is re-scheduled by hipcc and changes nothing; 8 waves per 128 x 128 tile (32 x 64 per wave, 4 waves
@@ -591,9 +591,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 // latency hiding.  Counters for this kernel (profiles/r01d_*): MFMA busy 31 %, LDS active 28 %, waves 40 % in waitcnt/barrier and
 // 32 % in issue stalls.
 constexpr int GL_STAGE_BYTES = 34816;   // A tile 16 KB | B tile 16 KB | 2 KB slack: = 4 waves x [32][68] fp32 of epilogue staging
-constexpr int GL_MAX_N = 2048;
+constexpr int GL_MAX_N = 2304;           // widest output WITH a bias (the MMoE layer-0 block: 4 x 512 expert columns + 8 gate logits)
 constexpr int GL_SMEM = 2 * GL_STAGE_BYTES + GL_MAX_N * 4;
 constexpr int GL_GRID = 256 * 2;        // 2 resident workgroups per CU (77 KB of LDS each)
+constexpr int GL_OOB = (int)0x80000000u; // a voffset past every descriptor's range: the lane's 16 bytes arrive as zeros
 
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_glds_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[GL_SMEM];   // the ONLY LDS object (a second one de-pipelines the DMA)
@@ -612,23 +613,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int a_voff = (int)(((long long)lrow * g.a_rs + lchunk * 8) * 2);
   const int b_voff = (int)(((long long)lrow * g.b_cs + lchunk * 8) * 2);
   const int a_pstep = (int)(32 * g.a_rs * 2), b_pstep = (int)(32 * g.b_cs * 2);
+  // the last k-step of a reduction that is not a multiple of 64: this lane's chunk lies at k >= K (in the NEXT row's bytes) -> zeros
+  const int ktail = g.K & 63;
+  const bool chunk_in = (ktail == 0) || (lchunk * 8 < ktail);
+  const int a_voff_t = chunk_in ? a_voff : GL_OOB, b_voff_t = chunk_in ? b_voff : GL_OOB;
   // fragment reads: lane l, row (l & 31) of a 32-row block, k chunk 2*(kk/16) + (l >> 5) -> slot = chunk ^ ((row >> 1) & 7)
   const int fr_base = (lane & 31) * 128;
   const int fr_y = ((((lane >> 1) & 7) ^ (lane >> 5))) * 16;
 
   auto make_rsrc = [&](const T* base, long long rows_left, long long rs) {
     long long bytes = rows_left > 0 ? ((rows_left - 1) * rs + g.K) * 2 : 0;
-    bytes = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : bytes;
+    bytes = bytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : bytes;     // (a tile addresses < 2^31 bytes from its base: fast_ok; GL_OOB stays outside)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(unsigned)bytes, 0x00020000);
   };
-  auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0) {
+  auto issue = [&](int stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int k0, bool last) {
     unsigned char* sb = smem + stage * GL_STAGE_BYTES + wave * 1024;
+    const int av = last ? a_voff_t : a_voff, bv = last ? b_voff_t : b_voff;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(sb + p * 4096), 16, a_voff, k0 * 2 + p * a_pstep, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(sb + p * 4096), 16, av, k0 * 2 + p * a_pstep, 0, 0);
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, b_voff, k0 * 2 + p * b_pstep, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vp)(sb + 16384 + p * 4096), 16, bv, k0 * 2 + p * b_pstep, 0, 0);
   };
 
   f32x16_t acc[2][2];
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const bf16_t* gate = reinterpret_cast<const bf16_t*>(g.gate);
   const bf16_t* resid = reinterpret_cast<const bf16_t*>(g.resid);
   bf16_t* Cg = reinterpret_cast<bf16_t*>(g.C);
-  const int nk = g.K / 64;
+  const int nk = (g.K + 63) / 64;
   const int G = (int)gridDim.x;
   int cur = 0;
   bool pre = false;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (!pre) issue(cur, ra, rb, 0);
+    if (!pre) issue(cur, ra, rb, 0, nk == 1);
     // ONE barrier per k-step: after it, stage `cur` has landed for every wave and every wave has left stage cur^1 (its
     // previous multiply, or the previous tile's epilogue staging), so the next DMA can be aimed at cur^1 right away.
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       relaxed = false;
       __builtin_amdgcn_s_barrier();
-      issue(cur ^ 1, ra, rb, (kt + 1) * 64);
+      issue(cur ^ 1, ra, rb, (kt + 1) * 64, kt + 2 == nk);
       compute(cur);
       cur ^= 1;
     }
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     pre = false;
     if (L + G < g.total_blocks && Pn < g.panels) {
       const int m0n = Pn * BM, n0n = in_n * BN;
-      issue(cur ^ 1, make_rsrc(Ag + (long long)m0n * g.a_rs, g.M - m0n, g.a_rs), make_rsrc(Bg + (long long)n0n * g.b_cs, g.N - n0n, g.b_cs), 0);
+      issue(cur ^ 1, make_rsrc(Ag + (long long)m0n * g.a_rs, g.M - m0n, g.a_rs), make_rsrc(Bg + (long long)n0n * g.b_cs, g.N - n0n, g.b_cs), 0, nk == 1);
       pre = true;
     }
     compute(cur);
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int nl = j * 32 + 8 * q + h4;
-            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[cbase + nl]);
+            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[min(cbase + nl, GL_MAX_N - 4)]);   // (N > GL_MAX_N: no bias, all zeros)
             float x0 = acc[i][j][4 * q + 0] + bv.x, x1 = acc[i][j][4 * q + 1] + bv.y;
             float x2 = acc[i][j][4 * q + 2] + bv.z, x3 = acc[i][j][4 * q + 3] + bv.w;
             if (relu_mode == 2) {
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int nl = j * 32 + 8 * q + h4;
-            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[cbase + nl]);
+            const float4 bv = *reinterpret_cast<const float4*>(&bias_lds[min(cbase + nl, GL_MAX_N - 4)]);   // (N > GL_MAX_N: no bias, all zeros)
             float4 x;
             x.x = acc[i][j][4 * q + 0] + bv.x; x.y = acc[i][j][4 * q + 1] + bv.y;
             x.z = acc[i][j][4 * q + 2] + bv.z; x.w = acc[i][j][4 * q + 3] + bv.w;
@@ -1261,15 +1267,17 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
     const long long a_v_bytes = (g.a_mode == 1 ? 64ll * d->a_cs : 128ll * d->a_rs) * esz, b_v_bytes = (g.b_mode == 1 ? 64ll * d->b_rs : 128ll * d->b_cs) * esz;
     g.fast_ok = (a_k_bytes + a_v_bytes < 0x7FFFFFFFll && b_k_bytes + b_v_bytes < 0x7FFFFFFFll) ? 1 : 0;
   }
+  // the B-row class (short reduction, any batch): one round of loads, whole B operand in LDS
+  const bool small_shape = d->in_dtype == DMT_BF16 && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && d->gate == nullptr &&
+                           d->K % 8 == 0 && d->K <= 384 && d->N % 4 == 0 && d->N <= 320 && d->M <= 65536 &&
+                           (long long)(SG_BM + sg_np(d->N)) * (sg_kp(d->K) / 8) <= (long long)SG_IT * NT && sg_lds(d->N, d->K) <= 120 * 1024 &&
+                           (d->resid == nullptr || d->ldr % 4 == 0);
+  // direct-to-LDS: whole 64-wide k-steps as in round 1; a shorter last k-step (K % 8 == 0) where the B-row kernel does not apply
   const bool glds = d->in_dtype == DMT_BF16 && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && g.fast_ok && batch == 1 &&
-                    (d->K % 64 == 0) && d->N <= GL_MAX_N;
+                    (d->K % 64 == 0 || (d->K % 8 == 0 && !small_shape)) && (d->N <= GL_MAX_N || d->bias == nullptr);
   const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok &&
                        (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
-  // the B-row class (short reduction, any batch): one round of loads, whole B operand in LDS
-  const bool small = d->in_dtype == DMT_BF16 && !glds && !dw_glds && g.a_mode == 0 && g.b_mode == 0 && g.vec_epi && d->gate == nullptr &&
-                     d->K % 8 == 0 && d->K <= 384 && d->N % 4 == 0 && d->N <= 320 && d->M <= 65536 &&
-                     (long long)(SG_BM + sg_np(d->N)) * (sg_kp(d->K) / 8) <= (long long)SG_IT * NT && sg_lds(d->N, d->K) <= 120 * 1024 &&
-                     (d->resid == nullptr || d->ldr % 4 == 0);
+  const bool small = small_shape && !glds && !dw_glds;
   if (small) {
     // the attribute belongs to the (function, device) pair: set it on every device this process launches from (a host-side table
     // lookup per call after the first; no process-wide flag that a second GPU or a second host thread could find already set)
@@ -1300,6 +1308,8 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
     else hipLaunchKernelGGL((gemm_dw_glds_kernel<64, 2>), gd, dim3(NT), 0, st, g);
   } else if (glds) {
     hipLaunchKernelGGL(gemm_glds_kernel, dim3((unsigned)(nblk < GL_GRID ? nblk : GL_GRID)), dim3(NT), 0, st, g);
+    DMT_CHECK_LAUNCH("dmt_gemm(glds)");
+    return DMT_OK;
   } else if (d->in_dtype == DMT_F32) {
     launch_gemm<float>(g, grid, st);
   } else {

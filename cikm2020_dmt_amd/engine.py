@@ -590,8 +590,9 @@ class DMTEngine:
         E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
         K = self.plan.K
         zin = z if z.shape[1] == K else z[:, :K]      # inference() hands over the already split [B, K] view
+        # (z is this engine's own zero-initialised buffer; its columns past K hold the bias tower's inputs: x_pad_finite)
         g1 = ops.linear(zin, self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
-                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0])
+                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0], x_pad_finite=True)
         # [B, E * u0]: the four experts' layer-0 outputs side by side | both gates' logits
         if self.use_mmoe_fused and ops.mmoe_experts_supported(units, E, T, g1.dtype):
             # fused expert-MLP + gate kernels: layers 1-2 of every expert, the gate softmaxes and the mixtures in one launch

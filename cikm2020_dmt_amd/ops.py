@@ -20,6 +20,7 @@ F32, BF16 = torch.float32, torch.bfloat16
 # Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg):
 #   PROFILE = {"gemm": [], "gather": []}  ->  entries (start_event, end_event, algorithmic_work)
 PROFILE = None
+PROFILE_KEYS = None        # None: every family is timed; a set: only these keys get events (each pair of events costs the stream ~3 us)
 
 
 class _Timed:
@@ -27,14 +28,15 @@ class _Timed:
         self.key, self.work = key, work
 
     def __enter__(self):
-        if PROFILE is not None:
+        self.on = PROFILE is not None and (PROFILE_KEYS is None or self.key in PROFILE_KEYS)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *a):
-        if PROFILE is not None:
+        if self.on:
             self.e1.record()
             PROFILE.setdefault(self.key, []).append((self.e0, self.e1, self.work))
         return False
@@ -144,11 +146,20 @@ class Weight:
         self.proj = None          # streamed-weight image of dmt_proj (VariableStore.proj), when the geometry has a kernel
 
 
-def linear_forward(x, w: Weight, bias, act_ncols=0, resid=None, out=None, out_dtype=None):
-    """y[M,N] = epi(x[M,K] @ W[K,N]).  x: 2-D row-major view (any row stride)."""
+def linear_forward(x, w: Weight, bias, act_ncols=0, resid=None, out=None, out_dtype=None, x_pad_finite=False):
+    """y[M,N] = epi(x[M,K] @ W[K,N]).  x: 2-D row-major view (any row stride).
+
+    x_pad_finite: the caller owns the buffer x is a view of and its columns K .. ceil8(K) hold FINITE values (not uninitialised
+    memory).  With an odd K (the 3047-wide MMoE input) the bf16 reduction then runs over ceil8(K) columns -- the transposed shadow
+    holds zeros there (VariableStore allocates it zeroed and only ever writes [:, :K]) -- which is the shape the direct-to-LDS
+    GEMM takes (16-byte chunks)."""
     M, K = x.shape
     N = w.f32.shape[1]
     ldx = _row_major2d(x, "x")
+    if x_pad_finite and x.dtype == BF16 and K % 8:
+        Kp = (K + 7) // 8 * 8
+        if ldx >= Kp and w.lp_t.stride(0) >= Kp and x.storage_offset() + (M - 1) * ldx + Kp <= x.untyped_storage().nbytes() // 2:
+            K = Kp
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
     ldc = _row_major2d(out, "out")
@@ -168,7 +179,10 @@ def linear_backward_input(dz, w: Weight, gate=None, resid=None, out=None):
     K = w.f32.shape[0]
     ldz = _row_major2d(dz, "dz")
     if out is None:
-        out = torch.empty((M, K), dtype=dz.dtype, device=dz.device)
+        # (bf16: 16-byte aligned rows also for an odd width -- the vector epilogue and the direct-to-LDS route need them)
+        Kp = (K + 7) // 8 * 8 if dz.dtype == BF16 else K
+        out = torch.empty((M, Kp), dtype=dz.dtype, device=dz.device)
+        out = out[:, :K] if Kp != K else out
     ldc = _row_major2d(out, "out")
     wm = w.lp if dz.dtype == BF16 else w.f32          # [K, N]: B(k=n, n'=k') = W[k'*ld + n]
     gemm(dz, ldz, 1, wm, 1, wm.stride(0), M, K, N, out, ldc,
@@ -428,9 +442,9 @@ class LinearFn(torch.autograd.Function):
     """y = relu?(x W + b) (+ resid), the op behind base.dense_layer / tf.layers.dense call sites."""
 
     @staticmethod
-    def forward(ctx, x, w_leaf, b_leaf, w: Weight, act_ncols, out_dtype):
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, act_ncols, out_dtype, x_pad_finite=False):
         x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
-        y = linear_forward(x2, w, b_leaf, act_ncols=act_ncols, out_dtype=out_dtype)
+        y = linear_forward(x2, w, b_leaf, act_ncols=act_ncols, out_dtype=out_dtype, x_pad_finite=x_pad_finite)
         ctx.w = w
         ctx.leaves = (w_leaf, b_leaf)
         ctx.act_ncols = act_ncols
@@ -454,13 +468,13 @@ class LinearFn(torch.autograd.Function):
         dW, db = linear_backward_weight(x2, dz, want_bias=ctx.has_bias, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
         if dx is not None:
             dx = dx.reshape(ctx.xshape)
-        return dx, dW, db, None, None, None
+        return dx, dW, db, None, None, None, None
 
 
-def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=None):
+def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=None, x_pad_finite=False):
     n = w.f32.shape[1]
     a = (n if relu else 0) if act_ncols is None else act_ncols
-    return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype)
+    return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype, x_pad_finite)
 
 
 def _uniform_stride(ts):

@@ -1,36 +1,51 @@
-"""Host (enqueue) time per training step vs the GPU's: is the step launch-bound?  usage: python scripts/host_time.py [--profile]"""
+"""Host-side cost of one train step: how long the Python / ctypes / autograd side takes to ENQUEUE a step when nothing holds it back
+(queues empty after a synchronize, a burst of n steps, n small enough that no queue fills), against the GPU time of the same steps.
+
+    python scripts/host_time.py [burst]
+"""
+import os
 import sys
 import time
-import torch
-from cikm2020_dmt_amd import spec as S
-from cikm2020_dmt_amd.data_feed.synthetic import make_batch
-from cikm2020_dmt_amd.train import Trainer
 
-dev = torch.device("cuda:0")
-sp = S.e64_spec()
-tr = Trainer(sp, device=dev, compute_dtype=torch.bfloat16, seed=1, dropout=True)
-bs = []
-for i in range(4):
-    inputs, mask, label = make_batch(sp, 4096, seed=i, lengths="full")
-    bs.append(tr.make_batch(inputs, mask, label))
-def step(i):
-    b = bs[i % 4]; b._prep = None
-    return tr.train_step(b)
-for i in range(6):
-    step(i)
-torch.cuda.synchronize()
-for rep in range(2):
-    t0 = time.perf_counter(); hs = []
-    for i in range(20):
-        a = time.perf_counter(); step(i); hs.append(time.perf_counter() - a)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print("host enqueue %.2f ms/step (min %.2f)  wall %.2f ms/step  drain after last enqueue %.2f ms" % ((t1 - t0) / 20 * 1e3, min(hs) * 1e3, (t2 - t0) / 20 * 1e3, (t2 - t1) * 1e3))
-if "--profile" in sys.argv:
-    import cProfile, pstats
-    pr = cProfile.Profile(); pr.enable()
-    for i in range(10):
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cikm2020_dmt_amd import spec as S                      # noqa: E402
+from cikm2020_dmt_amd.data_feed.synthetic import make_batch  # noqa: E402
+from cikm2020_dmt_amd.train import Trainer                  # noqa: E402
+
+
+def main(burst):
+    sp = S.e64_spec()
+    tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16, seed=1234, dropout=True)
+    batches = [tr.make_batch(*make_batch(sp, 4096, seed=7 + i, lengths="full", law="zipf")) for i in range(4)]
+
+    def step(i):
+        b, nxt = batches[i % 4], batches[(i + 1) % 4]
+        nxt._prep = None
+        return tr.train_step(b, prefetch=nxt)
+    for i in range(12):
         step(i)
-    pr.disable(); torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(35)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        t0 = time.perf_counter()
+        for i in range(burst):
+            step(i)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("burst of %d steps: host enqueue %.3f ms/step, until the GPU is done %.3f ms/step" % (burst, (t1 - t0) / burst * 1e3, (t2 - t0) / burst * 1e3))
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(burst):
+        step(i)
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 3)

@@ -131,6 +131,79 @@ def test_gemm_small_kernel_route(cuda, M, N, K, Bt, epi):
     assert (got[:, :, N:] == 7.0).all()                         # nothing written past column N
 
 
+@pytest.mark.parametrize("M,N,K", [(260, 2056, 3048), (300, 3047, 2056), (128, 328, 8), (130, 400, 72), (4096, 320, 1288), (64, 2304, 64)])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "gate_resid"])
+def test_gemm_direct_to_lds_route_k_tails_and_wide_outputs(cuda, M, N, K, epi):
+    """gemm_glds_kernel past its round-1 limits: a reduction that is a multiple of 8 but not of 64 (the last k-step's chunks at k >= K
+    must come back as ZEROS -- both operands hold garbage there: the next row's values), outputs wider than the bias block in LDS
+    (N = 3047: the MMoE layer-0 input gradient, odd width in a padded row), N = 2056 with a bias (layer-0 forward).  Route asserted."""
+    from cikm2020_dmt_amd import _lib as L
+    dt = torch.bfloat16
+    if epi == "bias_relu" and N > 2304:
+        pytest.skip("outputs wider than 2304 columns take the direct-to-LDS route only without a bias")
+    g = torch.Generator().manual_seed(31)
+    lda, ldb, ldc = K + 24, K + 8, (N + 7) // 8 * 8
+    xa = (torch.randn((M, lda), generator=g) * 0.5).to(dt).to(cuda)        # pad columns hold data, not zeros
+    wb = (torch.randn((N, ldb), generator=g) * 0.5).to(dt).to(cuda)
+    xr, wr = xa[:, :K].double().cpu(), wb[:, :K].double().cpu()
+    o = torch.full((M, ldc), 7.0, dtype=dt, device=cuda)
+    ref = xr @ wr.t()
+    kw = {}
+    if epi == "bias_relu":
+        b = torch.randn(N, device=cuda)
+        nrelu = (N // 2) & ~3
+        kw.update(bias=b, act_ncols=nrelu)
+        ref = ref + b.double().cpu()
+        ref[:, :nrelu] = ref[:, :nrelu].clamp_min(0)
+    elif epi == "gate_resid":
+        gt = (torch.randn((M, ldc), generator=g)).to(dt).to(cuda)
+        r = (torch.randn((M, ldc), generator=g)).to(dt).to(cuda)
+        kw.update(gate=gt, ldg=ldc, resid=r, ldr=ldc)
+        ref = ref * (gt[:, :N].double().cpu() > 0) + r[:, :N].double().cpu()
+    with L.route_trace() as rt:
+        ops.gemm(xa, lda, 1, wb, 1, ldb, M, N, K, o, ldc, **kw)
+        torch.cuda.synchronize()
+    assert rt.counts.get("dmt_gemm(glds)", 0) == 1, rt.counts
+    got = o.double().cpu()
+    assert (got[:, :N] - ref).abs().max().item() / ref.abs().max().item() < _tol(dt)
+    assert (got[:, N:] == 7.0).all()                            # nothing written past column N
+
+
+def test_linear_over_a_padded_odd_width_input(cuda):
+    """ops.linear(..., x_pad_finite=True) on a 3047-wide view of a wider buffer (the MMoE input): the reduction runs over 3048 columns
+    against the zero column of the transposed shadow; forward, input gradient (odd width, padded rows) and weight gradient against fp64."""
+    from cikm2020_dmt_amd import _lib as L
+    dt = torch.bfloat16
+    M, K, N = 384, 3047, 2056
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn((M, 3096), generator=g) * 0.5).to(dt).to(cuda)       # columns >= K: other (finite) data
+    w32 = (torch.randn((K, N), generator=g) * 0.02).to(cuda).requires_grad_(True)
+    b32 = torch.randn(N, generator=g).to(cuda).requires_grad_(True)
+    lp = w32.detach().to(dt)
+    lp_t = torch.zeros((N, 3048), dtype=dt, device=cuda)[:, :K]
+    lp_t.copy_(lp.t())
+    W = ops.Weight(w32.detach(), lp, lp_t)
+    x = z[:, :K].detach().requires_grad_(True)
+    w32.grad = torch.zeros_like(w32)
+    b32.grad = torch.zeros_like(b32)
+    with L.route_trace() as rt:
+        y = ops.linear(x, w32, b32, W, act_ncols=2048, x_pad_finite=True)
+        dy = (torch.randn((M, N), generator=g) * 0.5).to(dt).to(cuda)
+        y.backward(dy)
+        torch.cuda.synchronize()
+    assert rt.counts.get("dmt_gemm(glds)", 0) == 2, rt.counts              # forward and input gradient
+    xr, wr, br = x.detach().double().cpu().requires_grad_(True), lp.double().cpu().requires_grad_(True), b32.detach().double().cpu().requires_grad_(True)
+    pre = xr @ wr + br
+    yr = torch.cat([pre[:, :2048].clamp_min(0), pre[:, 2048:]], 1)
+    assert (y.double().cpu() - yr.detach()).abs().max().item() / yr.abs().max().item() < _tol(dt)
+    dyr = dy.double().cpu() * torch.cat([(y[:, :2048].double().cpu() > 0).double(), torch.ones(M, N - 2048, dtype=torch.float64)], 1)
+    dxr = dyr @ wr.detach().t()
+    assert (x.grad.double().cpu() - dxr).abs().max().item() / dxr.abs().max().item() < _tol(dt)
+    dwr = xr.detach().t() @ dyr
+    assert (w32.grad.double().cpu() - dwr).abs().max().item() / dwr.abs().max().item() < 1e-4
+    assert (b32.grad.double().cpu() - dyr.sum(0)).abs().max().item() / dyr.sum(0).abs().max().item() < 1e-4
+
+
 def test_gemm_rejects_bad_args(cuda):
     from cikm2020_dmt_amd._lib import DmtError
     x = torch.zeros((4, 4), device=cuda)
