@@ -17,7 +17,8 @@ FAMILIES = {
     "gather_fwd": ["gather_group_kernel"],
     "embgrad_reduce": ["embgrad_reduce_kernel"],
     "adam_sparse": ["adam_sparse_kernel"],
-    "mhsa": ["mhsa2_fwd_kernel", "mhsa2_bwd_kernel"],
+    "mhsa_block": ["mhsa_fwd_kernel"],
+    "gemm_small": ["gemm_small_kernel"],
     "adam_catchup": ["adam_catchup_kernel"],
     "ln": ["ln_fwd", "ln_bwd"],
 }
