@@ -571,6 +571,10 @@ class DMTEngine:
             for st in side:
                 if st is not None:
                     main.wait_stream(st)
+            # the junction: from here to the first long backward kernel the compute stream runs one B-row kernel after the other
+            # (MMoE layer 0, experts, towers, loss and back) and most of the chip is idle -- Trainer._catch_up_early starts there
+            self.junction_event = torch.cuda.Event()
+            self.junction_event.record(main)
         z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *us)
         self.intermediates["zbuf"] = z
         return z

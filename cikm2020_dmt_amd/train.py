@@ -85,6 +85,7 @@ class Trainer:
         # the one-GPU step is throughput-bound, not latency-bound -- measured 10.12 ms with it against 10.01 ms without (the replay
         # takes the same GPU time on the index lane, 0.83 ms, and slows the kernels it runs beside)
         self.early_catchup = os.environ.get("DMT_EARLY_CATCHUP", "0") == "1"
+        self.early_catchup_at_junction = os.environ.get("DMT_EARLY_CATCHUP_AT", "junction") == "junction"
         self._inflight = None        # (event "begin() of the step in flight has run and its rows are stamped", that step's local number)
         if self.device.type == "cuda":
             streams.lanes(self.device)                     # bind the step's lanes to hardware queues before anything else (streams.py)
@@ -179,6 +180,11 @@ class Trainer:
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(side):
             side.wait_event(ev_begun)
+            jev = getattr(self.engine, "junction_event", None)
+            if jev is not None and self.early_catchup_at_junction:
+                # not beside the forward's long kernels (measured: no gain, the replay takes its issue slots from them) but where the
+                # step leaves the chip nearly idle: the chain of B-row kernels between the last decoder and the first long backward kernel
+                side.wait_event(jev)
             with self._span("adam_catchup_early"):
                 self.opt.catch_up_early(prep["uniq"], prep["n_uniq"], prep["cap"], to_step)
             ev = torch.cuda.Event()
