@@ -10,6 +10,9 @@
 #include <unistd.h>
 
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -487,6 +490,66 @@ static void zero_row(const ParseCtx& cx, int b) {
   }
 }
 
+// A process-wide pool of parked worker threads.  std::thread per call cost ~60 us per thread in a process of this size (clone + stack
+// mapping + join): 2 ms of a 4.7 ms batch at 32 threads, 8 ms at 128 -- the floor that made more parser threads SLOWER.  One job at a
+// time (callers serialise on job_mu; the parser's calls are per-batch and short); workers sleep on a condition variable between jobs.
+class WorkerPool {
+ public:
+  static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }     // (never destroyed: no join at process exit)
+  // run task(t) for t in [0, nt) -- task 0 on the caller, the others on pool threads -- and return when all are done
+  void run(int nt, const std::function<void(int)>& task) {
+    std::lock_guard<std::mutex> job(job_mu_);
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      if (pid_ != getpid()) {            // a fork()ed child has none of the parent's threads: start over
+        pid_ = getpid();
+        threads_.clear();                // (detached handles: nothing to join)
+        epoch_ = 0;
+      }
+      while ((int)threads_.size() < nt - 1) {
+        const int id = (int)threads_.size();
+        threads_.emplace_back([this, id]() { loop(id); });
+        threads_.back().detach();
+      }
+      task_ = &task;
+      n_tasks_ = nt;
+      pending_ = nt - 1;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    task(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this]() { return pending_ == 0; });
+    task_ = nullptr;
+  }
+
+ private:
+  void loop(int id) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* task = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return epoch_ != seen; });
+        seen = epoch_;
+        if (id + 1 < n_tasks_) task = task_;
+      }
+      if (task) {
+        (*task)(id + 1);
+        std::unique_lock<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> threads_;
+  const std::function<void(int)>* task_ = nullptr;
+  int n_tasks_ = 0, pending_ = 0;
+  unsigned long long epoch_ = 0;
+  pid_t pid_ = getpid();
+};
+
 // run fn(b) for b in [0, n) on nt threads; the first failure wins
 template <typename F>
 static int parallel_rows(int n, int n_threads, F&& fn) {
@@ -501,16 +564,14 @@ static int parallel_rows(int n, int n_threads, F&& fn) {
   }
   std::vector<int> rcs((size_t)nt, DMT_IN_OK);
   std::vector<std::string> errs((size_t)nt);
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t]() {
-      const int b0 = (int)((long long)n * t / nt), b1 = (int)((long long)n * (t + 1) / nt);
-      for (int b = b0; b < b1; ++b) {
-        const int rc = fn(b);
-        if (rc != DMT_IN_OK) { rcs[t] = rc; errs[t] = g_err; return; }
-      }
-    });
-  for (auto& x : th) x.join();
+  const std::function<void(int)> task = [&](int t) {
+    const int b0 = (int)((long long)n * t / nt), b1 = (int)((long long)n * (t + 1) / nt);
+    for (int b = b0; b < b1; ++b) {
+      const int rc = fn(b);
+      if (rc != DMT_IN_OK) { rcs[t] = rc; errs[t] = g_err; return; }
+    }
+  };
+  WorkerPool::get().run(nt, task);
   for (int t = 0; t < nt; ++t)
     if (rcs[t] != DMT_IN_OK) return fail(rcs[t], "%s", errs[t].c_str());
   return DMT_IN_OK;
