@@ -59,7 +59,8 @@ void dmt_vocab_destroy(dmt_vocab* v);
  *   float feature (vocab == NULL): Example key `name` is a float list of exactly max_len values -> dense[b, :]
  *                                 (`features` 615, `mask` 5, `label` 1); a missing key leaves zeros.
  * Rows are zero filled first.  A list longer than max_len is an error (DMT_IN_ERR_RANGE), like a shape mismatch in
- * tf.parse_example.  n_threads <= 1: the calling thread does all the work. */
+ * tf.parse_example.  n_threads <= 1: the calling thread does all the work; otherwise the rows are split over n_threads workers of a
+ * process-wide pool of parked threads (created on first use, one job at a time: concurrent callers take turns). */
 typedef struct {
   const char* name;
   const dmt_vocab* vocab;

@@ -130,6 +130,60 @@ def test_tfrecord_and_batch_parse_equal_the_python_pipeline(tmp_path):
     assert np.array_equal(np.concatenate([b["seq_sku"] for b in bs]), got["seq_sku"])
 
 
+def test_worker_pool_serves_concurrent_callers_growing_thread_counts_and_a_forked_child(tmp_path):
+    """The library's parked worker pool (one job at a time, callers serialise): several Python threads parsing at once with different
+    thread counts (the pool grows between jobs), every result equal to the single-threaded parse; an error raised inside a worker comes
+    back as the caller's error; a fork()ed child -- which has none of the parent's threads -- starts its own workers."""
+    import threading
+    rng = np.random.default_rng(7)
+    exs = _make_examples(97, rng)
+    recs = [tfrecord.encode_example(e) for e in exs]
+    voc = _vocab_lists()
+    sizes = {"Sku": 1000, "Cid": 7, "Time": 4, "CidB": 7}
+    emb_of = {"item_sku": "Sku", "seq_sku": "Sku", "seq_cid": "Cid", "seq_ts": "Time", "item_cid": "CidB"}
+    feats = ["item_sku", "seq_sku", "seq_cid", "seq_ts", "item_cid"]
+
+    def make(nt, T=6):
+        nat_voc = {k: native.Vocab(v, sizes[k]) for k, v in voc.items()}
+        return native.BatchParser([(f, nat_voc[emb_of[f]], T) for f in feats], [("features", 6), ("mask", 5), ("label", 1)], n_threads=nt)
+    ref = make(1).parse(recs)
+    out, errs = {}, []
+
+    def work(i, nt):
+        try:
+            p = make(nt)
+            for _ in range(20):
+                got = p.parse(recs)
+                for k, v in ref.items():
+                    if isinstance(v, np.ndarray) and not np.array_equal(got[k], v):
+                        raise AssertionError("thread %d (%d workers): column %s differs" % (i, nt, k))
+            out[i] = True
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i, nt)) for i, nt in enumerate((2, 5, 3, 8, 4, 16))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert len(out) == 6
+    # a failure inside a pool worker reaches the caller (the over-long list is in the LAST record: not the caller's own chunk)
+    with pytest.raises(native.InputError):
+        make(4, T=1).parse(recs)
+    assert np.array_equal(make(4).parse(recs)["seq_sku"], ref["seq_sku"])      # the pool is usable after the failure
+    # fork: the child has the pool object but none of its threads
+    pid = os.fork()
+    if pid == 0:
+        ok = 1
+        try:
+            got = make(4).parse(recs)
+            ok = 0 if all(np.array_equal(got[k], v) for k, v in ref.items() if isinstance(v, np.ndarray)) else 2
+        finally:
+            os._exit(ok)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+
+
 def test_reader_rejects_corruption_and_parser_rejects_overlong_lists(tmp_path):
     rng = np.random.default_rng(3)
     exs = _make_examples(4, rng)
