@@ -15,7 +15,7 @@ DMT_F32, DMT_BF16, DMT_FP8_E4M3 = 0, 1, 2
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
-DMT_ABI_VERSION = 3        # include/dmt_hip.h: the revision this binding was written against (checked by load())
+DMT_ABI_VERSION = 4        # include/dmt_hip.h: the revision this binding was written against (checked by load())
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -70,7 +70,8 @@ class MmoeDesc(C.Structure):
                 ("w1t", c_vp), ("w1t_expert_stride", c_i64), ("w1t_ld", c_i64), ("w2t", c_vp), ("w2t_expert_stride", c_i64), ("w2t_ld", c_i64),
                 ("w1", c_vp), ("w1_expert_stride", c_i64), ("w2", c_vp), ("w2_expert_stride", c_i64),
                 ("b1", c_vp), ("b1_expert_stride", c_i64), ("b2", c_vp), ("b2_expert_stride", c_i64),
-                ("h1", c_vp), ("h2", c_vp), ("gates", c_vp), ("mix", c_vp), ("dmix", c_vp), ("dh1", c_vp), ("dh2", c_vp), ("dg1", c_vp), ("lddg", c_i64)]
+                ("h1", c_vp), ("h2", c_vp), ("gates", c_vp), ("mix", c_vp), ("dmix", c_vp), ("dh1", c_vp), ("dh2", c_vp), ("dg1", c_vp), ("lddg", c_i64),
+                ("ws", c_vp), ("ws_bytes", c_i64), ("gate_dx", c_i32)]
 
 
 class HeadsDesc(C.Structure):
@@ -186,7 +187,7 @@ _SIGS = {
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS.keys()) + ["dmt_last_error", "dmt_version", "dmt_build_arch", "dmt_ln_bwd_partials", "dmt_struct_size", "dmt_chain_supported", "dmt_proj_supported", "dmt_image_job_bytes",
-                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_reduce_det_ws_bytes", "dmt_wgrad320_det_ws_bytes", "dmt_route_trace", "dmt_route_count", "dmt_route_dump"])
+                                                 "dmt_attn_long_supported", "dmt_mmoe_experts_supported", "dmt_mmoe_experts_ws_bytes", "dmt_heads_supported", "dmt_q1mem_supported", "dmt_reduce_det_ws_bytes", "dmt_wgrad320_det_ws_bytes", "dmt_route_trace", "dmt_route_count", "dmt_route_dump"])
 
 _lib = None
 
@@ -227,6 +228,8 @@ def load():
     lib.dmt_heads_supported.argtypes = [c_i32] * 6
     lib.dmt_mmoe_experts_supported.restype = c_i32
     lib.dmt_mmoe_experts_supported.argtypes = [c_i32] * 5
+    lib.dmt_mmoe_experts_ws_bytes.restype = c_i64
+    lib.dmt_mmoe_experts_ws_bytes.argtypes = [c_i32]
     lib.dmt_reduce_det_ws_bytes.restype = C.c_uint64
     lib.dmt_reduce_det_ws_bytes.argtypes = [c_i64, c_i32]
     lib.dmt_attn_long_supported.restype = c_i32

@@ -15,6 +15,8 @@
 // round trips of h1 / h2 / their gradients between them.
 #include "dmt_common.h"
 
+extern "C" int64_t dmt_mmoe_experts_ws_bytes(int32_t B);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
@@ -43,6 +45,10 @@ struct MmoeArgs {
   const bf16_t* dmix;                              // [T, B, U2]
   bf16_t* dh1; bf16_t* dh2;                        // [B, E*U1], [B, E*U2]: operands of the weight-gradient GEMMs
   bf16_t* dg1; long long lddg;                     // [B, >= E*U0 + T*E]
+  // split form (one workgroup per (row tile, expert)): the experts' d gate partials
+  int n_tiles;
+  float* dgs;                                      // [B][MAXG]
+  int gate_dx;                                     // backward: d x *= (g1 > 0)
 };
 
 __device__ __forceinline__ f32x16_t zero16() {
@@ -346,6 +352,273 @@ __global__ __launch_bounds__(256) void mmoe_experts_bwd_kernel(const MmoeArgs a)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- split form (round 4)
+// B = 4096 rows are 128 row tiles: the kernels above fill half the chip, and a workgroup walks its four experts one after the other
+// -- a chain of L2 round trips (every MFMA operand of the weights comes straight from global memory) four experts long: 85 / 75 us
+// in the middle of the step's junction, where nothing else runs.  Here one workgroup owns (row tile, expert): 512 workgroups, a chain one
+// expert long.  What needs all experts of a tile -- the mixtures, the softmax gradient of the gate logits -- is done by a small second
+// launch (mmoe_mix_finish_kernel / mmoe_dgate_finish_kernel: one workgroup per row tile) that walks the experts in index order over the
+// values the first one stored (h2 rounded to bf16, the fp32 gates, the fp32 d gate partials): the same operations in the same order as
+// above, bit-identical results.  (First built with the tile's last-arriving workgroup doing that step behind a device-scope counter:
+// correct, and SLOWER than the one-workgroup form -- 128 against 80 us per launch -- because a device-scope release on this chip is a
+// write-back of the XCD's whole L2, once per workgroup.  The kernel boundary is the cheap release.)  Workgroup i runs on XCD i % 8:
+// the E workgroups of a tile are E consecutive workgroups of one XCD (they share the tile's g1 / d mix rows in its L2).
+__device__ __forceinline__ bool split_map(const MmoeArgs& a, int& tile, int& e) {
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  tile = (int)((slot / (unsigned)a.E) * 8u + xcd);
+  e = (int)(slot % (unsigned)a.E);
+  return tile < a.n_tiles;
+}
+
+__global__ __launch_bounds__(256) void mmoe_split_fwd_kernel(const MmoeArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_h1[MR * H1S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  int tile, e;
+  if (!split_map(a, tile, e)) return;
+  const long long r0 = (long long)tile * MR;
+  const int E = a.E, T = a.T;
+  // ---- gates (expert 0's workgroup): softmax over the experts' logits, per (row, task)
+  if (e == 0 && tid < MR * T) {
+    const int m = tid / T, t = tid - m * T;
+    const long long row = r0 + m;
+    if (row < a.B) {
+      const bf16_t* gl = a.g1 + row * a.ldg + E * U0 + t * E;
+      float ex[MAXG];
+      float mx = -3.0e38f;
+      for (int q = 0; q < E; ++q) mx = fmaxf(mx, bf2f(gl[q]));
+      float s = 0.f;
+      for (int q = 0; q < E; ++q) { const float v = expf(bf2f(gl[q]) - mx); ex[q] = v; s += v; }
+      for (int q = 0; q < E; ++q) a.gates[((long long)t * a.B + row) * E + q] = ex[q] / s;
+    }
+  }
+  const long long rowm = r0 + l31;
+  const bool rok = rowm < a.B;
+  // ---- layer 1: h1^T [U1][32] = W1^T [U1][U0] x^T; this wave: hidden units 64 wave .. +63
+  {
+    f32x16_t acc[2] = {zero16(), zero16()};
+    const bf16_t* wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wp[i] = a.w1t + e * a.w1_es + (long long)(64 * wave + 32 * i + l31) * a.w1_ld + 8 * half;
+    const bf16_t* xp = a.g1 + (rok ? rowm : 0) * a.ldg + e * U0 + 8 * half;
+#pragma unroll 8
+    for (int k0 = 0; k0 < U0; k0 += 16) {
+      const bf16x8_t w0 = ld8(wp[0] + k0), w1 = ld8(wp[1] + k0);
+      const bf16x8_t x = ld8(xp + k0);
+      acc[0] = mma(w0, x, acc[0]);
+      acc[1] = mma(w1, x, acc[1]);
+    }
+    const float* bias = a.b1 + e * a.b1_es;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 64 * wave + 32 * nt + 8 * g + 4 * half;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+        const uint2 pk = pack4(fmaxf(acc[nt][4 * g + 0] + bb.x, 0.f), fmaxf(acc[nt][4 * g + 1] + bb.y, 0.f),
+                               fmaxf(acc[nt][4 * g + 2] + bb.z, 0.f), fmaxf(acc[nt][4 * g + 3] + bb.w, 0.f));
+        *reinterpret_cast<uint2*>(s_h1 + l31 * H1S + n) = pk;
+        if (rok) *reinterpret_cast<uint2*>(a.h1 + rowm * (long long)(E * U1) + e * U1 + n) = pk;
+      }
+  }
+  __syncthreads();
+  // ---- layer 2: h2^T [U2][32] = W2^T [U2][U1] h1^T; this wave: output units 32 wave .. +31
+  {
+    f32x16_t acc = zero16();
+    const bf16_t* wp = a.w2t + e * a.w2_es + (long long)(32 * wave + l31) * a.w2_ld + 8 * half;
+    const bf16_t* hp = s_h1 + l31 * H1S + 8 * half;
+#pragma unroll 8
+    for (int k0 = 0; k0 < U1; k0 += 16) acc = mma(ld8(wp + k0), ld8(hp + k0), acc);
+    const float* bias = a.b2 + e * a.b2_es;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = 32 * wave + 8 * g + 4 * half;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+      if (rok)
+        *reinterpret_cast<uint2*>(a.h2 + rowm * (long long)(E * U2) + e * U2 + n) =
+            pack4(fmaxf(acc[4 * g + 0] + bb.x, 0.f), fmaxf(acc[4 * g + 1] + bb.y, 0.f), fmaxf(acc[4 * g + 2] + bb.z, 0.f), fmaxf(acc[4 * g + 3] + bb.w, 0.f));
+    }
+  }
+}
+
+// mix[t] = sum_e gate[t][e] * h2_e, e ascending (an fmaf chain from 0, as in the one-workgroup form); one workgroup per row tile
+__global__ __launch_bounds__(256) void mmoe_mix_finish_kernel(const MmoeArgs a) {
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * MR;
+  const int E = a.E, T = a.T;
+  const int m = tid >> 3, c0 = (tid & 7) * 16;
+  const long long row = r0 + m;
+  if (row >= a.B) return;
+  for (int t = 0; t < T; ++t) {
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int q = 0; q < E; ++q) {
+      const float gt = a.gates[((long long)t * a.B + row) * E + q];
+      union { uint4 u[2]; bf16_t h[16]; } hv;
+      const uint4* hp = reinterpret_cast<const uint4*>(a.h2 + row * (long long)(E * U2) + q * U2 + c0);
+      hv.u[0] = hp[0]; hv.u[1] = hp[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(gt, bf2f(hv.h[i]), acc[i]);
+    }
+    uint4 o[2];
+    o[0] = make_uint4(dmt_pack_bf16(acc[0], acc[1]), dmt_pack_bf16(acc[2], acc[3]), dmt_pack_bf16(acc[4], acc[5]), dmt_pack_bf16(acc[6], acc[7]));
+    o[1] = make_uint4(dmt_pack_bf16(acc[8], acc[9]), dmt_pack_bf16(acc[10], acc[11]), dmt_pack_bf16(acc[12], acc[13]), dmt_pack_bf16(acc[14], acc[15]));
+    uint4* mp = reinterpret_cast<uint4*>(a.mix + ((long long)t * a.B + row) * U2 + c0);
+    mp[0] = o[0]; mp[1] = o[1];
+  }
+}
+
+__global__ __launch_bounds__(256) void mmoe_split_bwd_kernel(const MmoeArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_dh2[MR * H2S];
+  __shared__ __attribute__((aligned(16))) bf16_t s_dh1[MR * H1S];
+  __shared__ float s_gate[MR][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  int tile, e;
+  if (!split_map(a, tile, e)) return;
+  const long long r0 = (long long)tile * MR;
+  const int E = a.E, T = a.T;
+  if (tid < MR * 4) {
+    const int m = tid >> 2, t = tid & 3;
+    const long long row = r0 + m;
+    s_gate[m][t] = (t < T && row < a.B) ? a.gates[((long long)t * a.B + row) * E + e] : 0.f;
+  }
+  __syncthreads();
+  const long long rowm = r0 + l31;
+  const bool rok = rowm < a.B;
+  constexpr int EPR = 256 / MR, ECW = U2 / EPR;
+  const int em = tid / EPR, ec = (tid % EPR) * ECW;
+  const long long erow = r0 + em;
+  const bool eok = erow < a.B;
+  // ---- d h2 = relu'(h2) * sum_t gate[t][e] d mix[t];  d gate[t][e] = d mix[t] . h2
+  {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c8 = 0; c8 < ECW; c8 += 8) {
+      float hv[8], dv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv[i] = 0.f;
+      union { uint4 q; bf16_t h[8]; } hx, dm;
+      hx.q = eok ? *reinterpret_cast<const uint4*>(a.h2 + erow * (long long)(E * U2) + e * U2 + ec + c8) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = bf2f(hx.h[i]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t >= T) break;
+        dm.q = eok ? *reinterpret_cast<const uint4*>(a.dmix + ((long long)t * a.B + erow) * U2 + ec + c8) : make_uint4(0u, 0u, 0u, 0u);
+        const float gt = s_gate[em][t];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = bf2f(dm.h[i]);
+          dv[i] = fmaf(gt, d, dv[i]);
+          part[t] = fmaf(hv[i], d, part[t]);
+        }
+      }
+      uint4 o;
+      o.x = dmt_pack_bf16(hv[0] > 0.f ? dv[0] : 0.f, hv[1] > 0.f ? dv[1] : 0.f);
+      o.y = dmt_pack_bf16(hv[2] > 0.f ? dv[2] : 0.f, hv[3] > 0.f ? dv[3] : 0.f);
+      o.z = dmt_pack_bf16(hv[4] > 0.f ? dv[4] : 0.f, hv[5] > 0.f ? dv[5] : 0.f);
+      o.w = dmt_pack_bf16(hv[6] > 0.f ? dv[6] : 0.f, hv[7] > 0.f ? dv[7] : 0.f);
+      *reinterpret_cast<uint4*>(s_dh2 + em * H2S + ec + c8) = o;
+      if (eok) *reinterpret_cast<uint4*>(a.dh2 + erow * (long long)(E * U2) + e * U2 + ec + c8) = o;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= T) break;
+      float p = part[t];
+#pragma unroll
+      for (int o = 1; o < EPR; o <<= 1) p += __shfl_xor(p, o, 64);
+      if ((tid % EPR) == 0 && eok) a.dgs[erow * MAXG + t * E + e] = p;
+    }
+  }
+  __syncthreads();
+  // ---- d h1^T [U1][32] = W2 [U1][U2] d h2^T, relu gate of h1; this wave: hidden units 64 wave .. +63
+  {
+    f32x16_t acc[2] = {zero16(), zero16()};
+    const bf16_t* wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wp[i] = a.w2p + e * a.w2p_es + (long long)(64 * wave + 32 * i + l31) * U2 + 8 * half;
+    const bf16_t* dp = s_dh2 + l31 * H2S + 8 * half;
+#pragma unroll
+    for (int k0 = 0; k0 < U2; k0 += 16) {
+      const bf16x8_t w0 = ld8(wp[0] + k0), w1 = ld8(wp[1] + k0);
+      const bf16x8_t dd = ld8(dp + k0);
+      acc[0] = mma(w0, dd, acc[0]);
+      acc[1] = mma(w1, dd, acc[1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 64 * wave + 32 * nt + 8 * g + 4 * half;
+        union { uint2 u; bf16_t h[4]; } hv;
+        hv.u = rok ? *reinterpret_cast<const uint2*>(a.h1 + rowm * (long long)(E * U1) + e * U1 + n) : make_uint2(0u, 0u);
+        const uint2 pk = pack4(bf2f(hv.h[0]) > 0.f ? acc[nt][4 * g + 0] : 0.f, bf2f(hv.h[1]) > 0.f ? acc[nt][4 * g + 1] : 0.f,
+                               bf2f(hv.h[2]) > 0.f ? acc[nt][4 * g + 2] : 0.f, bf2f(hv.h[3]) > 0.f ? acc[nt][4 * g + 3] : 0.f);
+        *reinterpret_cast<uint2*>(s_dh1 + l31 * H1S + n) = pk;
+        if (rok) *reinterpret_cast<uint2*>(a.dh1 + rowm * (long long)(E * U1) + e * U1 + n) = pk;
+      }
+  }
+  __syncthreads();
+  // ---- d x^T [U0][32] = W1 [U0][U1] d h1^T; this wave: inputs 128 wave .. +127 (gate_dx: times the relu gradient of the layer that made g1)
+  {
+    f32x16_t acc[4] = {zero16(), zero16(), zero16(), zero16()};
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wp[i] = a.w1p + e * a.w1p_es + (long long)(128 * wave + 32 * i + l31) * U1 + 8 * half;
+    const bf16_t* dp = s_dh1 + l31 * H1S + 8 * half;
+#pragma unroll 4
+    for (int k0 = 0; k0 < U1; k0 += 16) {
+      const bf16x8_t dd = ld8(dp + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = mma(ld8(wp[i] + k0), dd, acc[i]);
+    }
+    if (rok) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const long long col = e * U0 + 128 * wave + 32 * nt + 4 * half;
+        bf16_t* xp = a.dg1 + rowm * a.lddg + col;
+        const bf16_t* gp = a.g1 + rowm * a.ldg + col;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v0 = acc[nt][4 * g], v1 = acc[nt][4 * g + 1], v2 = acc[nt][4 * g + 2], v3 = acc[nt][4 * g + 3];
+          if (a.gate_dx) {
+            union { uint2 u; bf16_t h[4]; } gv;
+            gv.u = *reinterpret_cast<const uint2*>(gp + 8 * g);
+            v0 = bf2f(gv.h[0]) > 0.f ? v0 : 0.f; v1 = bf2f(gv.h[1]) > 0.f ? v1 : 0.f;
+            v2 = bf2f(gv.h[2]) > 0.f ? v2 : 0.f; v3 = bf2f(gv.h[3]) > 0.f ? v3 : 0.f;
+          }
+          *reinterpret_cast<uint2*>(xp + 8 * g) = pack4(v0, v1, v2, v3);
+        }
+      }
+    }
+  }
+}
+
+// d gate logits: softmax backward per (row, task) over the experts' partials, experts ascending; one workgroup per row tile
+__global__ __launch_bounds__(256) void mmoe_dgate_finish_kernel(const MmoeArgs a) {
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * MR;
+  const int E = a.E, T = a.T;
+  if (tid < MR * T) {
+    const int m = tid / T, t = tid - m * T;
+    const long long row = r0 + m;
+    if (row < a.B) {
+      float gt[MAXG], dg[MAXG];
+      float dot = 0.f;
+      for (int q = 0; q < E; ++q) {
+        gt[q] = a.gates[((long long)t * a.B + row) * E + q];
+        dg[q] = a.dgs[row * MAXG + t * E + q];
+        dot += gt[q] * dg[q];
+      }
+      bf16_t* dl = a.dg1 + row * a.lddg + E * U0 + t * E;
+      for (int q = 0; q < E; ++q) dl[q] = f2bf(gt[q] * (dg[q] - dot));
+    }
+  }
+}
+
 int fill(MmoeArgs& a, const dmt_mmoe_desc* d, const char* who) {
   DMT_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
   DMT_CHECK_ARG(d->B > 0 && d->E > 0 && d->T > 0 && d->T <= 4 && d->T * d->E <= MAXG, "%s: bad dims (T <= 4, T*E <= 16)", who);
@@ -362,10 +635,23 @@ int fill(MmoeArgs& a, const dmt_mmoe_desc* d, const char* who) {
   a.b2 = d->b2; a.b2_es = d->b2_expert_stride;
   a.h1 = (bf16_t*)d->h1; a.h2 = (bf16_t*)d->h2; a.gates = d->gates; a.mix = (bf16_t*)d->mix;
   a.dmix = (const bf16_t*)d->dmix; a.dh1 = (bf16_t*)d->dh1; a.dh2 = (bf16_t*)d->dh2; a.dg1 = (bf16_t*)d->dg1; a.lddg = d->lddg;
+  a.n_tiles = (int)cdiv64(d->B, MR);
+  a.dgs = nullptr;
+  a.gate_dx = d->gate_dx ? 1 : 0;
+  if (d->ws != nullptr) {
+    DMT_CHECK_ARG(d->ws_bytes >= dmt_mmoe_experts_ws_bytes(d->B) && (((uintptr_t)d->ws) & 15) == 0, "%s: workspace too small (%lld < %lld bytes) or misaligned", who,
+                  (long long)d->ws_bytes, (long long)dmt_mmoe_experts_ws_bytes(d->B));
+    a.dgs = (float*)d->ws;
+  }
   return DMT_OK;
 }
 
 }  // namespace
+
+extern "C" int64_t dmt_mmoe_experts_ws_bytes(int32_t B) {
+  if (B <= 0) return 0;
+  return (int64_t)((size_t)B * MAXG * sizeof(float));
+}
 
 extern "C" int dmt_mmoe_experts_supported(int32_t u0, int32_t u1, int32_t u2, int32_t E, int32_t T) {
   return (u0 == U0 && u1 == U1 && u2 == U2 && E >= 1 && T >= 1 && T <= 4 && T * E <= MAXG) ? 1 : 0;
@@ -378,6 +664,13 @@ extern "C" int dmt_mmoe_experts_fwd(const dmt_mmoe_desc* d, void* stream) {
   DMT_CHECK_ARG(d->w1t_ld % 8 == 0 && d->w2t_ld % 8 == 0 && d->w1t_expert_stride % 8 == 0 && d->w2t_expert_stride % 8 == 0 &&
                 ((((uintptr_t)d->w1t) | ((uintptr_t)d->w2t)) & 15) == 0 && ((((uintptr_t)d->b1) | ((uintptr_t)d->b2)) & 15) == 0 &&
                 d->b1_expert_stride % 4 == 0 && d->b2_expert_stride % 4 == 0, "dmt_mmoe_experts_fwd: weight / bias rows must be 16-byte aligned");
+  if (a.dgs != nullptr) {
+    const unsigned nb = (unsigned)((a.n_tiles + 7) / 8 * 8 * a.E);
+    hipLaunchKernelGGL(mmoe_split_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mmoe_mix_finish_kernel, dim3((unsigned)a.n_tiles), dim3(256), 0, (hipStream_t)stream, a);
+    DMT_CHECK_LAUNCH("dmt_mmoe_experts_fwd(split)");
+    return DMT_OK;
+  }
   hipLaunchKernelGGL(mmoe_experts_fwd_kernel, dim3((unsigned)cdiv64(d->B, MR)), dim3(256), 0, (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_mmoe_experts_fwd");
   return DMT_OK;
@@ -389,6 +682,14 @@ extern "C" int dmt_mmoe_experts_bwd(const dmt_mmoe_desc* d, void* stream) {
   DMT_CHECK_ARG(d->w1 && d->w2 && d->dmix && d->dh1 && d->dh2 && d->dg1, "dmt_mmoe_experts_bwd: null argument");
   DMT_CHECK_ARG(d->lddg % 4 == 0 && (((uintptr_t)d->dg1) & 7) == 0 && d->w1_expert_stride % 8 == 0 && d->w2_expert_stride % 8 == 0 &&
                 ((((uintptr_t)d->w1) | ((uintptr_t)d->w2)) & 15) == 0, "dmt_mmoe_experts_bwd: rows must be aligned (weights 16 B, dg1 8 B)");
+  if (a.dgs != nullptr) {
+    const unsigned nb = (unsigned)((a.n_tiles + 7) / 8 * 8 * a.E);
+    hipLaunchKernelGGL(mmoe_split_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mmoe_dgate_finish_kernel, dim3((unsigned)a.n_tiles), dim3(256), 0, (hipStream_t)stream, a);
+    DMT_CHECK_LAUNCH("dmt_mmoe_experts_bwd(split)");
+    return DMT_OK;
+  }
+  DMT_CHECK_ARG(!a.gate_dx, "dmt_mmoe_experts_bwd: gate_dx needs the workspace form");
   hipLaunchKernelGGL(mmoe_experts_bwd_kernel, dim3((unsigned)cdiv64(d->B, MR)), dim3(256), 0, (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_mmoe_experts_bwd");
   return DMT_OK;

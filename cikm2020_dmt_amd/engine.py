@@ -595,15 +595,17 @@ class DMTEngine:
         K = self.plan.K
         zin = z if z.shape[1] == K else z[:, :K]      # inference() hands over the already split [B, K] view
         # (z is this engine's own zero-initialised buffer; its columns past K hold the bias tower's inputs: x_pad_finite)
+        fused = self.use_mmoe_fused and ops.mmoe_experts_supported(units, E, T, zin.dtype)
+        # (fused expert kernels: their backward hands d g1 over already times the relu gradient of this layer -- no pass of its own)
         g1 = ops.linear(zin, self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
-                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0], x_pad_finite=True)
+                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0], x_pad_finite=True, relu_grad_by_consumer=fused)
         # [B, E * u0]: the four experts' layer-0 outputs side by side | both gates' logits
-        if self.use_mmoe_fused and ops.mmoe_experts_supported(units, E, T, g1.dtype):
+        if fused:
             # fused expert-MLP + gate kernels: layers 1-2 of every expert, the gate softmaxes and the mixtures in one launch
             names = [["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)] for li in (1, 2)]
             mix, gates = ops.MmoeExpertsFn.apply(g1, [self._w(n + "weights") for n in names[0]], [self._w(n + "weights") for n in names[1]],
                                                  [self._lf(n + "weights") for n in names[0]], [self._lf(n + "biases") for n in names[0]],
-                                                 [self._lf(n + "weights") for n in names[1]], [self._lf(n + "biases") for n in names[1]], E, T)
+                                                 [self._lf(n + "weights") for n in names[1]], [self._lf(n + "biases") for n in names[1]], E, T, True)
             self.intermediates["gates"] = gates
             return mix if want_mix else list(ops.Unbind0Fn.apply(mix))
         expert, glogit = ops.split_cols(g1, 0, E * units[0], E * units[0], E * units[0] + T * E)

@@ -212,6 +212,17 @@ def _grad_view(leaf):
 WGRAD320_MIN_ROWS = 16384      # default row threshold of the "long-row" weight gradients (a StepState may carry its own)
 
 
+def _mmoe_workspace(state, Bn, dev):
+    """The split expert kernels' scratch buffer (the experts' d gate partials between the backward's two launches) of this engine."""
+    need = int(L.load().dmt_mmoe_experts_ws_bytes(int(Bn)))
+    key = (dev.type, dev.index)
+    ws = state.mmoe_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        state.mmoe_ws[key] = ws
+    return ws
+
+
 class StepState:
     """What ONE training step in flight keeps between its forward / backward and the point where the Trainer collects it: the long-row
     weight gradients backward only collected (deferred), the lane the MMoE / tower weight gradients fork to, the row threshold.  Every
@@ -219,13 +230,14 @@ class StepState:
     Trainers with different deferral needs in one process do not see each other's (round-3 review: these were module globals).  The
     autograd engine runs backward on its own thread: the active state is a module-level pointer, not a thread-local -- steps of
     different Trainers may alternate in one process, they may not run concurrently."""
-    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows")
+    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws")
 
     def __init__(self, wgrad320_min_rows=None):
         self.deferred = None          # list of closures while the step collects its long-row weight gradients
         self.deferred_limit = None    # only gradients that end before this element offset of the gradient arena may be collected
         self.fork = None              # dict(stream, off, n): B-row weight gradients at / behind `off` run on an idle lane
         self.wgrad320_min_rows = wgrad320_min_rows      # None: the module default above (tests lower it)
+        self.mmoe_ws = {}             # device -> workspace of the split expert kernels (_mmoe_workspace)
 
     def min_rows(self):
         return WGRAD320_MIN_ROWS if self.wgrad320_min_rows is None else self.wgrad320_min_rows
@@ -442,15 +454,16 @@ class LinearFn(torch.autograd.Function):
     """y = relu?(x W + b) (+ resid), the op behind base.dense_layer / tf.layers.dense call sites."""
 
     @staticmethod
-    def forward(ctx, x, w_leaf, b_leaf, w: Weight, act_ncols, out_dtype, x_pad_finite=False):
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, act_ncols, out_dtype, x_pad_finite=False, relu_grad_by_consumer=False):
         x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
         y = linear_forward(x2, w, b_leaf, act_ncols=act_ncols, out_dtype=out_dtype, x_pad_finite=x_pad_finite)
+        ctx.pre_gated = bool(relu_grad_by_consumer)      # the consumer's backward hands over d y already times (y > 0) on the relu columns
         ctx.w = w
         ctx.leaves = (w_leaf, b_leaf)
         ctx.act_ncols = act_ncols
         ctx.xshape = x.shape
         ctx.has_bias = b_leaf is not None
-        ctx.save_for_backward(x2, y if act_ncols > 0 else None)
+        ctx.save_for_backward(x2, y if (act_ncols > 0 and not relu_grad_by_consumer) else None)
         return y.reshape(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -459,7 +472,7 @@ class LinearFn(torch.autograd.Function):
         dz = dy.reshape(-1, dy.shape[-1])
         if dz.dtype != x2.dtype:
             dz = dz.to(x2.dtype)
-        if ctx.act_ncols > 0:
+        if ctx.act_ncols > 0 and not ctx.pre_gated:
             yy = y.to(dz.dtype) if y.dtype != dz.dtype else y
             dz = relu_bwd(dz, yy, ctx.act_ncols) if dz.data_ptr() == dy.data_ptr() else relu_bwd_(dz, yy, ctx.act_ncols)
         elif dz.stride(-1) != 1:
@@ -468,13 +481,13 @@ class LinearFn(torch.autograd.Function):
         dW, db = linear_backward_weight(x2, dz, want_bias=ctx.has_bias, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
         if dx is not None:
             dx = dx.reshape(ctx.xshape)
-        return dx, dW, db, None, None, None, None
+        return dx, dW, db, None, None, None, None, None
 
 
-def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=None, x_pad_finite=False):
+def linear(x, w_leaf, b_leaf, w: Weight, relu=False, act_ncols=None, out_dtype=None, x_pad_finite=False, relu_grad_by_consumer=False):
     n = w.f32.shape[1]
     a = (n if relu else 0) if act_ncols is None else act_ncols
-    return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype, x_pad_finite)
+    return LinearFn.apply(x, w_leaf, b_leaf, w, a, out_dtype, x_pad_finite, relu_grad_by_consumer)
 
 
 def _uniform_stride(ts):
@@ -1327,7 +1340,7 @@ class MmoeExpertsFn(torch.autograd.Function):
     g1 (dmt_mmoe_experts_bwd) + the two batched weight-gradient GEMMs.  expert_gate, mmoe_transformer_unbias.py:63-105."""
 
     @staticmethod
-    def forward(ctx, g1, ws1, ws2, wl1, bl1, wl2, bl2, E, T):
+    def forward(ctx, g1, ws1, ws2, wl1, bl1, wl2, bl2, E, T, gate_dx=False, split=True):
         Bn = g1.shape[0]
         u0, u1 = ws1[0].f32.shape
         u2 = ws2[0].f32.shape[1]
@@ -1350,6 +1363,12 @@ class MmoeExpertsFn(torch.autograd.Function):
         gates = torch.empty((T, Bn, E), dtype=F32, device=dev)
         mix = torch.empty((T, Bn, u2), dtype=BF16, device=dev)
         d.h1, d.h2, d.gates, d.mix = h1.data_ptr(), h2.data_ptr(), gates.data_ptr(), mix.data_ptr()
+        # one workgroup per (row tile, expert) -- a workspace of the engine's step state says so; gate_dx: the backward also applies the
+        # relu gradient of the layer that produced g1 (ops.linear(relu_grad_by_consumer=True)): needs the split form
+        ws = _mmoe_workspace(_state, Bn, dev) if (split or gate_dx) else None
+        d.ws, d.ws_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+        d.gate_dx = 1 if gate_dx else 0
+        ctx.ws = ws
         with _Timed("mmoe_experts", 2.0 * Bn * E * (u0 * u1 + u1 * u2)):
             L.call("dmt_mmoe_experts_fwd", C.byref(d), stream_ptr())
         ctx.desc = d
@@ -1385,7 +1404,7 @@ class MmoeExpertsFn(torch.autograd.Function):
             tiles = E * ((rows + 127) // 128) * ((N + 127) // 128)
             gemm(x, 1, ldx, dz, dz.stride(0), 1, rows, N, Bn, gws[0], gws[0].stride(0), ones_row=True, c_last=gbs[0], split_k=_pick_split(tiles, Bn),
                  accumulate=True, batch=E, a_bs=K, b_bs=N, c_bs=sg, clast_bs=sgb)
-        return dg1, None, None, None, None, None, None, None, None
+        return dg1, None, None, None, None, None, None, None, None, None, None
 
 
 def heads_supported(u_in, tower_units, bias_in, bias_units, T, dtype):

@@ -42,8 +42,9 @@ extern "C" {
  * revision it was written against before its first call -- cikm2020_dmt_amd/_lib.py does).
  *   1  rounds 1-2.   2  round 3: dmt_set/get_deterministic removed; dmt_colsum / dmt_colsum_drop (ordered), dmt_softmax_fwd / _bwd
  *   (causal) gained an int before `stream`; dmt_wgrad_desc grew (det_ws).   3  round 4: dmt_mhsa_block_fwd re-implemented (a new weight-image layout: images of revision 2 are not
- *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31). */
-#define DMT_ABI_VERSION 3
+ *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31).   4  round 4: dmt_mmoe_desc grew (ws, ws_bytes,
+ *   gate_dx); dmt_mmoe_experts_ws_bytes added. */
+#define DMT_ABI_VERSION 4
 const char* dmt_last_error(void);
 int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
@@ -600,7 +601,17 @@ typedef struct {
   const void* dmix;            /* [T, B, u2] bf16 (backward) */
   void* dh1; void* dh2;        /* [B, E*u1], [B, E*u2] bf16 (backward) */
   void* dg1; int64_t lddg;     /* [B, >= E*u0 + T*E] bf16 (backward) */
+  /* revision 4.  ws: NULL, or a scratch buffer of >= dmt_mmoe_experts_ws_bytes(B) bytes (no initialisation needed; holds the experts'
+   * d gate partials between the two launches of the backward): the E experts of a 32-row tile then run as E workgroups side by side
+   * and a second small launch sums the mixtures / finishes the gate-logit gradient in expert order -- bit-identical to the
+   * one-workgroup-per-tile form that ws == NULL selects.  One call at a time per buffer.
+   * gate_dx != 0 (backward, ws form only): the expert-input columns of dg1 are multiplied by (g1 > 0), i.e. the relu gradient of the
+   * layer that produced g1 is applied here instead of by a pass of its own. */
+  void* ws; int64_t ws_bytes;
+  int32_t gate_dx;
 } dmt_mmoe_desc;
+
+int64_t dmt_mmoe_experts_ws_bytes(int32_t B);
 
 int dmt_mmoe_experts_supported(int32_t u0, int32_t u1, int32_t u2, int32_t E, int32_t T);
 int dmt_mmoe_experts_fwd(const dmt_mmoe_desc* d, void* stream);

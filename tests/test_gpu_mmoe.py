@@ -69,3 +69,43 @@ def test_fused_expert_kernels_match_the_oracle(cuda):
     for a, b in zip(tasks, want):
         e = np.abs(a.float().cpu().numpy() - b).max() / (np.abs(b).max() + 1e-9)
         assert e < 3e-2, e
+
+
+@pytest.mark.parametrize("B", [1, 31, 33, 257, 4096])
+def test_split_expert_kernels_are_bit_identical_to_the_one_workgroup_form(cuda, B):
+    """One workgroup per (row tile, expert) + a small second launch that sums the mixtures / finishes the gate-logit gradient in expert
+    order (workspace form, round 4) against one workgroup per row tile walking its experts: same operations, same order -- every output
+    bit for bit; gate_dx is exactly a multiplication of the expert-input columns by (g1 > 0).  Route asserted."""
+    from cikm2020_dmt_amd import _lib as L
+    sp, st, eng = _engine(cuda, seed=11)
+    E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
+    g = torch.Generator(device="cpu").manual_seed(B + 5)
+    ncol = E * units[0] + T * E
+    g1v = (torch.randn((B, ncol), generator=g) * 0.7).to(torch.bfloat16).to(cuda)
+    g1v[:, : E * units[0]].clamp_(min=0)              # (relu'd layer-0 outputs: about half of them zero)
+    dmix = (torch.randn((T, B, units[-1]), generator=g) * 0.3).to(torch.bfloat16).to(cuda)
+    names = [["mmoe_layers/expert-%d/expert-layer-%d/" % (e, li) for e in range(E)] for li in (1, 2)]
+    args = ([eng._w(n + "weights") for n in names[0]], [eng._w(n + "weights") for n in names[1]],
+            [eng._lf(n + "weights") for n in names[0]], [eng._lf(n + "biases") for n in names[0]],
+            [eng._lf(n + "weights") for n in names[1]], [eng._lf(n + "biases") for n in names[1]], E, T)
+    out = {}
+    for key, gate_dx, split in (("one", False, False), ("split", False, True), ("split_gated", True, True)):
+        st.zero_grad()
+        x = g1v.clone().requires_grad_(True)
+        with L.route_trace() as rt:
+            mix, gates = ops.MmoeExpertsFn.apply(x, *args, gate_dx, split)
+            mix.backward(dmix)
+            torch.cuda.synchronize()
+        want = "(split)" if split else ""
+        assert rt.counts.get("dmt_mmoe_experts_fwd" + want, 0) == 1 and rt.counts.get("dmt_mmoe_experts_bwd" + want, 0) == 1, rt.counts
+        out[key] = (mix.detach().clone(), gates.clone(), x.grad.clone(), st.grads.clone())
+    for i, name in enumerate(("mix", "gates", "d g1")):
+        assert torch.equal(out["one"][i], out["split"][i]), name
+    # (the weight gradients are batched GEMMs over the saved d h1 / d h2 -- bit-identical operands; at large B they sum split-K pieces
+    #  with fp32 atomics, whose order is not reproducible from run to run)
+    ga, gb = out["one"][3], out["split"][3]
+    assert ((ga - gb).norm() / ga.norm()).item() < 1e-6
+    want = out["split"][2].clone()
+    want[:, : E * units[0]] *= (g1v[:, : E * units[0]] > 0).to(want.dtype)
+    assert torch.equal(out["split_gated"][2], want)
+    assert torch.equal(out["split_gated"][0], out["split"][0])
