@@ -230,7 +230,7 @@ class StepState:
     Trainers with different deferral needs in one process do not see each other's (round-3 review: these were module globals).  The
     autograd engine runs backward on its own thread: the active state is a module-level pointer, not a thread-local -- steps of
     different Trainers may alternate in one process, they may not run concurrently."""
-    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws")
+    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws", "unit_loss_grad")
 
     def __init__(self, wgrad320_min_rows=None):
         self.deferred = None          # list of closures while the step collects its long-row weight gradients
@@ -238,6 +238,7 @@ class StepState:
         self.fork = None              # dict(stream, off, n): B-row weight gradients at / behind `off` run on an idle lane
         self.wgrad320_min_rows = wgrad320_min_rows      # None: the module default above (tests lower it)
         self.mmoe_ws = {}             # device -> workspace of the split expert kernels (_mmoe_workspace)
+        self.unit_loss_grad = False   # Trainer.forward_backward: the loss's incoming gradient is exactly 1 (no scaling launch)
 
     def min_rows(self):
         return WGRAD320_MIN_ROWS if self.wgrad320_min_rows is None else self.wgrad320_min_rows
@@ -1510,7 +1511,7 @@ class LossUnbiasFn(torch.autograd.Function):
         s0, s1, s2, t0, t1, t2 = ctx.shapes
         if gloss is None:
             return (None,) * 9
-        g = dall * gloss
+        g = dall if _state.unit_loss_grad else dall * gloss
         return (g[0].reshape(s0).to(t0), g[1].reshape(s1).to(t1), g[2].reshape(s2).to(t2), None, None, None, None, None, None)
 
 

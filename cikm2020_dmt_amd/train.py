@@ -454,7 +454,16 @@ class Trainer:
                 fork_lane = pool[-1]
                 ops.begin_fork_wgrads(fork_lane, self.store.leaves["mmoe_layers/l0_cat_weights"].offset)
         try:
-            loss.backward()
+            # d loss / d loss = 1: a cached scalar instead of the ones_like() fill autograd would launch, and the loss kernel's saved
+            # logit gradients are handed on as they are (ops.StepState.unit_loss_grad) instead of through a `* 1` launch
+            one = getattr(self, "_unit_grad", None)
+            if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                one = self._unit_grad = torch.ones((), dtype=loss.dtype, device=loss.device)
+            self.engine.step_state.unit_loss_grad = True
+            try:
+                loss.backward(gradient=one)
+            finally:
+                self.engine.step_state.unit_loss_grad = False
         except BaseException:
             ops.reset_deferred_wgrads()
             self.engine._pending_sparse = None

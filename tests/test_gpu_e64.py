@@ -32,7 +32,7 @@ E64_ROWS = {"Sku": 2000, "Brand": 300, "Shopid": 300, "Cid3": 120, "Cid2": 50}
 # routes the E64 bf16 step must take (labels of DMT_CHECK_LAUNCH in csrc/)
 # (fused self-attention block on, the default; E64_ROUTES_UNFUSED: Trainer(fused_mhsa=False), the three-launch self-attention forward)
 E64_ROUTES = ("dmt_gather_fwd", "dmt_mhsa_block_fwd", "dmt_attn_bwd(mfma, coalesced)", "dmt_chain2", "dmt_wgrad320",
-              "dmt_q1mem_fwd", "dmt_q1mem_bwd", "dmt_mmoe_experts_fwd", "dmt_mmoe_experts_bwd", "dmt_heads_fwd", "dmt_heads_bwd",
+              "dmt_q1mem_fwd", "dmt_q1mem_bwd", "dmt_mmoe_experts_fwd(split)", "dmt_mmoe_experts_bwd(split)", "dmt_heads_fwd", "dmt_heads_bwd",
               "dmt_embgrad_reduce")
 E64_ROUTES_UNFUSED = tuple(r for r in E64_ROUTES if r != "dmt_mhsa_block_fwd") + ("dmt_proj", "dmt_attn_fwd(mfma, coalesced)")
 BF16_MAX_ULPS, BF16_TAIL_ULPS, BF16_TAIL_FRAC = 256.0, 16.0, 0.12
