@@ -12,7 +12,7 @@ FAMILIES = {
     "attn": ["attn_fwd_co_kernel", "attn_bwd_co_kernel", "attn_q1v_kernel"],
     "attn_long": ["attn_long_fwd", "attn_long_bwd", "attn_q1_long"],
     "q1mem": ["q1m_fwd_kernel", "q1m_bwd_kernel"],
-    "mmoe_experts": ["mmoe_experts_"],
+    "mmoe_experts": ["mmoe_experts_", "mmoe_split_", "mmoe_mix_finish", "mmoe_dgate_finish"],
     "heads": ["heads_fwd_kernel", "heads_bwd_kernel"],
     "gather_fwd": ["gather_group_kernel"],
     "embgrad_reduce": ["embgrad_reduce_kernel"],
