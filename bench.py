@@ -27,6 +27,9 @@ import numpy as np
 import torch
 
 
+# kernel families whose arithmetic is a few operations per byte moved: priced against the HBM roof, not the MFMA peak
+HBM_BOUND_FAMILIES = ("q1mem",)
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -36,6 +39,8 @@ def main():
     ap.add_argument("--dims", default="e64", choices=["e64", "ref"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--law", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--lengths", default="full", choices=["full", "ragged"], help="sequence lengths of the synthetic batches: full = every history at its "
+                    "maximum (the headline, roofline runs); ragged = len ~ U{1..L} per example and sequence (SURVEY.md section 8d variant (ii))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
     ap.add_argument("--long-seq", type=int, default=0, help="BASELINE long-seq variant: click / order histories of this length (e.g. 200) instead of 50")
@@ -117,7 +122,7 @@ def main():
     nb = max(2, args.fresh_batches)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:      # (numpy releases the GIL: ~0.15 s per batch on 8 threads)
-        raw = list(ex.map(lambda i: make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths="full", law=args.law, seq_lens=seq_lens), range(nb)))
+        raw = list(ex.map(lambda i: make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths=args.lengths, law=args.law, seq_lens=seq_lens), range(nb)))
     batches = [tr.make_batch(inputs, mask, label) for (inputs, mask, label) in raw]
     del raw
     age_info = age_tables(tr, sp, args, seq_lens) if args.age_tables > 0 else None
@@ -222,8 +227,15 @@ def main():
                                                    "the sequence lanes serialised (one kernel on the chip at a time)" % steps_x)
         else:
             n_m, t_m, fl_m, how = n_k, t_k, fl_k, "HIP events on the launch stream over the timed region"
-        fams.append({"key": key, "kernel": desc_, "bound": "mfma", "achieved": round(fl_m / t_m / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(fl_m / t_m / 1e12 / peak, 4), "traffic": None, "launches_per_step": round(n_k / max(steps_k, 1), 1),
+        alg_bytes = (sum(byts) / len(byts)) if byts else None
+        if key in HBM_BOUND_FAMILIES and alg_bytes:
+            # an HBM kernel (its rows are read once and written once; its arithmetic is a few dot2 per byte): priced against the HBM roof
+            gbs = alg_bytes * n_m / t_m / 1e9
+            head = {"key": key, "kernel": desc_, "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+        else:
+            head = {"key": key, "kernel": desc_, "bound": "mfma", "achieved": round(fl_m / t_m / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(fl_m / t_m / 1e12 / peak, 4)}
+        fams.append({**head, "traffic": None, "launches_per_step": round(n_k / max(steps_k, 1), 1),
                      "avg_launch_us": round(t_m / n_m * 1e6, 2), "measured": how,
                      "time_share": round((t_m / n_m) * (n_k / max(steps_k, 1)) / (dt / args.steps), 3),
                      "algorithmic_flop_per_launch": int(fl_k / n_k),
@@ -236,7 +248,7 @@ def main():
     # (the newest committed counter file whose kernel-source sha is this build's: profiles/rNN_traffic.json)
     import glob
     default_cfg = (args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and not args.shard_tables and not args.sku_rows
-                   and args.fresh_batches == 64 and args.age_tables == 100000)
+                   and args.fresh_batches == 64 and args.age_tables == 100000 and args.lengths == "full")
     tj, traffic_stale, tname = {}, None, None
     if default_cfg:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
@@ -280,9 +292,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=%s full%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s, "
+                               "per-GPU batch %d, L=%s %s%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s, "
                                "%d distinct resident batches, tables %s"
-                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10",
+                               % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", "full" if args.lengths == "full" else "ragged (len ~ U{1..L})",
                                   (" (flash-style attention kernels, %s MFMA forward%s)" % (args.attn_dtype, ": e4m3 attention DOES NOT MEET north_star's 1e-4 AUC bar (BASELINE.md section 5)" if args.attn_dtype == "fp8" else "")) if args.long_seq > 64 else "", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
@@ -303,6 +315,16 @@ def main():
     out["whole_step_note"] = ("mfma: %.3f TFLOP of algorithmic MFMA work per step; hbm: %s" % (
         flop_step / 1e12, ("%.2f GB of counter traffic per step (%s, every kernel from the first gather on)" % (tall_["hbm_bytes_per_step"] / 1e9, tname))
         if tall_ else "no counter file for this build (profiles/rNN_traffic.json is tied to the kernel sources' sha)"))
+    # wasted traffic as ONE number for the step: counter bytes over algorithmic bytes, over the families that carry both
+    both = [f for f in fams if f.get("traffic") and f.get("algorithmic_bytes_per_launch")]
+    if gather.get("traffic") and gather.get("bytes_per_launch"):
+        both = both + [{"key": "gather_fwd", "traffic": gather["traffic"], "algorithmic_bytes_per_launch": gather["bytes_per_launch"], "launches_per_step": ga_per_step}]
+    if both:
+        alg = sum(f["algorithmic_bytes_per_launch"] * f["launches_per_step"] for f in both)
+        cnt = sum(f["traffic"] * f["launches_per_step"] for f in both)
+        out["algorithmic_hbm_bytes_per_step"] = {"families": [f["key"] for f in both], "algorithmic": int(alg), "counter": int(cnt), "counter_over_algorithmic": round(cnt / alg, 3),
+                                                 "not_covered": "families without an algorithmic byte model (attention core, LayerNorm passes, embedding-gradient / Adam row kernels, MMoE / heads): "
+                                                                "%.2f GB of the step's counter bytes" % ((tall_["hbm_bytes_per_step"] - cnt) / 1e9) if tall_ else None}
     if args.record_files > 0 and world == 1 and not force_dp and not args.shard_tables and not args.long_seq and args.dims == "e64":
         try:
             out["input_inclusive"] = input_inclusive(tr, sp, args, out["ms_per_step"])

@@ -29,6 +29,11 @@ struct AttnArgs {
   float drop_inv;
   int drop_on;
   int vec16;   // bf16 MFMA path: every operand row is 16-byte aligned and dh % 8 == 0
+  // packed rows (include/dmt_hip.h, attn_bwd_co_kernel only): example b's rows at rows row_off[b] + t, it has k_lens[b] of them;
+  // ex_list: the n_list examples this launch covers
+  const int* row_off;
+  const int* ex_list;
+  int n_list;
 };
 
 __device__ __forceinline__ float drop_factor(const AttnArgs& a, int b, int h, int q, int key) {
@@ -975,19 +980,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // fetched -- and written back as a partial line -- twice (counters: 1.8 GB per launch against 0.92 GB algorithmic at B = 4096, T = 50).
   // Here the H heads of an example are H consecutive workgroups OF ONE XCD.
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const int b = (int)((slot / (unsigned)a.H) * 8u + xcd), h = (int)(slot % (unsigned)a.H);
-  if (b >= a.B) return;
-  const int Tq = a.Tq, Tk = a.Tk;
+  const int bi = (int)((slot / (unsigned)a.H) * 8u + xcd), h = (int)(slot % (unsigned)a.H);
+  if (bi >= (a.ex_list ? a.n_list : a.B)) return;
+  const int b = a.ex_list ? a.ex_list[bi] : bi;
+  // packed rows: the example has k_lens[b] rows, queries and keys alike (rows past them do not exist: in the dense layout they are
+  // masked keys -- softmax weight exactly 0 -- and queries whose output gradient is zero, so both layouts give the same dQ / dK / dV on
+  // the rows that exist); a.Tq / a.Tk stay the dense lengths for the dropout index
+  int Tq = a.Tq, Tk = a.Tk;
+  long long bq = (long long)b * a.q_bs, bk = (long long)b * a.k_bs, bv = (long long)b * a.v_bs, bdo = (long long)b * a.do_bs;
+  long long bdq = (long long)b * a.dq_bs, bdk = (long long)b * a.dk_bs, bdv = (long long)b * a.dv_bs;
+  if (a.row_off) {
+    int n = a.k_lens[b];
+    n = n < 1 ? 1 : (n > a.Tk ? a.Tk : n);
+    Tq = n; Tk = n;
+    const long long r0 = a.row_off[b];
+    bq = r0 * a.q_rs; bk = r0 * a.k_rs; bv = r0 * a.v_rs; bdo = r0 * a.do_rs; bdq = r0 * a.dq_rs; bdk = r0 * a.dk_rs; bdv = r0 * a.dv_rs;
+  }
   const int half = lane >> 5, l31 = lane & 31;
   bf16_t* X = reinterpret_cast<bf16_t*>(smem);
   bf16_t* PD = X + CB::X_BYTES / 2;                // P, then dS, as [q][key]
   bf16_t* ST = PD + CB::PD_BYTES / 2;              // output staging
   bf16_t* Y = X + CB::Y_OFFSET / 2;                // raw dO tile during phase A
 
-  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + (long long)b * a.q_bs + h * DH;
-  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + (long long)b * a.k_bs + h * DH;
-  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + (long long)b * a.v_bs + h * DH;
-  const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + (long long)b * a.do_bs + h * DH;
+  const bf16_t* Qg = reinterpret_cast<const bf16_t*>(a.Q) + bq + h * DH;
+  const bf16_t* Kg = reinterpret_cast<const bf16_t*>(a.K) + bk + h * DH;
+  const bf16_t* Vg = reinterpret_cast<const bf16_t*>(a.V) + bv + h * DH;
+  const bf16_t* dOg = reinterpret_cast<const bf16_t*>(a.dout) + bdo + h * DH;
 
   // all four operand tiles are requested up front: ONE exposed global round trip instead of four
   uint4 g0[CoMap<DH>::NI], g1[CoMap<DH>::NI];
@@ -1154,9 +1172,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   };
 
   // ---- dQ^T = K^T dS^T
-  bf16_t* dQg = reinterpret_cast<bf16_t*>(a.dQ) + (long long)b * a.dq_bs + h * DH;
-  bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + (long long)b * a.dk_bs + h * DH;
-  bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + (long long)b * a.dv_bs + h * DH;
+  bf16_t* dQg = reinterpret_cast<bf16_t*>(a.dQ) + bdq + h * DH;
+  bf16_t* dKg = reinterpret_cast<bf16_t*>(a.dK) + bdk + h * DH;
+  bf16_t* dVg = reinterpret_cast<bf16_t*>(a.dV) + bdv + h * DH;
   co_store<DH>(g0, X, RS, lane);
   co_load<DH>(g1, dOg, a.do_rs, Tq, lane);         // for phase C, in flight during phase B
   __builtin_amdgcn_wave_barrier();
@@ -1584,6 +1602,7 @@ int fill_args(AttnArgs& a, const dmt_attn_desc* d) {
   a.dout = nullptr; a.dQ = a.dK = a.dV = nullptr;
   a.vec16 = 0;
   a.do_bs = a.do_rs = a.dq_bs = a.dq_rs = a.dk_bs = a.dk_rs = a.dv_bs = a.dv_rs = 0;
+  a.row_off = nullptr; a.ex_list = nullptr; a.n_list = 0;      // (packed rows: set by dmt_attn_bwd on the one route that takes them)
   return 0;
 }
 
@@ -1702,6 +1721,11 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
   int rc = check_desc(&d->f, "dmt_attn_bwd");
   if (rc != DMT_OK) return rc;
   DMT_CHECK_ARG(d->dout && d->dQ && d->dK && d->dV, "dmt_attn_bwd: null gradient buffer");
+  const bool packed = d->f.row_off != nullptr || d->f.ex_list != nullptr;
+  if (packed) {
+    DMT_CHECK_ARG(d->f.dtype == DMT_BF16 && d->f.Tq == d->f.Tk && d->f.Tq > 1 && d->f.k_lens != nullptr && (d->f.ex_list == nullptr || d->f.n_list > 0),
+                  "dmt_attn_bwd: packed rows / example lists are taken by the bf16 self-attention form only (Tq == Tk > 1, k_lens given)");
+  }
   AttnArgs a;
   fill_args(a, &d->f);
   a.dout = d->dout; a.do_bs = d->do_bs; a.do_rs = d->do_rs;
@@ -1744,9 +1768,12 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
       const unsigned nbm = (unsigned)((long long)f.B * f.H);
       if (a.vec16 && f.dh % 16 == 0 && q1v_aligned(d->dQ, d->dq_bs, d->dq_rs) && q1v_aligned(d->dK, d->dk_bs, d->dk_rs) &&
           q1v_aligned(d->dV, d->dv_bs, d->dv_rs)) {
-        const int ntq = f.Tq <= 32 ? 1 : 2, ntk = f.Tk <= 32 ? 1 : 2;
+        a.row_off = f.row_off; a.ex_list = f.ex_list; a.n_list = f.n_list;
+        const int tmax = (packed && f.max_len > 0 && f.max_len < f.Tq) ? f.max_len : f.Tq;
+        const int ntq = tmax <= 32 ? 1 : 2, ntk = (packed ? tmax : f.Tk) <= 32 ? 1 : 2;
+        const long long n_ex = f.ex_list ? f.n_list : f.B;
 #define DMT_BWD_CO(DHV) do { const size_t lb = (size_t)CoBwd<DHV>::BYTES; \
-    const unsigned nbx = (unsigned)(((long long)f.B + 7) / 8 * 8 * f.H);       /* (examples in groups of 8: one per XCD) */ \
+    const unsigned nbx = (unsigned)((n_ex + 7) / 8 * 8 * f.H);       /* (examples in groups of 8: one per XCD) */ \
     if (ntq == 1 && ntk == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 1>), dim3(nbx), dim3(64), lb, st, a); \
     else if (ntq == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 2>), dim3(nbx), dim3(64), lb, st, a); \
     else hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 2, 2>), dim3(nbx), dim3(64), lb, st, a); } while (0)
@@ -1760,6 +1787,7 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
         DMT_CHECK_LAUNCH("dmt_attn_bwd(mfma, coalesced)");
         return DMT_OK;
       }
+      DMT_CHECK_ARG(!packed, "dmt_attn_bwd: packed rows need 16-byte aligned rows and dh %% 16 == 0 (the coalesced MFMA kernel)");
       switch (f.dh) {
         case 16: hipLaunchKernelGGL((attn_bwd_mfma_kernel<16>), dim3(nbm), dim3(64), ldsm, st, a); break;
         case 20: hipLaunchKernelGGL((attn_bwd_mfma_kernel<20>), dim3(nbm), dim3(64), ldsm, st, a); break;
@@ -1771,6 +1799,7 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
       return DMT_OK;
     }
   }
+  DMT_CHECK_ARG(!packed, "dmt_attn_bwd: packed rows are taken by the coalesced MFMA kernel only (bf16, dh in 16/32/64/80, 16-byte aligned rows, T >= 8)");
   int r = (d->f.dtype == DMT_F32) ? launch_bwd<float>(a, nw, lds, st) : launch_bwd<bf16_t>(a, nw, lds, st);
   if (r != 0) { dmt_set_error("dmt_attn_bwd: head dim %d not instantiated (4,8,16,20,32,64,80)", d->f.dh); return DMT_ERR_UNSUPPORTED; }
   DMT_CHECK_LAUNCH("dmt_attn_bwd");

@@ -36,8 +36,10 @@ struct GFeat {
 struct GGroup {
   int B, nfeat;
   GFeat f[MAX_GF];
-  void* seq_out;    // [B, seq_T, d_model] (or tar_out with seq_T == 1)
+  void* seq_out;    // [B, seq_T, d_model] (or tar_out with seq_T == 1); packed rows: [R, d_model]
   int seq_T;
+  const int* row_off;   // packed rows (include/dmt_hip.h): example b's rows t < row_len[b] at rows row_off[b] + t; null: dense
+  const int* row_len;
   const float* pos;
   int d_model;
   float scale;
@@ -150,9 +152,12 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
 
   // ---- sequence rows: out[b,t,:] = scale * [0;E][idx] + pos[t]
   if (g.seq_out) {
-    OutT* out = reinterpret_cast<OutT*>(g.seq_out) + (long long)b * g.seq_T * g.d_model;
+    // packed rows: only the rows that exist are produced, at their packed position (the dropout index below stays the dense one)
+    int n_t = g.seq_T;
+    if (g.row_off) { n_t = g.row_len[b]; n_t = n_t < 0 ? 0 : (n_t > g.seq_T ? g.seq_T : n_t); }
+    OutT* out = reinterpret_cast<OutT*>(g.seq_out) + (g.row_off ? (long long)g.row_off[b] : (long long)b * g.seq_T) * g.d_model;
     const int nch = g.d_model / VEC;
-    const int items = g.seq_T * nch;
+    const int items = n_t * nch;
     // U items per thread and pass, all table / position requests issued BRANCH-FREE before the first use (a predicated load
     // is waited for before the next one goes out: one memory latency per item instead of one per pass).  Padding ids (0 ->
     // the all-zero row of [0;E]) and items past the end read a valid row and are masked afterwards.
@@ -427,8 +432,16 @@ __global__ __launch_bounds__(256) void embgrad_reduce_kernel(const dmt_embgrad_d
         if (fsid == DMT_SEQ_TARGET)
           my_src = reinterpret_cast<const GT_*>(d.dtar) + (long long)b * d.d_model + fso;
         else {
-          const long long flat = ((long long)b * d.seq_T[fsid] + t) * d.d_model + fso;
-          my_src = reinterpret_cast<const GT_*>(d.dseq[fsid]) + flat;
+          const long long flat = ((long long)b * d.seq_T[fsid] + t) * d.d_model + fso;      // dense element index (dropout counter)
+          const int* ro = d.seq_row_off[fsid];
+          if (ro != nullptr) {
+            // packed rows: the gradient row of (b, t) is row ro[b] + t; a position past the example's rows carries nothing
+            const bool there = t < d.seq_row_len[fsid][b];
+            my_src = reinterpret_cast<const GT_*>(d.dseq[fsid]) + (there ? ((long long)ro[b] + t) * d.d_model + fso : (long long)fso);
+            if (!there) my_scale = 0.f;
+          } else {
+            my_src = reinterpret_cast<const GT_*>(d.dseq[fsid]) + flat;
+          }
           if (drop_on) { my_dim |= 1 << 16; my_dseed = d.seq_drop_seed[fsid]; my_flat = (uint32_t)flat; my_scale *= drop_inv; }
         }
       }
@@ -672,6 +685,7 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
     g.seq_out = nullptr;
     g.drop_seed = 0; g.drop_thr = 0; g.drop_inv = 0.f;
     g.seq_T = 0;
+    g.row_off = nullptr; g.row_len = nullptr;
     g.pos = nullptr;
     g.d_model = d->d_model > 0 ? d->d_model : 4;
     g.scale = d->seq_scale;
@@ -712,6 +726,8 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
     } else if (seq_id >= 0) {
       DMT_CHECK_ARG(seq_id < d->n_seq && d->seq_out[seq_id] != nullptr, "dmt_gather_fwd: seq_out[%d] missing", seq_id);
       g.seq_out = d->seq_out[seq_id]; g.seq_T = d->seq_T[seq_id]; g.pos = d->pos[seq_id];
+      DMT_CHECK_ARG((d->seq_row_off[seq_id] == nullptr) == (d->seq_row_len[seq_id] == nullptr), "dmt_gather_fwd: seq_row_off[%d] and seq_row_len[%d] go together", seq_id, seq_id);
+      g.row_off = d->seq_row_off[seq_id]; g.row_len = d->seq_row_len[seq_id];
       if (d->seq_drop_keep > 0.f && d->seq_drop_keep < 1.f) {
         g.drop_seed = d->seq_drop_seed[seq_id];
         g.drop_thr = (uint32_t)(d->seq_drop_keep * 16777216.0f);

@@ -6,26 +6,28 @@
 // scaled_dot_product_attention :11-56, mask :80-108 (key mask before the softmax, query mask after it, both -2^32 + 1), dropout on
 // the attention weights :51 and ln :58-78.  There is no output projection in the reference.
 //
-// Round-4 form (the round-2 kernel ran one 8-wavefront workgroup per CU whose phases -- projection, attention, qkv copy, LayerNorm
-// pass -- followed each other with nothing to hide them; its ablation is in DESIGN.md section 3).  Now:
-//   * a workgroup = 4 compute wavefronts (32 rows each: 128 rows = 128 / Tp examples, every example padded to Tp in {16, 32, 64} rows)
-//     + ONE LOADER wavefront that owns the weight stream (its vmcnt counts DMA pieces only, dmt_chain.hip:proj_kernel); 80 KB of LDS
-//     and <= 168 registers, so TWO workgroups share a CU and one's attention runs beside the other's projection;
-//   * per head h a compute wavefront multiplies ITS 32 input rows (20 MFMA fragments, reloaded per head so that they are dead during
-//     the attention) with the 240 columns (Q_h | K_h | V_h) of the packed projection -- eight 32-column tiles of a prebuilt weight
-//     image, each streamed through a 3-slot LDS ring in two k halves (10.5 KB stages).  Q_h / K_h tiles are computed transposed (lane
-//     = row), V_h tiles untransposed (lane = column), so that
+// The kernel that ships (MCfg<8, 5>, the one shape built; how it got there: DESIGN.md section 3d):
+//   * a workgroup = 8 wavefronts of 32 rows each = 256 rows = 256 / Tp examples, every example padded to Tp in {16, 32, 64} rows; ONE
+//     workgroup per CU (149 KB of LDS, <= 256 registers), persistent over the row tiles.  There is no loader wavefront: every
+//     wavefront computes AND issues its two pieces of every stage of the weight stream (an LDS-DMA instruction holds its wavefront ~230
+//     cycles, so the pieces are spread over all eight), a ring of five 10.5 KB stage slots in LDS;
+//   * per head h a wavefront multiplies ITS 32 input rows (20 MFMA fragments, loaded once per row tile and resident for the four
+//     heads and their residual adds; the next tile's rows are requested before the LayerNorm pass) with the 240 columns
+//     (V_h | K_h | Q_h, head-major order, + 16 zero columns) of the packed projection -- eight 32-column tiles of a prebuilt weight image,
+//     each streamed in two k halves.  Every tile is computed transposed (lane = row), so that
 //       - Q_h stays in REGISTERS: the packed accumulators ARE the B fragments of S^T = K Q^T (k order of a 16-chunk: 0-3, 8-11 | 4-7,
 //         12-15 -- the order the 32x32 accumulator hands out; the K rows in LDS are written in the same order, a reduction does not
 //         care as long as both operands agree),
-//       - K_h goes to LDS as [key][5 chunks x (lower-lane 16 B | upper-lane 16 B)] and V_h as V^T [80][keys in the same chunk order]:
-//         one ds_write_b128 per chunk, read back by ds_read_b128 as MFMA A fragments,
-//       - the (Q | K | V) side output for the backward pass leaves straight from the accumulators (16-byte pieces for Q / K rows,
-//         2-byte pieces in 64-byte runs for the V columns);
+//       - K_h goes to LDS as [key][5 chunks x (lower-lane 16 B | upper-lane 16 B)] (one ds_write_b128 per chunk, read back by
+//         ds_read_b128 as MFMA A fragments) and V_h row-major [key][80] (ds_write_b64), read back TRANSPOSED by ds_read_b64_tr_b16 as
+//         the A fragments of O^T = V^T P^T,
+//       - the (Q | K | V) side output for the backward pass leaves straight from the accumulators in 16-byte pieces of the rows;
 //   * attention of the wavefront's 32 queries: a lane owns one query, the softmax is an in-lane reduction plus one exchange with
-//     lane + 32; P feeds O^T = V^T P^T from the accumulators; s = O + x is stored per head, its row sums kept;
+//     lane + 32; P feeds O^T = V^T P^T from the accumulators; s = O + x is stored per head and its row sums kept (shifted by the row's
+//     first input element: no cancellation in the variance);
 //   * after the four heads the rows' mean / variance are known: the wavefront re-reads its own s pieces (L2) and writes y = LN(s).
-// qkv never travels back from memory, the scores never leave registers, LayerNorm is not a separate launch.
+// qkv never travels back from memory, the scores never leave registers, LayerNorm is not a separate launch.  Every global access is a
+// buffer access with a 32-bit offset (rows that do not exist: out-of-range offsets, zeros on load, dropped on store).
 #include "dmt_common.h"
 #include <utility>
 #include <stdlib.h>
@@ -124,6 +126,8 @@ struct MhsaArgs {
   bf16_t* y_out;            // [B*T, 320]
   float* stats;             // [B*T, 2] or null
   int B, T, Tp, lgTp, tiles;
+  const int* blocks;        // packed rows (include/dmt_hip.h): [tiles][8 blocks][2] x (example, length, first packed row, log2 Tp); null: dense
+  long long n_rows;         // rows of x / s / y / qkv / stats (B * T when dense)
   unsigned drop_seed, drop_thr;   // thr = keep * 2^24, 0: dropout off
   float drop_inv_keep;
   int dbg;   // timing experiments only (make EXPERIMENTS=1, DMT_MHSA_DEBUG): 1 no qkv side stores, 2 no attention, 4 no projection MFMAs,
@@ -169,6 +173,10 @@ __device__ __forceinline__ void mh_swap(unsigned& a, unsigned& b) {   // lanes 3
 
 typedef MCfg<8, 5> C;      // the one shape built: 8 wavefronts = 256 rows per workgroup, ring of 5 stage slots (149 KB of LDS)
 
+// PK: packed rows.  The examples of a tile are described by the caller's block table (one 16-byte entry per half block: example, its
+// length, its first packed row, log2 of the tile's padded length); the dense instantiation computes all of that from (tile, B, T) as
+// before and compiles to the code it was.  A packed example HAS `length` rows: keys past them do not exist (dense: masked, weight 0).
+template <bool PK>
 __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   constexpr int MH_NT = C::NT, MH_NS = C::NS, MH_K_OFF = C::K_OFF, MH_V_OFF = C::V_OFF, MH_BIAS_OFF = C::BIAS_OFF;
   constexpr int NCW = C::NCW, ROWS = C::ROWS;
@@ -212,15 +220,16 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   // lane).  No 64-bit address pairs (they were what the register allocator spilled, and a reload from scratch waits -- vmcnt is in
   // order -- behind every side-output store issued before it), and a row that does not exist is an offset past the end: its load
   // returns zeros, its store is dropped, without a branch.
-  const long long nrow = (long long)g.B * g.T;
+  const long long nrow = PK ? g.n_rows : (long long)g.B * g.T;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.x), 0, (int)(nrow * MH_D * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rqkv = __builtin_amdgcn_make_buffer_rsrc(g.qkv, 0, g.qkv ? (int)(unsigned)(nrow * 960 * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.s_out, 0, (int)(nrow * MH_D * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(g.y_out, 0, (int)(nrow * MH_D * 2), 0x00020000);
   constexpr unsigned OOB = 0x80000000u;              // a byte offset past the end of every tensor here (and far from wrapping around)
   const unsigned a_lane = lds0 + ml * MH_WSTRIDE + 16 * hi_;         // weight fragment (A operand): row ml of the tile, chunk c at + 32 c
-  const int Tp = g.Tp, T = g.T, lg = g.lgTp;
-  const int epw = ROWS >> lg;                        // examples per workgroup
+  int Tp = g.Tp, lg = g.lgTp;                        // (packed rows: per tile, from the block table)
+  const int T = g.T;
+  const int epw = ROWS >> lg;                        // examples per workgroup (dense)
   const float scale = 0.11180339887498948f;          // 1 / sqrt(80)
   int gs = 0;                                        // stages consumed so far by this workgroup
 
@@ -229,6 +238,22 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   // is a value spilled, and a reload from scratch waits (vmcnt is in order) behind every side-output store issued before it.
   // Global rows are 32-bit: every address is (uniform base) + (32-bit offset).
   struct RowInfo { int t_pos, ex; bool rvalid; unsigned grow, growc, row640; };
+  struct TileInfo { int ex, len, off, lg; };         // packed rows: this lane's example in the tile (kept in registers for the tile)
+  auto load_info = [&](int tl) -> TileInfo {
+    const int4 v = *reinterpret_cast<const int4*>(g.blocks + (((long long)tl * NCW + rb) * 2 + ((lane & 31) >> 4)) * 4);
+    return TileInfo{v.x, v.y, v.z, v.w};
+  };
+  auto rowinfo_pk = [&](const TileInfo& ti) -> RowInfo {
+    const int r_loc = 32 * rb + (mh_here(lane) & 31);
+    RowInfo r;
+    r.t_pos = r_loc & ((1 << ti.lg) - 1);
+    r.ex = ti.ex;
+    r.rvalid = (ti.ex >= 0) && (r.t_pos < ti.len);
+    r.grow = (unsigned)ti.off + (unsigned)r.t_pos;
+    r.growc = r.rvalid ? r.grow : 0u;
+    r.row640 = r.rvalid ? r.grow * (unsigned)(MH_D * 2) : OOB;
+    return r;
+  };
   auto rowinfo_t = [&](int tl) -> RowInfo {
     const int r_loc = 32 * rb + (mh_here(lane) & 31);
     RowInfo r;
@@ -243,8 +268,10 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   // the raw input rows of a tile: requested one tile ahead (before the LayerNorm pass of the tile in flight, whose latency they share)
   // (ONE set of 80 registers: the raw rows land in the fragment registers and are swapped into fragment order in place)
   bf16x8_t X[MH_KC];
+  TileInfo tnext = TileInfo{-1, 0, 0, 6};            // packed rows: the block entry of the tile whose rows were requested last
   auto request_x = [&](int tl) {
-    const RowInfo ri = rowinfo_t(tl);
+    if constexpr (PK) tnext = load_info(tl);         // (a dependent round trip in front of the row requests: once per tile)
+    const RowInfo ri = PK ? rowinfo_pk(tnext) : rowinfo_t(tl);
     const unsigned xo = ri.row640 + 16u * (unsigned)hi_;
 #pragma unroll
     for (int c = 0; c < MH_KC; ++c) X[c] = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
@@ -256,9 +283,12 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
   request_x((int)blockIdx.x);
 
   for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
-    auto rowinfo = [&]() -> RowInfo { return rowinfo_t(tile); };
+    const TileInfo tcur = tnext;                     // (packed rows: request_x of this tile left it there)
+    if constexpr (PK) { lg = __builtin_amdgcn_readfirstlane(tcur.lg); Tp = 1 << lg; }
+    auto rowinfo = [&]() -> RowInfo { if constexpr (PK) return rowinfo_pk(tcur); else return rowinfo_t(tile); };
     int len;
-    { const RowInfo ri = rowinfo(); len = (ri.ex < g.B) ? g.lens[ri.ex] : 0; }
+    if constexpr (PK) len = tcur.ex >= 0 ? tcur.len : 0;
+    else { const RowInfo ri = rowinfo(); len = (ri.ex < g.B) ? g.lens[ri.ex] : 0; }
     float rsum = 0.f, rsq = 0.f;                               // row statistics of s
 
     // ---- the wavefront's 32 input rows as MFMA fragments (k permuted: lower lane 0-3 | 8-11, upper 4-7 | 12-15 of every 16-chunk),
@@ -273,6 +303,10 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
       mh_swap(a1, a3);
       X[c] = __builtin_bit_cast(bf16x8_t, u32x4_t{a0, a1, a2, a3});
     }
+    // shift of the row statistics: the row's own first input element (lane hi = 0 holds it; both lanes of a row use the same value).
+    // sum (s - c) and sum (s - c)^2 lose nothing to cancellation when a row's mean is far larger than its spread -- the plain
+    // E[s^2] - mean^2 form does, and with eps = 1e-8 its clamp at zero would then hand the LayerNorm gradient an rstd of 1e4
+    const float cshift = __shfl(__uint_as_float(__builtin_bit_cast(u32x4_t, X[0])[0] << 16), lane & 31, 64);
 
 #pragma unroll 1
     for (int h = 0; h < MH_H; ++h) {
@@ -383,10 +417,11 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
         const RowInfo ri = rowinfo();
         const bool rvalid = ri.rvalid;
         const bool q_live = rvalid && (ri.t_pos < len);
-        int Tm = T - 4 * hi, Lm = len - 4 * hi;            // key < T  <=>  const(r) < Tm
+        const int Tx = PK ? len : T;                       // keys that EXIST (packed rows: the example's own rows, nothing past them)
+        int Tm = Tx - 4 * hi, Lm = len - 4 * hi;           // key < Tx  <=>  const(r) < Tm
         const int ehalf = (mh_here(lane) & 31) >> 4;       // (Tp = 16) which example of the 32-row window this query belongs to
         auto kexists = [&](int cr, int tm) -> bool {
-          if constexpr (TPK == 16) return (((cr + 4 * hi) >> 4) == ehalf) && (((cr + 4 * hi) & 15) < T);
+          if constexpr (TPK == 16) return (((cr + 4 * hi) >> 4) == ehalf) && (((cr + 4 * hi) & 15) < Tx);
           else return cr < tm;
         };
         auto kvalid_f = [&](int cr, int lm) -> bool {
@@ -509,8 +544,9 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
             for (int z = 0; z < 2; ++z) {
               const float f0 = __uint_as_float(a[z] << 16), f1 = __uint_as_float(a[z] & 0xFFFF0000u);
               const float f2 = __uint_as_float(b[z] << 16), f3 = __uint_as_float(b[z] & 0xFFFF0000u);
-              rsum += (f0 + f1) + (f2 + f3);
-              rsq += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+              const float e0 = f0 - cshift, e1 = f1 - cshift, e2 = f2 - cshift, e3 = f3 - cshift;
+              rsum += (e0 + e1) + (e2 + e3);
+              rsq += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
             }
             mh_swap(a[0], b[0]); mh_swap(a[1], b[1]);
             if (!(dbg & 32)) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{a[0], a[1], b[0], b[1]}, rs, sro + 32u * pr, 0, 0);
@@ -531,8 +567,9 @@ __global__ __launch_bounds__(C::NT, 2) void mhsa_fwd_kernel(const MhsaArgs g) {
     {
       rsum += __shfl_xor(rsum, 32, 64);
       rsq += __shfl_xor(rsq, 32, 64);
-      const float mean = rsum / (float)MH_D;
-      float var = rsq / (float)MH_D - mean * mean;
+      const float dmean = rsum / (float)MH_D;                  // mean - cshift
+      const float mean = dmean + cshift;
+      float var = rsq / (float)MH_D - dmean * dmean;
       var = var > 0.f ? var : 0.f;
       const float rstd = 1.f / sqrtf(var + g.eps);
       const RowInfo ri = rowinfo();
@@ -588,7 +625,10 @@ extern "C" int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream) {
   DMT_CHECK_ARG(d->x && d->lens && d->image && d->bias && d->gamma && d->beta && d->y_out, "dmt_mhsa_block_fwd: null pointer");
   DMT_CHECK_ARG((((uintptr_t)d->x | (uintptr_t)d->s_out | (uintptr_t)d->y_out | (uintptr_t)d->qkv) & 15) == 0, "dmt_mhsa_block_fwd: tensors must be 16-byte aligned");
   DMT_CHECK_ARG((long long)d->B * d->T * d->num_heads * d->T < (1ll << 32), "dmt_mhsa_block_fwd: dropout counter range");
-  DMT_CHECK_ARG((long long)d->B * d->T * 1920 < 0x7FFF0000ll, "dmt_mhsa_block_fwd: 32-bit byte offsets (B * T * 1920 < 2^31)");
+  const bool packed = d->blocks != nullptr;
+  DMT_CHECK_ARG(!packed || (d->n_tiles > 0 && d->n_rows > 0 && d->n_rows <= (long long)d->B * d->T && (((uintptr_t)d->blocks) & 15) == 0),
+                "dmt_mhsa_block_fwd: packed rows need n_tiles > 0, 0 < n_rows <= B * T and a 16-byte aligned block table");
+  DMT_CHECK_ARG((packed ? (long long)d->n_rows : (long long)d->B * d->T) * 1920 < 0x7FFF0000ll, "dmt_mhsa_block_fwd: 32-bit byte offsets (rows * 1920 < 2^31)");
   MhsaArgs a;
   a.x = (const bf16_t*)d->x; a.lens = d->lens; a.image = (const unsigned char*)d->image;
   a.bias = d->bias; a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
@@ -609,9 +649,16 @@ extern "C" int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream) {
 #endif
   (void)shape;
   const int epw = C::ROWS / a.Tp;
-  a.tiles = (d->B + epw - 1) / epw;
+  a.tiles = packed ? d->n_tiles : (d->B + epw - 1) / epw;
+  a.blocks = d->blocks;
+  a.n_rows = packed ? d->n_rows : (long long)d->B * d->T;
   const int grid = a.tiles < 256 ? a.tiles : 256;     // one workgroup per CU, persistent over the row tiles
-  hipLaunchKernelGGL(mhsa_fwd_kernel, dim3(grid), dim3(C::NT), 0, (hipStream_t)stream, a);
+  if (packed) {
+    hipLaunchKernelGGL(mhsa_fwd_kernel<true>, dim3(grid), dim3(C::NT), 0, (hipStream_t)stream, a);
+    DMT_CHECK_LAUNCH("dmt_mhsa_block_fwd(packed)");
+    return DMT_OK;
+  }
+  hipLaunchKernelGGL(mhsa_fwd_kernel<false>, dim3(grid), dim3(C::NT), 0, (hipStream_t)stream, a);
   DMT_CHECK_LAUNCH("dmt_mhsa_block_fwd");
   return DMT_OK;
 }

@@ -45,6 +45,7 @@ struct Q1mArgs {
   int dh;
   bf16_t* dqp;                         // [B][H][D]
   bf16_t* dmem; long long dm_bs, dm_rs;
+  const int* row_off;                  // packed rows (include/dmt_hip.h): example b's memory rows at rows row_off[b] + k, k < k_lens[b]; null: dense
 };
 
 __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
@@ -161,12 +162,15 @@ __device__ __forceinline__ void stage_rows(bf16_t* __restrict__ s_mem, const bf1
 __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x, T = a.T, H = a.H;
-  const Q1mLds L = q1m_carve(smem, T, H, false);
-  const int MR = q1m_mem_rows(T), TP = q1m_tp(T);
-  const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
-  int klen = a.k_lens ? a.k_lens[b] : T;
-  klen = klen < 0 ? 0 : (klen > T ? T : klen);
+  const int b = blockIdx.x, Td = a.T, H = a.H;       // Td: the dense length (LDS carve-up, dropout index)
+  const Q1mLds L = q1m_carve(smem, Td, H, false);
+  const int MR = q1m_mem_rows(Td), TP = q1m_tp(Td);
+  int klen = a.k_lens ? a.k_lens[b] : Td;
+  klen = klen < 0 ? 0 : (klen > Td ? Td : klen);
+  // packed rows: the example HAS klen rows (T = klen: a key past it does not exist -- in the dense layout it is masked to the padding
+  // value, whose softmax weight is exactly 0 beside any valid key: the same P, context and gradients on the rows that exist)
+  const int T = a.row_off ? (klen > 0 ? klen : 1) : Td;
+  const bf16_t* mem_b = a.mem + (a.row_off ? (long long)a.row_off[b] * a.m_rs : (long long)b * a.m_bs);
   for (int i = tid; i < H * D / 8; i += 256) reinterpret_cast<uint4*>(L.q)[i] = reinterpret_cast<const uint4*>(a.qp + (long long)b * H * D)[i];
   const int nchunk = (T + CK - 1) / CK;
   const int h = wave;                  // one head per wavefront (H <= 4)
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
     softmax_row(L.sc + h * TP, T, klen, lane);
     for (int k = lane; k < T; k += 64) {
       float p = L.sc[h * TP + k];
-      if (a.drop_on) p = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? p * a.drop_inv : 0.f;
+      if (a.drop_on) p = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * Td + k), a.drop_thr) ? p * a.drop_inv : 0.f;
       const bf16_t pb = f2bf(p);
       L.pb[h * TP + k] = (unsigned)pb;
       ssum += bf2f(pb);
@@ -226,12 +230,13 @@ __global__ __launch_bounds__(256) void q1m_fwd_kernel(const Q1mArgs a) {
 __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x, T = a.T, H = a.H;
-  const Q1mLds L = q1m_carve(smem, T, H, true);
-  const int MR = q1m_mem_rows(T), TP = q1m_tp(T);
-  const bf16_t* mem_b = a.mem + (long long)b * a.m_bs;
-  int klen = a.k_lens ? a.k_lens[b] : T;
-  klen = klen < 0 ? 0 : (klen > T ? T : klen);
+  const int b = blockIdx.x, Td = a.T, H = a.H;
+  const Q1mLds L = q1m_carve(smem, Td, H, true);
+  const int MR = q1m_mem_rows(Td), TP = q1m_tp(Td);
+  int klen = a.k_lens ? a.k_lens[b] : Td;
+  klen = klen < 0 ? 0 : (klen > Td ? Td : klen);
+  const int T = a.row_off ? (klen > 0 ? klen : 1) : Td;     // (packed rows: see the forward kernel)
+  const bf16_t* mem_b = a.mem + (a.row_off ? (long long)a.row_off[b] * a.m_rs : (long long)b * a.m_bs);
   for (int i = tid; i < H * D / 8; i += 256) {
     reinterpret_cast<uint4*>(L.q)[i] = reinterpret_cast<const uint4*>(a.qp + (long long)b * H * D)[i];
     reinterpret_cast<uint4*>(L.dc)[i] = reinterpret_cast<const uint4*>(a.dctx + (long long)b * H * D)[i];
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
     float dot = 0.f;
     for (int k = lane; k < T; k += 64) {
       float keep = 1.f;
-      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
+      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * Td + k), a.drop_thr) ? a.drop_inv : 0.f;
       const float dp = g[k] * keep;
       g[k] = dp;
       dot += sc[k] * dp;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
     dot = wave_sum(dot);
     for (int k = lane; k < T; k += 64) {
       float keep = 1.f;
-      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * T + k), a.drop_thr) ? a.drop_inv : 0.f;
+      if (a.drop_on) keep = dmt_drop_keep(a.drop_seed, (unsigned)((b * H + h) * Td + k), a.drop_thr) ? a.drop_inv : 0.f;
       const float p = sc[k];
       const float ds = (k < klen) ? p * (g[k] - dot) * a.inv_sc : 0.f;     // (carries the 1 / sqrt(dh) of the score)
       L.pds[h * TP + k] = (unsigned)f2bf(p * keep) | ((unsigned)f2bf(ds) << 16);
@@ -306,8 +311,9 @@ __global__ __launch_bounds__(256) void q1m_bwd_kernel(const Q1mArgs a) {
   }
   __syncthreads();
   // ---- d mem_k = sum_h Pd_k,h d ctx_h + dS_k,h q'_h: one (key, 8 columns) item per thread, one dot2 per (head, column)
-  bf16_t* dm_b = a.dmem + (long long)b * a.dm_bs;
-  for (int it = tid; it < T * NCH; it += 256) {
+  bf16_t* dm_b = a.dmem + (a.row_off ? (long long)a.row_off[b] * a.dm_rs : (long long)b * a.dm_bs);
+  const int n_out = (a.row_off && klen == 0) ? 0 : T;      // (an example without rows owns no row of the packed gradient)
+  for (int it = tid; it < n_out * NCH; it += 256) {
     const int k = it / NCH, ch = it - k * NCH;
     float acc[8];
 #pragma unroll
@@ -341,6 +347,8 @@ int fill(Q1mArgs& a, const dmt_q1mem_desc* d, const char* who) {
   a.drop_inv = a.drop_on ? 1.f / d->drop_keep : 1.f;
   a.dctx = (const bf16_t*)d->dctx; a.dout = (const bf16_t*)d->dout; a.do_bs = d->do_bs; a.bv = d->bv;
   a.dqp = (bf16_t*)d->dqp; a.dmem = (bf16_t*)d->dmem; a.dm_bs = d->dm_bs; a.dm_rs = d->dm_rs;
+  a.row_off = d->row_off;
+  DMT_CHECK_ARG(d->row_off == nullptr || d->k_lens != nullptr, "%s: packed rows (row_off) need k_lens", who);
   return DMT_OK;
 }
 

@@ -499,6 +499,63 @@ __global__ __launch_bounds__(256) void colsum_drop_v8_kernel(long long rows, lon
   }
 }
 
+// Learned-position gradient of a PACKED sequence (include/dmt_hip.h "PACKED ROWS"): out[t, c] += scale * sum over the examples b with
+// lens[b] > t of mask((b * T + t) * d + c) * x[row_off[b] + t, c] -- the dense kernel above with the rows looked up instead of strided;
+// the dropout index is the DENSE one, so both layouts draw the same mask.  bf16, d % 8 == 0.  Workgroup (t, chunk of examples): a lane
+// owns 8 columns, the four wavefronts take interleaved examples (4 row requests in flight each), partial sums meet in LDS and leave as
+// one atomic per column (ordered: one chunk, plain add).
+__global__ __launch_bounds__(256) void colsum_packed_kernel(int B, int T, int d, const bf16_t* __restrict__ x, const int* __restrict__ row_off,
+                                                            const int* __restrict__ lens, float scale, float* __restrict__ out, int ex_per_block,
+                                                            uint32_t seed, uint32_t thr24, int drop_on, int atomic) {
+  __shared__ float part[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  const int b0 = blockIdx.y * ex_per_block;
+  const int b1 = (b0 + ex_per_block < B) ? b0 + ex_per_block : B;
+  const int nch = d / 8;
+  for (int c0 = 0; c0 < nch; c0 += 64) {
+    const int ch = c0 + lane;
+    const int chc = ch < nch ? ch : nch - 1;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int bb = b0 + wave; bb < b1; bb += 16) {
+      uint4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = bb + 4 * u;
+        const int bc = b < b1 ? b : b1 - 1;
+        ok[u] = b < b1 && lens[bc] > t;
+        const long long row = ok[u] ? (long long)row_off[bc] + t : 0ll;      // (branch-free: a row that does not exist re-reads row 0)
+        v[u] = *reinterpret_cast<const uint4*>(x + row * d + chc * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const int b = bb + 4 * u;
+        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const uint32_t base = (uint32_t)(((long long)b * T + t) * d + chc * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!drop_on || dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
+          if (!drop_on || dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[wave][i * 64 + lane] = s[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 512; e += 256) {
+      const int i = e >> 6, l = e & 63;
+      const int col = (c0 + l) * 8 + i;
+      if (c0 + l < nch) {
+        const float v2 = (((part[0][e] + part[1][e]) + part[2][e]) + part[3][e]) * scale;
+        if (atomic) atomicAdd(out + (long long)t * d + col, v2); else out[(long long)t * d + col] += v2;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(long long n, const float* __restrict__ src, bf16_t* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = f2bf(src[i]);
@@ -874,6 +931,21 @@ extern "C" int dmt_relu_bwd(int32_t dtype, int64_t rows, int64_t cols, const voi
     hipLaunchKernelGGL((relu_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (long long)rows, (long long)cols, (const bf16_t*)dy,
                        (long long)lddy, (const bf16_t*)y, (long long)ldy, (bf16_t*)dz, (long long)lddz);
   DMT_CHECK_LAUNCH("dmt_relu_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_colsum_rows_packed(int32_t dtype, int32_t B, int32_t T, int32_t d, const void* x, const int32_t* row_off, const int32_t* lens,
+                                      float scale, float* out, uint32_t seed, float keep_prob, int32_t ordered, void* stream) {
+  DMT_CHECK_ARG(dtype == DMT_BF16 && B > 0 && T > 0 && d > 0 && d % 8 == 0 && x && row_off && lens && out, "dmt_colsum_rows_packed: bf16 rows, d %% 8 == 0, non-null arguments");
+  DMT_CHECK_ARG(((uintptr_t)x & 15) == 0, "dmt_colsum_rows_packed: rows must be 16-byte aligned");
+  DMT_CHECK_ARG((long long)B * T * d < (1ll << 32), "dmt_colsum_rows_packed: dropout counter range");
+  const bool drop = keep_prob > 0.f && keep_prob < 1.f;
+  const uint32_t thr = drop ? (uint32_t)(keep_prob * 16777216.0f) : 0u;
+  const int epb = ordered ? B : (B + 15) / 16;
+  dim3 grid((unsigned)T, (unsigned)((B + epb - 1) / epb));
+  hipLaunchKernelGGL(colsum_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, B, T, d, (const bf16_t*)x, row_off, lens, drop ? scale / keep_prob : scale, out,
+                     epb, seed, thr, drop ? 1 : 0, ordered ? 0 : 1);
+  DMT_CHECK_LAUNCH("dmt_colsum_rows_packed");
   return DMT_OK;
 }
 

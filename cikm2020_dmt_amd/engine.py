@@ -588,17 +588,19 @@ class DMTEngine:
             self._seq_streams = [None] + pool[: n - 1]
         return self._seq_streams
 
-    def expert_gate(self, z, want_mix=False):
-        """Per-task mixtures; want_mix: as ONE [T, B, U] tensor (for heads()), else a list of [B, U] (reference shape)."""
+    def expert_gate(self, z, want_mix=False, z_is_engine_buffer=False):
+        """Per-task mixtures; want_mix: as ONE [T, B, U] tensor (for heads()), else a list of [B, U] (reference shape).
+        z_is_engine_buffer: z is (a view of) this engine's own zero-initialised zbuf, whose columns past K hold finite values (the bias
+        tower's inputs) -- only then may the layer-0 GEMM read the pad column K .. ceil8(K) against its zero weight row.  A caller's own
+        tensor (the reference-named facade) may hold NaN / uninitialised memory there: 0 * NaN would poison every output."""
         sp = self.spec
         E, T, units = sp["num_experts"], sp["num_tasks"], sp["hidden_units_bottom"]
         K = self.plan.K
         zin = z if z.shape[1] == K else z[:, :K]      # inference() hands over the already split [B, K] view
-        # (z is this engine's own zero-initialised buffer; its columns past K hold the bias tower's inputs: x_pad_finite)
         fused = self.use_mmoe_fused and ops.mmoe_experts_supported(units, E, T, zin.dtype)
         # (fused expert kernels: their backward hands d g1 over already times the relu gradient of this layer -- no pass of its own)
         g1 = ops.linear(zin, self._lf("mmoe_layers/l0_cat_weights"), self._lf("mmoe_layers/l0_cat_biases"),
-                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0], x_pad_finite=True, relu_grad_by_consumer=fused)
+                        self._w("mmoe_layers/l0_cat_weights"), act_ncols=E * units[0], x_pad_finite=bool(z_is_engine_buffer), relu_grad_by_consumer=fused)
         # [B, E * u0]: the four experts' layer-0 outputs side by side | both gates' logits
         if fused:
             # fused expert-MLP + gate kernels: layers 1-2 of every expert, the gate softmaxes and the mixtures in one launch
@@ -657,7 +659,7 @@ class DMTEngine:
     def inference(self, batch: DeviceBatch, is_predict=False):
         z = self.embedding_trans(batch)
         if is_predict:
-            tasks = self.expert_gate(z)
+            tasks = self.expert_gate(z, z_is_engine_buffer=True)
             return tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         # MMoE input | bias-tower input: one autograd node for both column slices of z
         plan = self.plan
@@ -667,9 +669,9 @@ class DMTEngine:
             z_main, z_bias = ops.split_cols(z, 0, plan.K, plan.bias_off, plan.bias_off + plan.bias_width)
         if self.use_heads_fused and ops.heads_supported(sp_units(self.spec)[0], self.spec["hidden_units_task"], plan.bias_width,
                                                         self.spec["hidden_units_bias"], self.spec["num_tasks"], z.dtype):
-            mix = self.expert_gate(z_main, want_mix=True)
+            mix = self.expert_gate(z_main, want_mix=True, z_is_engine_buffer=True)
             return self.heads(mix, z_bias)
-        tasks = self.expert_gate(z_main)
+        tasks = self.expert_gate(z_main, z_is_engine_buffer=True)
         logits = tuple(self.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         return logits, self.embedding_mlp_bias(z_bias)
 

@@ -32,10 +32,11 @@ class TransformerModel():
             # TransformerModel.py:61-64: seq_k += positional_encoding(seq_k, maxlen) -- the sinusoid table is a constant, no variable
             pe = positional_encoding(seq_k, seq_max_len, masking=False, scope="positional_encoding_k_position_sin_cos")
             return ops.ScaleAddPosFn.apply(seq_k, None, scale) + pe.to(seq_k.dtype)
-        if method in ("time_add", "time_concat"):
+        if method in ("time_add", "time_concat") and self._get("is_use_seq_ts", False) and seq_k_ts is not None:
             # (:70-78: a dense layer over the time-stamp embedding, `dense_trans_seq_time_*`: variables the DMT inventory -- SURVEY.md
-            #  Appendix B, dmt.conf -- does not hold)
-            raise NotImplementedError("position_encoding_method=%s needs the dense_trans_seq_%s variables, which dmt.conf's model does not create" % (method, method))
+            #  Appendix B, dmt.conf -- does not hold.  The reference takes these branches ONLY with is_use_seq_ts set and a time-stamp
+            #  tensor present; otherwise the scaled embedding passes through below, as it does there)
+            raise NotImplementedError("position_encoding_method=%s with is_use_seq_ts needs the dense_trans_seq_%s variables, which dmt.conf's model does not create" % (method, method))
         if method != "position_learn":
             return ops.ScaleAddPosFn.apply(seq_k, None, scale)       # (:59-82: no branch matches, the scaled embedding passes through)
         with R.variable_scope("positional_encoding_k_position_learn"):

@@ -1078,6 +1078,8 @@ class CrossQ1Fn(torch.autograd.Function):
         dd.k_lens = k_lens.data_ptr() if k_lens is not None else None
         dd.qp, dd.ctx, dd.ctx_hs = qp.data_ptr(), cx.data_ptr(), d + 8
         dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
+        if PROFILE is not None:    # algorithmic bytes: the memory rows once, q' in, (ctx | sum P) out
+            PROFILE.setdefault("q1mem_bytes", []).append(float(Bn * T * d * 2 + Bn * H * d * 2 + Bn * H * (d + 8) * 2))
         with _Timed("q1mem", 4.0 * Bn * H * T * d):
             L.call("dmt_q1mem_fwd", C.byref(dd), stream_ptr())
         # out[:, hc] = (ctx_h | S_h) (Wv[:, hc] ; bv_h) + q_in[:, hc]
@@ -1106,6 +1108,8 @@ class CrossQ1Fn(torch.autograd.Function):
         dd.dctx, dd.dout, dd.do_bs = dctx.data_ptr(), dout.data_ptr(), d
         dd.bv = b_leaf.data_ptr() + 4 * 2 * d
         dd.dqp, dd.dmem, dd.dm_bs, dd.dm_rs = dqp.data_ptr(), dmem.data_ptr(), T * d, d
+        if PROFILE is not None:    # algorithmic bytes: the memory rows once, d mem written once, q' / d ctx in, d q' out
+            PROFILE.setdefault("q1mem_bytes", []).append(float(2 * Bn * T * d * 2 + 3 * Bn * H * d * 2 + Bn * d * 2))
         with _Timed("q1mem", 8.0 * Bn * H * T * d):
             L.call("dmt_q1mem_bwd", C.byref(dd), stream_ptr())
         # d Q_h = d q'_h Wk[:, hc]  -> [B, d] bf16   (B operand k-contiguous: the transposed shadow rows d + hc)

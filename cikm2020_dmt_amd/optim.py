@@ -42,6 +42,9 @@ class TFAdam:
         self.global_step = 0
         self._step_base = 0          # global_step at which the device-side step counter / lr history last restarted
         self._begun = False          # begin() of the step in flight has run (it may run early: Trainer.train_step)
+        self._applied = False        # a parameter update of the step in flight has been enqueued (no rollback past this point)
+        self._early_event = None     # the last early catch-up on the index lane (reads state / lr_hist / stamp)
+        self._broken = None          # why no further step may begin (a step failed between its parameter update and end())
         self.stamp = None            # int32 per local table row: "the optimizer step with this local number updates the row itself"
         self.tm = store.fill_table_map(L.TableMap())
 
@@ -58,6 +61,9 @@ class TFAdam:
         # row needs an older entry) and the history restarts; the Adam state (m, v, beta powers) is untouched.
         if self._begun:              # (idempotent within a step: the Trainer calls it at the step's start, the optimizer phase again)
             return
+        if self._broken is not None:
+            raise RuntimeError(self._broken)
+        self._applied = False
         if self.global_step - self._step_base + 1 >= self.max_steps:
             self.rebase()
         L.call("dmt_adam_begin_step", ops.p(self.state), ops.p(self.lr_hist), self.max_steps, float(self.current_lr()), self.b1,
@@ -77,6 +83,17 @@ class TFAdam:
         the zero-gradient update the dense sweep gives them at that step."""
         if not self._begun:
             return
+        if self._applied:
+            # the dense and / or sparse update of this step has already been enqueued: rolling the counter back would make the retry
+            # apply the same step number a second time on top of it.  Nothing exact is left to do from here.
+            self._begun = False
+            self._broken = ("TFAdam: a step failed after its parameter update had been enqueued (step %d); the optimizer state cannot be "
+                            "rolled back -- restore from a checkpoint" % (self.global_step + 1))
+            return
+        if self._early_event is not None:
+            # an early catch-up on the index lane reads state / lr_hist / stamp: order the rollback behind it
+            torch.cuda.current_stream(self.store.device).wait_event(self._early_event)
+            self._early_event = None
         self.state.view(torch.int32)[3] -= 1
         self._begun = False
         if self.stamp is not None:
@@ -101,9 +118,13 @@ class TFAdam:
         L.call("dmt_adam_catchup_rows_to", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
                ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self.state), ops.p(self.lr_hist), self.b1, self.b2, self.eps, int(to_step),
                ops.p(self.stamp) if self.stamp is not None else None, int(to_step), ops.stream_ptr())
+        if s.device.type == "cuda":
+            self._early_event = torch.cuda.Event()
+            self._early_event.record(torch.cuda.current_stream(s.device))
 
     def apply_dense(self, grad_scale: float = 1.0):
         s = self.store
+        self._applied = True
         L.call("dmt_adam_dense", s.P, ops.p(s.params), ops.p(s.adam_m), ops.p(s.adam_v), ops.p(s.grads), float(grad_scale),
                ops.p(self.state), self.b1, self.b2, self.eps, None, ops.stream_ptr())
 
@@ -112,6 +133,7 @@ class TFAdam:
         uniq, n_uniq, grad_rows, cap = sparse
         if int(cap) == 0:
             return
+        self._applied = True
         if grad_rows.dtype == torch.bfloat16:      # reduced rows straight off the data-parallel wire
             L.call("dmt_adam_sparse_rows_bf16", C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
                    ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.shape[1]), float(grad_scale),

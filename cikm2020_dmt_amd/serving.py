@@ -107,7 +107,7 @@ class CandidateScorer:
                 k_lens = lens1.expand(batch.B).contiguous()
                 us.append(eng.decode_shared(tar.unsqueeze(1), mem1, k_lens, i).squeeze(1))
             z = AssembleFn.apply(zbuf, eng.plan.interest_off, spec["d_model"], *us)
-            tasks = eng.expert_gate(z)
+            tasks = eng.expert_gate(z, z_is_engine_buffer=True)          # (z is gather_pooled's zero-initialised zbuf)
             return tuple(eng.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         finally:
             eng.dropout_step_seed = saved_seed

@@ -144,6 +144,7 @@ class Trainer:
         main = torch.cuda.current_stream(self.device)
         if batch.ready is not None:
             side.wait_event(batch.ready)
+            self._record_batch(batch, main)      # (the id columns are read on this lane, possibly before forward_backward sees the batch)
         else:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -211,6 +212,35 @@ class Trainer:
             with self._span("adam_catchup"):
                 self.opt.catch_up(prep["uniq"], prep["n_uniq"], prep["cap"])
         return prep
+
+    def _record_batch(self, batch: DeviceBatch, cur):
+        """Every tensor of a batch uploaded on another stream, recorded once on every stream of the step that reads it: the compute
+        stream, the index lane (embgrad keys / sort of the id columns) and the sequence lanes (lens).  On the packed path all columns
+        are views of one storage; on the column-by-column path (parser.pinned = False, from_inputs under a side stream) each column is
+        its own allocation, and an unrecorded one could be handed to the next upload while this step still reads it."""
+        if getattr(batch, "_recorded_for", None) is self:
+            return
+        lanes = [cur]
+        side = self._index_stream()
+        if side is not None:
+            lanes.append(side)
+        if self.engine.seq_streams and self.device.type == "cuda":
+            n_seq = len(self.spec["attention_embed_pairs"])
+            lanes += [st for st in self.engine._seq_stream_pool(max(2, n_seq)) if st is not None]
+        seen = set()
+        tensors = [batch.dense, batch.mask, batch.label]
+        for col in batch.feats.values():
+            tensors += [col.idx, col.wts, col.lens]
+        for t in tensors:
+            if t is None or not t.is_cuda:
+                continue
+            key = t.untyped_storage().data_ptr()
+            if key in seen:
+                continue
+            seen.add(key)
+            for st in lanes:
+                t.record_stream(st)
+        batch._recorded_for = self
 
     def _index_stream(self):
         if self.device.type != "cuda" or not self.index_stream:
@@ -411,7 +441,7 @@ class Trainer:
             # that this stream reads the buffer (a no-op for a batch made on this stream)
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(batch.ready)
-            batch.dense.record_stream(cur)
+            self._record_batch(batch, cur)
         self.sync_rows(batch)
         if open_step:
             self._open_step(batch)

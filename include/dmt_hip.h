@@ -43,8 +43,16 @@ extern "C" {
  *   1  rounds 1-2.   2  round 3: dmt_set/get_deterministic removed; dmt_colsum / dmt_colsum_drop (ordered), dmt_softmax_fwd / _bwd
  *   (causal) gained an int before `stream`; dmt_wgrad_desc grew (det_ws).   3  round 4: dmt_mhsa_block_fwd re-implemented (a new weight-image layout: images of revision 2 are not
  *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31).   4  round 4: dmt_mmoe_desc grew (ws, ws_bytes,
- *   gate_dx); dmt_mmoe_experts_ws_bytes added. */
-#define DMT_ABI_VERSION 4
+ *   gate_dx); dmt_mmoe_experts_ws_bytes added.   5  round 5: PACKED ROWS (below): dmt_gather_desc / dmt_embgrad_desc grew (seq_row_off,
+ *   seq_row_len), dmt_attn_desc (row_off, ex_list, n_list), dmt_mhsa_desc (packed-row fields), dmt_q1mem_desc (row_off); dmt_colsum_rows_packed added.
+ *
+ * PACKED ROWS.  A behaviour sequence of a batch may be stored WITHOUT its padding: example b's rows t = 0 .. len[b] - 1 are rows
+ * row_off[b] + t of an [R, d] matrix, R = sum_b len[b] (row_off: int32 [B], any order of the examples -- the engine groups examples of
+ * one length class).  Every row-wise kernel (dmt_chain2, dmt_proj, dmt_gemm, dmt_ln_*, dmt_wgrad320) just sees R rows; the kernels that
+ * know about examples take row_off (NULL = the dense [B, T, d] layout, row b * T + t).  Rows t >= len[b] do not exist: in the dense
+ * layout they hold finite values nothing reads (the reference masks them as keys, and their gradients are zero), so the
+ * two layouts agree on every row that exists.  Dropout counters keep the DENSE element index, so a packed and a dense run draw the same mask. */
+#define DMT_ABI_VERSION 5
 const char* dmt_last_error(void);
 int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
@@ -111,6 +119,10 @@ typedef struct {
    * (i ^ seq_drop_seed[s]) passes seq_drop_keep, and scaled by 1/keep; seq_drop_keep <= 0 or >= 1: off.  */
   uint32_t seq_drop_seed[DMT_MAX_SEQS];
   float seq_drop_keep;
+  /* revision 5, packed rows: seq_out[s] is [R_s, d_model]; example b's rows t < seq_row_len[s][b] go to rows seq_row_off[s][b] + t, rows
+   * past seq_row_len are not written.  NULL (both): the dense layout.  The dropout index stays the dense one.                          */
+  const int32_t* seq_row_off[DMT_MAX_SEQS];
+  const int32_t* seq_row_len[DMT_MAX_SEQS];
 } dmt_gather_desc;
 
 int dmt_gather_fwd(const dmt_gather_desc* d, void* stream);
@@ -143,6 +155,10 @@ typedef struct {
   /* the same dropout mask as dmt_gather_desc, applied to dseq[s] while it is read (gradient of the fused dropout) */
   uint32_t seq_drop_seed[DMT_MAX_SEQS];
   float seq_drop_keep;
+  /* revision 5, packed rows: dseq[s] is [R_s, d_model]; entry (b, t) reads row seq_row_off[s][b] + t when t < seq_row_len[s][b] and
+   * contributes nothing otherwise.  NULL: dense.                                                                                       */
+  const int32_t* seq_row_off[DMT_MAX_SEQS];
+  const int32_t* seq_row_len[DMT_MAX_SEQS];
 } dmt_embgrad_desc;
 
 /* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e.            */
@@ -253,6 +269,15 @@ typedef struct {
                                /* i = ((b*H + h)*Tq + q)*Tk + k                                                                  */
   int32_t mma_dtype;           /* 0: the MFMAs run in `dtype`.  DMT_FP8_E4M3: long-sequence forward (64 < T <= 256, Tq > 1) converts Q, K, V and   */
                                /* the weights to OCP e4m3 for its two matrix products (BASELINE configs[4]); ignored elsewhere                 */
+  /* revision 5, packed rows (dmt_attn_bwd, bf16, self-attention form Tq == Tk <= 64 only): row_off != NULL: example b's operand rows are
+   * rows row_off[b] + t of Q / K / V / dout / dQ / dK / dV (the *_bs strides are ignored), and it has k_lens[b] rows (queries and keys).
+   * ex_list != NULL: the launch covers the n_list examples ex_list[0 .. n_list - 1] instead of 0 .. B - 1 (the engine launches one
+   * length class at a time, so that short examples take the one-tile kernel: max_len > 0 promises that no covered example is longer).
+   * Tq / Tk stay the DENSE lengths (dropout index).                                                                                    */
+  const int32_t* row_off;
+  const int32_t* ex_list;
+  int32_t n_list;
+  int32_t max_len;
 } dmt_attn_desc;
 
 int dmt_attn_fwd(const dmt_attn_desc* d, void* stream);
@@ -547,6 +572,14 @@ typedef struct {
   float* stats;           /* fp32 [B*T, 2] or NULL                       */
   uint32_t drop_seed;
   float drop_keep;
+  /* revision 5, packed rows: blocks != NULL: x / qkv / s_out / y_out / stats are [R, .] (R = n_rows) and the workgroups walk n_tiles row
+   * tiles of 8 blocks of 32 local rows each, described by blocks[tile][8][2] (int32 x 4 per entry: example, its length, its first packed
+   * row, log2 of the tile's padded example length Tp in {16, 32, 64}; example = -1: nothing there).  A block holds 32 / Tp examples
+   * (entry [.][.][1] is the second one of a Tp = 16 block), an example of Tp = 64 spans two blocks.  Built by the caller from the
+   * lengths (cikm2020_dmt_amd/engine.py SeqPack); B and T stay the dense dimensions (dropout index).                                   */
+  const int32_t* blocks;
+  int32_t n_tiles;
+  int64_t n_rows;
 } dmt_mhsa_desc;
 int dmt_mhsa_image_bytes(int64_t* bytes);
 int dmt_mhsa_image_build(const float* wqkv, int64_t ldw, void* image, void* stream);
@@ -560,6 +593,11 @@ int dmt_colsum(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t
  * dense: ldx == cols): the gradient of the learned positions behind the dropout fused into dmt_gather_fwd. */
 int dmt_colsum_drop(int32_t dtype, int64_t rows, int64_t cols, const void* x, float scale, float* out, uint32_t seed,
                     float keep_prob, int32_t ordered, void* stream);
+
+/* The same gradient for a PACKED sequence (revision 5): out[t, c] += scale * sum_{b: lens[b] > t} mask((b*T + t)*d + c) * x[row_off[b] + t, c] / keep,
+ * out fp32 [T, d]; bf16 rows, d % 8 == 0; keep_prob outside (0, 1): no mask.  ordered: one pass in example order (bit-reproducible). */
+int dmt_colsum_rows_packed(int32_t dtype, int32_t B, int32_t T, int32_t d, const void* x, const int32_t* row_off, const int32_t* lens,
+                           float scale, float* out, uint32_t seed, float keep_prob, int32_t ordered, void* stream);
 
 /* Streaming 200-threshold confusion histogram behind tf.metrics.auc (run_dnn.py:228-241):
  * hist[(label?1:0) * (n_thr+1) + #thresholds below pred] += 1 (int64).                                */
@@ -675,6 +713,9 @@ typedef struct {
   const float* bv;                           /* [H*dh] fp32 */
   void* dqp;                                 /* [B][H][d] bf16 */
   void* dmem; int64_t dm_bs, dm_rs;          /* [B][T][d] bf16 */
+  /* revision 5, packed rows: row_off != NULL: example b's memory rows are rows row_off[b] + k of mem / dmem (m_bs / dm_bs ignored), k <
+   * k_lens[b] (required then); T stays the dense length (dropout index, LDS sizing).                                                   */
+  const int32_t* row_off;
 } dmt_q1mem_desc;
 
 int dmt_q1mem_supported(int32_t dtype, int32_t d, int32_t H, int32_t T);

@@ -9,8 +9,13 @@ What comes from the reference itself:
   * demo474.npz        -- the 474 examples of jd_recsys_demo/*/test_ord/*/data/part-r-0000{0,1} at the
                           post-vocabulary-lookup boundary: vocabularies from the reference's conf/idtables/*.py
                           (Sku.py is missing upstream -> every SKU is an OOV hash bucket), feature names
-                          ord_seq_*_12m_10.
-  * lookup_golden.json -- raw id strings of a few features with the indices the lookup assigned.
+                          ord_seq_*_12m_10.  (The DATA -- records and vocabulary lists -- are the reference's; the
+                          lookup that maps them to indices is this repo's LookupTables, see the next item.)
+What is BUILD-GENERATED (a regression fixture, not a pin against the reference):
+  * lookup_golden.json -- raw id strings of a few features with the indices THIS REPO's data_feed.index_tables.LookupTables
+                          assigned (the reference's index_table_from_tensor needs TensorFlow).  Its OOV bucketing rests on
+                          data_feed/farmhash.py, which tests/test_host.py pins against published Fingerprint64 values
+                          (TensorFlow's own op test, BigQuery's FARM_FINGERPRINT documentation) -- all of them <= 16 bytes.
 What comes from the oracle (the reference has NO golden outputs, SURVEY.md F14 -> parity unpinned):
   * expected64.npz     -- logits / loss / gradient digests of oracle/dmt_oracle.py on the first 64 examples with
                           seeded weights, and a 100-step B=256 training run of oracle/dmt_oracle_torch.py (float64)

@@ -222,8 +222,14 @@ def test_transformer_model_position_options(cuda):
     assert np.abs(got - (_np(x) * np.sqrt(E) + enc[None, :T])).max() < 1e-5
     tm2 = TransformerModel(dict(sp, position_encoding_method="none_of_them"))
     assert np.abs(_np(tm2.position_encode(x, None, 50, float(E) ** 0.5)) - _np(x) * np.sqrt(E)).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        TransformerModel(dict(sp, position_encoding_method="time_add")).position_encode(x, None, 50, 1.0)
+    # time_add / time_concat: the reference takes those branches only with is_use_seq_ts set AND a time-stamp tensor
+    # (TransformerModel.py:70-78); otherwise the scaled embedding passes through
+    for meth in ("time_add", "time_concat"):
+        for conf_, ts in ((dict(sp, position_encoding_method=meth), None), (dict(sp, position_encoding_method=meth, is_use_seq_ts=True), None),
+                          (dict(sp, position_encoding_method=meth, is_use_seq_ts=False), x)):
+            assert np.abs(_np(TransformerModel(conf_).position_encode(x, ts, 50, float(E) ** 0.5)) - _np(x) * np.sqrt(E)).max() < 1e-5
+        with pytest.raises(NotImplementedError):
+            TransformerModel(dict(sp, position_encoding_method=meth, is_use_seq_ts=True)).position_encode(x, x, 50, 1.0)
     # decoder with sinusoid positions on the single query: differs from the default decoder by exactly PE[0] on its input
     lens = torch.tensor([9, 1, 4], dtype=torch.int32, device=cuda)
     q = torch.randn((B, 1, E), device=cuda)

@@ -77,6 +77,33 @@ def test_mhsa_block_forward(cuda, B, T, keep):
     assert ((stats[:, 0] - sm).abs() / s.float().abs().amax(-1).reshape(-1).clamp_min(1e-3)).max() < 1e-3
 
 
+def test_mhsa_block_statistics_of_large_mean_rows(cuda):
+    """Rows whose mean is ~1000 x their spread (a one-pass E[s^2] - mean^2 in fp32 loses the variance to cancellation
+    there, and with eps = 1e-8 the clamp at zero hands the LayerNorm gradient an rstd of 1e4).  The kernel accumulates the statistics
+    shifted by the row's first input element; the saved (mean, rstd) must match the two-pass statistics of the stored s, which is
+    what dmt_ln_fwd / dmt_ln_bwd of the three-launch path compute."""
+    B, T = 7, 50
+    x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=77)
+    # bf16 spacing at 64 is 0.5: offsets of +-0.5, +-1 around 64 are exact in bf16 and survive the rounding of s
+    g = torch.Generator().manual_seed(5)
+    x = (64.0 + 0.5 * torch.randint(-2, 3, (B, T, 320), generator=g).float()).to(BF).to(cuda)
+    w = w * 1e-3                                    # a small attention term: s stays x + O(1e-1)
+    img = torch.empty(ops.mhsa_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_image_build(w, img)
+    y, s, stats, _qkv = ops.mhsa_block_fwd(x, lens, img, b * 0.0, gamma, beta, 1e-8, 4, 0, 1.0)
+    torch.cuda.synchronize()
+    sf = s.float().reshape(-1, 320).double()
+    mean = sf.mean(-1)
+    var = ((sf - mean[:, None]) ** 2).mean(-1)
+    rstd = 1.0 / torch.sqrt(var + 1e-8)
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None]).reshape(-1)
+    assert (mean[live].abs() / var[live].sqrt()).min() > 50       # the case this test is about
+    assert ((stats[:, 0].double() - mean).abs()[live] / mean[live].abs()).max() < 1e-6
+    assert ((stats[:, 1].double() - rstd).abs()[live] / rstd[live]).max() < 1e-3
+    yr = (gamma.double() * ((sf - mean[:, None]) * rstd[:, None]) + beta.double()).reshape(B, T, 320)
+    assert ((y.double() - yr).abs()[live.reshape(B, T)]).max() < 2.0 ** -5
+
+
 def test_mhsa_block_autograd_matches_unfused_path(cuda):
     B, T, d, H = 37, 50, 320, 4
     x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=77)

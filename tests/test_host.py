@@ -45,6 +45,19 @@ def test_farmhash_known_answers():
     # tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]   (TensorFlow API docs)
     assert [to_hash_bucket_fast(s, 3) for s in (b"Hello", b"TensorFlow", b"2.x")] == [0, 2, 2]
     assert fingerprint64(b"") == 0x9AE16A3B2F90404F           # HashLen0to16 of the empty string is k2
+    # TensorFlow's own unit test of the op the reference calls (string_to_hash_bucket_op_test.py, testStringToHashBucketsFast: the
+    # Fingerprint64 values are written out in its comments; buckets [9, 2, 2, 5] of 10)
+    for t, v in ((b"a", 12917804110809363939), (b"b", 11795596070477164822), (b"c", 11430444447143000872), (b"d", 4470636696479570465)):
+        assert fingerprint64(t) == v
+    assert [to_hash_bucket_fast(t, 10) for t in (b"a", b"b", b"c", b"d")] == [9, 2, 2, 5]
+    # BigQuery FARM_FINGERPRINT documentation example (signed 64-bit view of Fingerprint64): lengths 8, 11, 5
+    s64 = lambda u: u - (1 << 64) if u >= (1 << 63) else u
+    assert [s64(fingerprint64(t)) for t in (b"1footrue", b"2applefalse", b"3true")] == [-1541654101129638711, 2794438866806483259, -4880158226897771312]
+    # README values of the `farmhash` Rust crate (hash64) and of pyfarmhash: lengths 11, 3
+    assert fingerprint64(b"hello world") == 6381520714923946011 and fingerprint64(b"abc") == 2640714258260161385
+    # (Every published vector available offline is <= 16 bytes: the 17-32 / 33-64 / > 64-byte branches are pinned only by the
+    #  native-vs-Python cross-check of tests/test_input_native.py -- two implementations by the same author -- and are not reached
+    #  by the demo data's ids, decimal strings of <= 12 characters.)
     for n in (1, 3, 4, 7, 8, 16, 17, 32, 33, 64, 65, 200):    # every length class runs and stays within 64 bits
         assert 0 <= fingerprint64(b"x" * n) < (1 << 64)
 
