@@ -15,7 +15,7 @@ DMT_F32, DMT_BF16, DMT_FP8_E4M3 = 0, 1, 2
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
-DMT_ABI_VERSION = 4        # include/dmt_hip.h: the revision this binding was written against (checked by load())
+DMT_ABI_VERSION = 5        # include/dmt_hip.h: the revision this binding was written against (checked by load())
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -31,7 +31,8 @@ class GatherDesc(C.Structure):
                 ("seq_out", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("pos", c_vp * DMT_MAX_SEQS),
                 ("tar_out", c_vp), ("d_model", c_i32), ("seq_scale", c_f32), ("pooled", c_vp), ("ld_pooled", c_i64),
                 ("dense", c_vp), ("n_dense", c_i32), ("out_dtype", c_i32),
-                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32)]
+                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32),
+                ("seq_row_off", c_vp * DMT_MAX_SEQS), ("seq_row_len", c_vp * DMT_MAX_SEQS)]      # revision 5: packed rows
 
 
 class EmbGradDesc(C.Structure):
@@ -39,7 +40,8 @@ class EmbGradDesc(C.Structure):
                 ("row_base", c_i32 * DMT_MAX_FEATURES), ("entry_base", c_i32 * (DMT_MAX_FEATURES + 1)),
                 ("total_rows", c_i32), ("dseq", c_vp * DMT_MAX_SEQS), ("seq_T", c_i32 * DMT_MAX_SEQS), ("dtar", c_vp),
                 ("dpooled", c_vp), ("ld_pooled", c_i64), ("d_model", c_i32), ("seq_scale", c_f32), ("grad_dtype", c_i32),
-                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32)]
+                ("seq_drop_seed", C.c_uint32 * DMT_MAX_SEQS), ("seq_drop_keep", c_f32),
+                ("seq_row_off", c_vp * DMT_MAX_SEQS), ("seq_row_len", c_vp * DMT_MAX_SEQS)]      # revision 5: packed rows
 
 
 class GemmDesc(C.Structure):
@@ -56,7 +58,8 @@ class AttnDesc(C.Structure):
                 ("Q", c_vp), ("q_bs", c_i64), ("q_rs", c_i64), ("K", c_vp), ("k_bs", c_i64), ("k_rs", c_i64),
                 ("V", c_vp), ("v_bs", c_i64), ("v_rs", c_i64), ("q_lens", c_vp), ("k_lens", c_vp),
                 ("resid", c_vp), ("r_bs", c_i64), ("r_rs", c_i64), ("out", c_vp), ("o_bs", c_i64), ("o_rs", c_i64),
-                ("drop_seed", C.c_uint32), ("drop_keep", c_f32), ("mma_dtype", c_i32)]
+                ("drop_seed", C.c_uint32), ("drop_keep", c_f32), ("mma_dtype", c_i32),
+                ("row_off", c_vp), ("ex_list", c_vp), ("n_list", c_i32), ("max_len", c_i32)]      # revision 5: packed rows (dmt_attn_bwd)
 
 
 class AttnBwdDesc(C.Structure):
@@ -85,7 +88,8 @@ class HeadsDesc(C.Structure):
 class Q1memDesc(C.Structure):
     _fields_ = [("B", c_i32), ("T", c_i32), ("H", c_i32), ("d", c_i32), ("dh", c_i32), ("mem", c_vp), ("m_bs", c_i64), ("m_rs", c_i64),
                 ("k_lens", c_vp), ("qp", c_vp), ("ctx", c_vp), ("ctx_hs", c_i64), ("drop_seed", C.c_uint32), ("drop_keep", c_f32),
-                ("dctx", c_vp), ("dout", c_vp), ("do_bs", c_i64), ("bv", c_vp), ("dqp", c_vp), ("dmem", c_vp), ("dm_bs", c_i64), ("dm_rs", c_i64)]
+                ("dctx", c_vp), ("dout", c_vp), ("do_bs", c_i64), ("bv", c_vp), ("dqp", c_vp), ("dmem", c_vp), ("dm_bs", c_i64), ("dm_rs", c_i64),
+                ("row_off", c_vp)]                                                                # revision 5: packed rows
 
 
 class CastJob(C.Structure):
@@ -105,7 +109,8 @@ DMT_CHAIN_FFN_LN, DMT_CHAIN_FFN_BWD = 0, 1
 class MhsaDesc(C.Structure):
     _fields_ = [("d_model", c_i32), ("num_heads", c_i32), ("B", c_i32), ("T", c_i32), ("x", c_vp), ("lens", c_vp), ("image", c_vp),
                 ("bias", c_vp), ("gamma", c_vp), ("beta", c_vp), ("eps", c_f32), ("qkv", c_vp), ("s_out", c_vp), ("y_out", c_vp),
-                ("stats", c_vp), ("drop_seed", C.c_uint32), ("drop_keep", c_f32)]
+                ("stats", c_vp), ("drop_seed", C.c_uint32), ("drop_keep", c_f32),
+                ("blocks", c_vp), ("n_tiles", c_i32), ("n_rows", c_i64)]                          # revision 5: packed rows
 
 
 class WgradDesc(C.Structure):
@@ -168,6 +173,7 @@ _SIGS = {
     "dmt_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
+    "dmt_colsum_rows_packed": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
     "dmt_confusion_counts": [c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],
     "dmt_l2_unique_rows": [c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],

@@ -501,13 +501,16 @@ __global__ __launch_bounds__(256) void colsum_drop_v8_kernel(long long rows, lon
 
 // Learned-position gradient of a PACKED sequence (include/dmt_hip.h "PACKED ROWS"): out[t, c] += scale * sum over the examples b with
 // lens[b] > t of mask((b * T + t) * d + c) * x[row_off[b] + t, c] -- the dense kernel above with the rows looked up instead of strided;
-// the dropout index is the DENSE one, so both layouts draw the same mask.  bf16, d % 8 == 0.  Workgroup (t, chunk of examples): a lane
-// owns 8 columns, the four wavefronts take interleaved examples (4 row requests in flight each), partial sums meet in LDS and leave as
-// one atomic per column (ordered: one chunk, plain add).
+// the dropout index is the DENSE one, so both layouts draw the same mask.  bf16, d % 8 == 0.  Workgroup (t, chunk of examples): the
+// chunk's row numbers (or -1) are staged in LDS once (coalesced reads of lens / row_off), then a lane owns 8 columns, the four wavefronts
+// take interleaved examples with eight row requests in flight each; partial sums meet in LDS and leave as one atomic per column
+// (ordered: one chunk, plain add, fixed order).
+constexpr int CSP_STAGE = 1024;
 __global__ __launch_bounds__(256) void colsum_packed_kernel(int B, int T, int d, const bf16_t* __restrict__ x, const int* __restrict__ row_off,
                                                             const int* __restrict__ lens, float scale, float* __restrict__ out, int ex_per_block,
                                                             uint32_t seed, uint32_t thr24, int drop_on, int atomic) {
   __shared__ float part[4][512];
+  __shared__ int s_row[CSP_STAGE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x;
   const int b0 = blockIdx.y * ex_per_block;
@@ -517,27 +520,31 @@ __global__ __launch_bounds__(256) void colsum_packed_kernel(int B, int T, int d,
     const int ch = c0 + lane;
     const int chc = ch < nch ? ch : nch - 1;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int bb = b0 + wave; bb < b1; bb += 16) {
-      uint4 v[4];
-      bool ok[4];
+    for (int bs = b0; bs < b1; bs += CSP_STAGE) {
+      const int nb = (b1 - bs) < CSP_STAGE ? (b1 - bs) : CSP_STAGE;
+      __syncthreads();
+      for (int i = threadIdx.x; i < nb; i += 256) s_row[i] = lens[bs + i] > t ? row_off[bs + i] + t : -1;
+      __syncthreads();
+      for (int i0 = wave; i0 < nb; i0 += 32) {
+        uint4 v[8];
+        int rw[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int b = bb + 4 * u;
-        const int bc = b < b1 ? b : b1 - 1;
-        ok[u] = b < b1 && lens[bc] > t;
-        const long long row = ok[u] ? (long long)row_off[bc] + t : 0ll;      // (branch-free: a row that does not exist re-reads row 0)
-        v[u] = *reinterpret_cast<const uint4*>(x + row * d + chc * 8);
-      }
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + 4 * u;
+          rw[u] = i < nb ? s_row[i] : -1;
+          v[u] = *reinterpret_cast<const uint4*>(x + (long long)(rw[u] >= 0 ? rw[u] : 0) * d + chc * 8);      // (branch-free: row 0 when there is none)
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!ok[u]) continue;
-        const int b = bb + 4 * u;
-        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        const uint32_t base = (uint32_t)(((long long)b * T + t) * d + chc * 8);
+        for (int u = 0; u < 8; ++u) {
+          if (rw[u] < 0) continue;                     // (wave-uniform)
+          const int b = bs + i0 + 4 * u;
+          const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          const uint32_t base = (uint32_t)(((long long)b * T + t) * d + chc * 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (!drop_on || dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
-          if (!drop_on || dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+          for (int i = 0; i < 4; ++i) {
+            if (!drop_on || dmt_drop_keep(seed, base + 2 * i, thr24)) s[2 * i] += __uint_as_float(w[i] << 16);
+            if (!drop_on || dmt_drop_keep(seed, base + 2 * i + 1, thr24)) s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u);
+          }
         }
       }
     }

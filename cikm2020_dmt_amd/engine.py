@@ -21,10 +21,71 @@ from .variables import VariableStore
 
 # ------------------------------------------------------------------------------------------------ batch
 class FeatureColumn:
-    __slots__ = ("idx", "wts", "lens", "T")
+    __slots__ = ("idx", "wts", "lens", "T", "lens_host")
 
-    def __init__(self, idx, wts, lens, T):
+    def __init__(self, idx, wts, lens, T, lens_host=None):
         self.idx, self.wts, self.lens, self.T = idx, wts, lens, T
+        self.lens_host = lens_host          # numpy int32 [B] (the lengths as the host saw them) or None: no packed rows for this column
+
+
+class SeqPack:
+    """Packed-row layout of ONE behaviour sequence of a batch (include/dmt_hip.h, "PACKED ROWS"): example b's rows t < len[b] are rows
+    row_off[b] + t of [R, d] matrices, R = sum len.  Examples are grouped by length class (len <= 16 / <= 32 / <= 64 -- the padded lengths
+    Tp the fused self-attention kernel tiles with), so a class is a contiguous range of `order` and of the rows.  Built on the host from
+    the batch's lengths (a few vectorised numpy passes over B entries), uploaded once as one int32 buffer and cached on the batch.
+    The reference computes every sequence at [B, T_max] (SURVEY.md F13 notes that a new kernel may skip the padded rows): on its
+    data -- click histories of 1 - 50 items -- about half of those rows are padding."""
+
+    def __init__(self, lens_np, T, device):
+        B = int(lens_np.shape[0])
+        ln = lens_np.astype(np.int64)
+        self.B, self.T = B, int(T)
+        cls = np.where(ln <= 16, 0, np.where(ln <= 32, 1, 2))
+        order = np.argsort(cls, kind="stable")
+        ln_s = ln[order]
+        off_s = np.zeros(B, np.int64)
+        off_s[1:] = np.cumsum(ln_s)[:-1]
+        self.R = int(ln_s.sum())
+        row_off = np.empty(B, np.int64)
+        row_off[order] = off_s
+        self.n_cls = [int((cls == c).sum()) for c in range(3)]
+        tabs, pos = [], 0
+        for c in range(3):
+            n, lg = self.n_cls[c], 4 + c
+            if n == 0:
+                continue
+            epw = 256 >> lg                                   # examples per 256-row tile
+            nt = (n + epw - 1) // epw
+            ent = np.zeros((nt * epw, 4), np.int32)
+            ent[:, 0], ent[:, 3] = -1, lg
+            ex = order[pos: pos + n]
+            ent[:n, 0], ent[:n, 1], ent[:n, 2] = ex, ln[ex], row_off[ex]
+            if lg == 4:                                       # two examples per 32-row block
+                tab = ent.reshape(nt, 8, 2, 4)
+            elif lg == 5:                                     # one example per block
+                tab = np.repeat(ent.reshape(nt, 8, 1, 4), 2, axis=2)
+            else:                                             # one example spans two blocks
+                tab = np.repeat(np.repeat(ent.reshape(nt, 4, 1, 1, 4), 2, axis=2), 2, axis=3).reshape(nt, 8, 2, 4)
+            tabs.append(tab)
+            pos += n
+        blocks = np.concatenate(tabs, axis=0) if tabs else np.zeros((0, 8, 2, 4), np.int32)
+        self.n_tiles = int(blocks.shape[0])
+        # one upload: [blocks | row_off | order]  (blocks first: the kernel reads 16-byte entries)
+        nb = blocks.size
+        buf = np.empty(nb + 2 * B, np.int32)
+        buf[:nb] = blocks.reshape(-1)
+        buf[nb: nb + B] = row_off
+        buf[nb + B:] = order
+        dbuf = torch.from_numpy(buf).to(device)
+        self.buf = dbuf
+        self.blocks, self.row_off, self.order = dbuf[:nb], dbuf[nb: nb + B], dbuf[nb + B:]
+        self.n_short = self.n_cls[0] + self.n_cls[1]         # examples of at most 32 rows: order[:n_short]
+
+    @staticmethod
+    def eligible(lens_np, T):
+        """Packed rows are defined for lengths in [1, T] (a length of 0 means "attend uniformly over padding" in the dense layout:
+        SURVEY.md Appendix A.1 -- the data never has it)."""
+        return lens_np is not None and lens_np.size > 0 and int(lens_np.min()) >= 1 and int(lens_np.max()) <= T
 
 
 class DeviceBatch:
@@ -33,6 +94,7 @@ class DeviceBatch:
     def __init__(self, B, feats: Dict[str, FeatureColumn], dense, mask=None, label=None):
         self.B, self.feats, self.dense, self.mask, self.label = B, feats, dense, mask, label
         self._prep = None
+        self._packs = {}             # sequence -> SeqPack or None (DMTEngine.seq_pack)
         # "the upload of this batch is done": what the index-plane stream of the Trainer waits for instead of the whole compute stream
         self.ready = None
         if dense.is_cuda:
@@ -62,7 +124,7 @@ class DeviceBatch:
                 w_np, _ = wsp.to_padded(T)
                 wts = torch.as_tensor(w_np.astype(np.float32)).to(device)
             feats[f] = FeatureColumn(torch.as_tensor(idx_np.astype(np.int32)).to(device), wts,
-                                     torch.as_tensor(lens_np.astype(np.int32)).to(device), T)
+                                     torch.as_tensor(lens_np.astype(np.int32)).to(device), T, lens_host=np.asarray(lens_np, dtype=np.int32))
         m = torch.as_tensor(np.asarray(mask, dtype=np.float32)).to(device) if mask is not None else None
         lb = torch.as_tensor(np.asarray(label, dtype=np.float32)).to(device) if label is not None else None
         return DeviceBatch(B, feats, dense, m, lb)
@@ -90,7 +152,9 @@ class DeviceBatch:
             for f in dict.fromkeys(names):
                 T = layout[f][2][1]
                 wts = view(f + "Wts") if int(not_one[id_feats.index(f)]) != 0 else None
-                feats[f] = FeatureColumn(view(f), wts, view(f + "/lens"), T)
+                o_l, dt_l, shape_l = layout[f + "/lens"]
+                lens_h = hbuf[o_l: o_l + int(np.prod(shape_l)) * 4].view(torch.int32).numpy().copy()     # (the pinned buffer is reused by the parser)
+                feats[f] = FeatureColumn(view(f), wts, view(f + "/lens"), T, lens_host=lens_h)
             dense = view("features")
             m = view("mask") if "mask" in layout else None
             lb = view("label")[:, 0] if "label" in layout else None
@@ -106,7 +170,8 @@ class DeviceBatch:
                 valid = np.arange(T)[None, :] < lens[:, None]
                 if valid.any() and not np.all(w[valid] == 1.0):
                     wts = torch.as_tensor(w).to(device, non_blocking=True)
-            feats[f] = FeatureColumn(torch.as_tensor(idx).to(device, non_blocking=True), wts, torch.as_tensor(lens).to(device, non_blocking=True), T)
+            feats[f] = FeatureColumn(torch.as_tensor(idx).to(device, non_blocking=True), wts, torch.as_tensor(lens).to(device, non_blocking=True), T,
+                                     lens_host=np.array(lens, dtype=np.int32))
         m = torch.as_tensor(cols["mask"]).to(device, non_blocking=True) if "mask" in cols else None
         lb = torch.as_tensor(cols["label"][:, 0]).to(device, non_blocking=True) if "label" in cols else None
         return DeviceBatch(B, feats, dense, m, lb)
@@ -184,7 +249,7 @@ class FanOutFn(torch.autograd.Function):
 
 class GatherFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, engine, batch, *pos_leaves):
+    def forward(ctx, engine, batch, packs, *pos_leaves):
         plan, store, spec = engine.plan, engine.store, engine.spec
         dev, cdt = store.device, store.compute_dtype
         B, d = batch.B, spec["d_model"]
@@ -192,7 +257,8 @@ class GatherFn(torch.autograd.Function):
         seq_T = []
         for pairs in spec["attention_embed_pairs"]:
             seq_T.append(max(batch.feats[uf].T for (uf, _i) in pairs))
-        X = [torch.empty((B, seq_T[s], d), dtype=cdt, device=dev) for s in range(n_seq)]
+        # packs[s]: SeqPack -> the sequence's rows are produced packed, [1, R, d] (one "example" of R rows for every row-wise op)
+        X = [torch.empty((1, max(packs[s].R, 1), d) if packs[s] is not None else (B, seq_T[s], d), dtype=cdt, device=dev) for s in range(n_seq)]
         tar = torch.empty((B, d), dtype=cdt, device=dev)
         zbuf = torch.zeros((B, plan.ldz), dtype=cdt, device=dev)
         desc = L.GatherDesc()
@@ -231,6 +297,9 @@ class GatherFn(torch.autograd.Function):
             desc.seq_out[s] = X[s].data_ptr()
             desc.seq_T[s] = seq_T[s]
             desc.pos[s] = pos_leaves[s].data_ptr()
+            if packs[s] is not None:
+                desc.seq_row_off[s] = packs[s].row_off.data_ptr()
+                desc.seq_row_len[s] = engine.seq_lens(batch, s).data_ptr()
             if seq_T[s] > pos_leaves[s].shape[0]:
                 raise ValueError("sequence %d length %d exceeds the learned position table (%d rows)" % (s, seq_T[s], pos_leaves[s].shape[0]))
         desc.tar_out = tar.data_ptr()
@@ -248,7 +317,7 @@ class GatherFn(torch.autograd.Function):
         ctx.drop = (seeds, keep)
         with ops._Timed("gather_fwd", engine.gather_bytes(batch, seq_T)):
             L.call("dmt_gather_fwd", C.byref(desc), ops.stream_ptr())
-        ctx.engine, ctx.batch, ctx.inv, ctx.seq_T = engine, batch, inv, seq_T
+        ctx.engine, ctx.batch, ctx.inv, ctx.seq_T, ctx.packs = engine, batch, inv, seq_T, packs
         ctx.pos_shapes = [tuple(pl.shape) for pl in pos_leaves]
         ctx.pos_leaves = pos_leaves
         return (*X, tar, zbuf)
@@ -261,7 +330,7 @@ class GatherFn(torch.autograd.Function):
         if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None for pl in ctx.pos_leaves):
             # Trainer.train_step finishes this node itself (finish_sparse_backward), on the index lane, beside the deferred weight gradients
             engine._pending_sparse = (ctx, grads)
-            return (None, None) + (None,) * n_seq
+            return (None, None, None) + (None,) * n_seq
         return GatherFn._finish(ctx, grads)
 
     @staticmethod
@@ -273,9 +342,10 @@ class GatherFn(torch.autograd.Function):
         dtar, dz = grads[n_seq], grads[n_seq + 1]
         B, d = batch.B, spec["d_model"]
         dev, cdt = engine.store.device, engine.store.compute_dtype
+        packs = ctx.packs
         for s in range(n_seq):
             if dX[s] is None:
-                dX[s] = torch.zeros((B, ctx.seq_T[s], d), dtype=cdt, device=dev)
+                dX[s] = torch.zeros((1, max(packs[s].R, 1), d) if packs[s] is not None else (B, ctx.seq_T[s], d), dtype=cdt, device=dev)
         dtar = dtar.contiguous() if dtar is not None else torch.zeros((B, d), dtype=cdt, device=dev)
         dz = dz.contiguous() if dz is not None else torch.zeros((B, engine.plan.ldz), dtype=cdt, device=dev)
         # learned positions: dP[t] = sum_b dX[b, t]   (lookup by range(T), TransformerModel_util.py:296-306)
@@ -286,14 +356,18 @@ class GatherFn(torch.autograd.Function):
             direct = gv is not None and gv.is_contiguous() and tuple(gv.shape) == ctx.pos_shapes[s]
             g = gv if direct else torch.zeros(ctx.pos_shapes[s], dtype=F32, device=dev)
             seeds, keep = ctx.drop
-            if 0.0 < keep < 1.0:
+            if packs[s] is not None:
+                # packed rows: dP[t] sums the rows (b, t) of the examples that have one (dmt_colsum_rows_packed; same dropout mask)
+                L.call("dmt_colsum_rows_packed", ops.dt_code(dX[s].dtype), B, ctx.seq_T[s], d, ops.p(dX[s]), ops.p(packs[s].row_off),
+                       ops.p(engine.seq_lens(batch, s)), 1.0, ops.p(g), int(seeds[s]), float(keep), 1 if ops.DETERMINISTIC else 0, ops.stream_ptr())
+            elif 0.0 < keep < 1.0:
                 L.call("dmt_colsum_drop", ops.dt_code(dX[s].dtype), B, ctx.seq_T[s] * d, ops.p(dX[s]), 1.0, ops.p(g), int(seeds[s]), float(keep),
                        1 if ops.DETERMINISTIC else 0, ops.stream_ptr())
             else:
                 ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
             dpos.append(None if direct else g)
-        engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz, ctx.drop)
-        return (None, None, *dpos)
+        engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz, ctx.drop, packs)
+        return (None, None, None, *dpos)
 
 
 class AssembleFn(torch.autograd.Function):
@@ -342,6 +416,10 @@ class DMTEngine:
         self.use_heads_fused = os.environ.get("DMT_FUSED_HEADS", "1") == "1"    # towers + bias tower in one launch each way (dmt_heads.hip)
         self.use_mmoe_fused = os.environ.get("DMT_FUSED_MMOE", "1") == "1"      # fused expert-MLP + gate kernels (dmt_mmoe.hip)
         self.use_chain = True            # fused ff + ln kernels (dmt_chain2) where the geometry has one; False: GEMM + LN launches
+        # packed rows (SeqPack): sequences whose padding is at least 10 % of their [B, T] grid are computed on their real rows only
+        self.packed_rows = os.environ.get("DMT_PACKED_ROWS", "1") == "1"
+        self.packed_rows_min_saving = 0.9
+        self._last_packs = None
         self.step_state = ops.StepState()  # collected weight gradients / fork lane / long-row threshold of the step in flight (ops.StepState)
         self.kopts = ops.KernelOptions()  # attention / projection kernel choices of THIS engine (fp8 MFMA forward, long fused form, dmt_proj)
 
@@ -390,9 +468,43 @@ class DMTEngine:
     def gather(self, batch: DeviceBatch):
         pos = [self._lf(trans_prefix(i) + "positional_encoding_k_position_learn/embedding_position_learn")
                for i in range(len(self.spec["attention_embed_pairs"]))]
-        outs = GatherFn.apply(self, batch, *pos)
+        packs = [self.seq_pack(batch, s) for s in range(len(pos))]
+        self._last_packs = packs
+        outs = GatherFn.apply(self, batch, packs, *pos)
         n = len(pos)
         return list(outs[:n]), outs[n], outs[n + 1]
+
+    # ---- packed rows
+    def seq_lens(self, batch, s):
+        """Device lengths of sequence s: those of its LAST field pair (mask / lens of mmoe_transformer.py:137-142)."""
+        return batch.feats[self.spec["attention_embed_pairs"][s][-1][0]].lens
+
+    def seq_pack(self, batch, s):
+        """The SeqPack of sequence s of this batch, or None when the sequence is computed in the dense [B, T, d] layout.  Packed rows
+        are taken when every kernel of the sequence's path has its packed form (bf16, the fused self-attention block, the raw-memory
+        decoder attention, the fused FFN), the lengths are known on the host and within [1, T], and the padding is worth skipping
+        (R <= packed_rows_min_saving * B * T).  Training and inference alike: the layout is a property of the forward graph."""
+        key = (id(self), s, self.packed_rows, self.use_mhsa, self.use_q1mem, self.use_chain)       # (a batch may be shared by engines / switch settings)
+        if key in batch._packs:
+            return batch._packs[key]
+        pack = None
+        spec, store = self.spec, self.store
+        d, H = spec["d_model"], spec["num_heads"]
+        pairs = spec["attention_embed_pairs"][s]
+        col = batch.feats[pairs[-1][0]]
+        T = max(batch.feats[uf].T for (uf, _i) in pairs)
+        blk = trans_prefix(s) + "num_blocks_0/"
+        ok = (self.packed_rows and store.compute_dtype == torch.bfloat16 and store.device.type == "cuda" and store.shard is None
+              and self.use_mhsa and store.mhsa.get(blk + "self-attention/") is not None and ops.mhsa_supported(d, H, T, batch.B)
+              and self.use_q1mem and store.q1mem.get(blk + "vanilla_attention/") is not None and ops.q1mem_supported(d, H, T)
+              and self.use_chain and store.chain.get(blk + "positionwise_feedforward/") is not None
+              and T >= 8 and SeqPack.eligible(col.lens_host, T))
+        if ok:
+            R = int(col.lens_host.astype(np.int64).sum())
+            if R <= self.packed_rows_min_saving * batch.B * T:
+                pack = SeqPack(col.lens_host, T, store.device)
+        batch._packs[key] = pack
+        return pack
 
     def gather_raw(self, batch: DeviceBatch):
         """generate_data's outputs: unscaled seq_emb / tar_emb ([0;E] lookups, no positions); no gradient path to the
@@ -464,31 +576,31 @@ class DMTEngine:
             return 0, 1.0
         return ops.site_seed(self.dropout_step_seed, stream), 1.0 - rate
 
-    def mha_self(self, x, lens, blk, stream=2):
-        """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d]."""
+    def mha_self(self, x, lens, blk, stream=2, pack=None):
+        """multihead_attention(x, x, x, lens, lens) (TransformerModel_util.py:160-209), x: [B,T,d] (pack: [1, R, d] packed rows)."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "self-attention/"
         img = self.store.mhsa.get(a) if x.dtype == torch.bfloat16 else None
-        if img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1], x.shape[0]):
+        if pack is not None or (img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1], x.shape[0])):
             seed, keep = self._attn_drop(stream)
             return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
-                                         self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8)
+                                         self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8, pack)
         s1 = ops.SelfAttnBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"), lens, H,
                                        *self._attn_drop(stream), self.kopts)
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
 
-    def mha_cross(self, q_in, mem, q_lens, k_lens, blk, stream=3):
-        """multihead_attention(q, mem, mem, q_lens, k_lens) with scope 'vanilla_attention'."""
+    def mha_cross(self, q_in, mem, q_lens, k_lens, blk, stream=3, pack=None):
+        """multihead_attention(q, mem, mem, q_lens, k_lens) with scope 'vanilla_attention' (pack: mem is [1, R, d] packed rows)."""
         d, H = self.spec["d_model"], self.spec["num_heads"]
         a = blk + "vanilla_attention/"
         wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
         q = ops.linear(q_in, wl[:, :d], bl[:d], self._wslice(w, 0, d))
         wv_aug = self.store.q1mem.get(a) if (self.use_q1mem and q_in.dtype == torch.bfloat16) else None
-        if (wv_aug is not None and q_lens is None and q_in.shape[1] == 1 and ops.q1mem_supported(d, H, mem.shape[1]) and
-                mem.stride(2) == 1 and mem.stride(1) % 8 == 0 and mem.stride(0) % 8 == 0 and mem.data_ptr() % 16 == 0):
+        if pack is not None or (wv_aug is not None and q_lens is None and q_in.shape[1] == 1 and ops.q1mem_supported(d, H, mem.shape[1]) and
+                                mem.stride(2) == 1 and mem.stride(1) % 8 == 0 and mem.stride(0) % 8 == 0 and mem.data_ptr() % 16 == 0):
             # one query per example: attend over the raw memory rows, no K / V projection of the memory (dmt_q1mem.hip)
             seed, keep = self._attn_drop(stream)
-            s = ops.CrossQ1Fn.apply(q.reshape(-1, d), mem, q_in.reshape(-1, d), k_lens, w, wl, bl, wv_aug, H, seed, keep).unsqueeze(1)
+            s = ops.CrossQ1Fn.apply(q.reshape(-1, d), mem, q_in.reshape(-1, d), k_lens, w, wl, bl, wv_aug, H, seed, keep, pack).unsqueeze(1)
             return ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
         kv = ops.linear(mem, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d))
         s = ops.AttnFn.apply(q, kv, q_in, q_lens, k_lens, H, d, False, *self._attn_drop(stream), self.kopts)
@@ -504,18 +616,18 @@ class DMTEngine:
                             self._lf(ffs + "dense_1/bias"), self._w(ffs + "dense/kernel"), self._w(ffs + "dense_1/kernel"))
         return ops.layer_norm(s, self._lf(ffs + "ln/gamma"), self._lf(ffs + "ln/beta"))
 
-    def encode_prepared(self, x, lens, i):
+    def encode_prepared(self, x, lens, i, pack=None):
         """TransformerModel.encode after the input prep (x = sqrt(d)*seq_emb + P, fused into the gather)."""
         blk = trans_prefix(i) + "num_blocks_0/"
         # TransformerModel.py:101 dropout(enc): already applied by the gather (GatherFn), stream id 10 * i + 0
-        x = self.mha_self(x, lens, blk, 10 * i + 2)
+        x = self.mha_self(x, lens, blk, 10 * i + 2, pack=pack)
         return self.ff(x, blk + "positionwise_feedforward/")
 
-    def decode_prepared(self, y, mem, lens, i):
+    def decode_prepared(self, y, mem, lens, i, pack=None):
         """TransformerModel.decode after the input prep (y = sqrt(d)*tar[:,None,:])."""
         blk = trans_prefix(i) + "num_blocks_0/"
         y = ops.dropout(y, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 1)     # TransformerModel.py:151
-        y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3)
+        y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3, pack=pack)
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(y, blk + ffs)
 
@@ -535,6 +647,7 @@ class DMTEngine:
 
     def embedding_trans(self, batch: DeviceBatch):
         X, tar, zbuf = self.gather(batch)
+        packs = self._last_packs
         n_seq = len(self.spec["attention_embed_pairs"])
         # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
         # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
@@ -557,16 +670,19 @@ class DMTEngine:
                 st.wait_event(ready)
                 X[i].record_stream(st)            # (allocated on the compute stream, read on this one)
                 tars[i].record_stream(st)
+                if packs[i] is not None:
+                    packs[i].buf.record_stream(st)
                 with torch.cuda.stream(st):
-                    mem = self.encode_prepared(X[i], lens, i)
-                    y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i)
+                    mem = self.encode_prepared(X[i], lens, i, pack=packs[i])
+                    y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i, pack=packs[i])
                     y.record_stream(main)
                     mem.record_stream(main)
             else:
-                mem = self.encode_prepared(X[i], lens, i)
-                y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i)
+                mem = self.encode_prepared(X[i], lens, i, pack=packs[i])
+                y = self.decode_prepared(tars[i].unsqueeze(1), mem, lens, i, pack=packs[i])
             us[i] = y.squeeze(1)
-            self.intermediates["memory_%d" % i] = mem
+            self.intermediates["memory_%d" % i] = mem          # ([1, R, d] when the sequence ran on packed rows: pack_%d)
+            self.intermediates["pack_%d" % i] = packs[i]
         if main is not None:
             for st in side:
                 if st is not None:
@@ -808,14 +924,21 @@ class DMTEngine:
         for g in grads:
             if g is not None and g.is_cuda:
                 g.record_stream(cur)
+        for pk in ctx.packs:
+            if pk is not None:
+                pk.buf.record_stream(cur)
         out = GatherFn._finish(ctx, grads)
         assert all(o is None for o in out)        # (position gradients went straight into the arena)
         return True
 
-    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz, drop=None):
+    def embedding_backward(self, batch, inv, seq_T, dX, dtar, dz, drop=None, packs=None):
         plan = self.plan
         prep = self.prepare(batch)
         desc, n = prep["desc"], prep["n"]
+        for s in range(len(dX)):                 # (the descriptor is cached on the batch: set both ways every time)
+            pk = packs[s] if packs is not None else None
+            desc.seq_row_off[s] = pk.row_off.data_ptr() if pk is not None else None
+            desc.seq_row_len[s] = self.seq_lens(batch, s).data_ptr() if pk is not None else None
         seeds, keep = drop if drop is not None else ([0] * len(dX), 0.0)
         for s in range(len(dX)):
             desc.seq_drop_seed[s] = seeds[s]

@@ -992,11 +992,29 @@ def attn_core_fwd(q, k, v, q_lens, k_lens, resid, out, H, drop_seed, drop_keep, 
     return None
 
 
-def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal=False):
+def attn_core_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal=False, pack=None):
     B, Tq, d = q.shape
     Tk = k.shape[1]
     if P is not None:
         return _long_attn_bwd(q, k, v, q_lens, k_lens, P, dout, dq, dk, dv, H, drop_seed, drop_keep, causal)
+    if pack is not None:
+        # packed rows ([1, R, .] operands): one launch per length class -- the examples of at most 32 rows take the one-tile kernel
+        rows = Tq
+        for lo, hi, max_len in ((0, pack.n_short, 32), (pack.n_short, pack.B, 0)):
+            if hi <= lo:
+                continue
+            bd = L.AttnBwdDesc()
+            bd.f = _attn_desc(q.dtype, pack.B, H, d // H, pack.T, pack.T, q, k, v, q_lens, k_lens, None, None)
+            bd.f.q_bs = bd.f.k_bs = bd.f.v_bs = 0
+            bd.f.drop_seed, bd.f.drop_keep = int(drop_seed), float(drop_keep)
+            bd.f.row_off, bd.f.ex_list, bd.f.n_list, bd.f.max_len = pack.row_off.data_ptr(), pack.order[lo:].data_ptr(), hi - lo, max_len
+            bd.dout, bd.do_bs, bd.do_rs = dout.data_ptr(), 0, dout.stride(1)
+            bd.dQ, bd.dq_bs, bd.dq_rs = dq.data_ptr(), 0, dq.stride(1)
+            bd.dK, bd.dk_bs, bd.dk_rs = dk.data_ptr(), 0, dk.stride(1)
+            bd.dV, bd.dv_bs, bd.dv_rs = dv.data_ptr(), 0, dv.stride(1)
+            with _Timed("attn", 10.0 * rows * (hi - lo) / pack.B * (rows / pack.B) * d):
+                L.call("dmt_attn_bwd", C.byref(bd), stream_ptr())
+        return
     bd = L.AttnBwdDesc()
     bd.f = _attn_desc(q.dtype, B, H, d // H, Tq, Tk, q, k, v, q_lens, k_lens, None, None)
     bd.f.drop_seed, bd.f.drop_keep = int(drop_seed), float(drop_keep)
@@ -1062,9 +1080,10 @@ class CrossQ1Fn(torch.autograd.Function):
     w / w_leaf / b_leaf are the packed (Q|K|V) kernel and bias of the attention scope, wv_aug its [d, d+8] V block (variables.py)."""
 
     @staticmethod
-    def forward(ctx, q, mem, q_in, k_lens, w: Weight, w_leaf, b_leaf, wv_aug, H, drop_seed, drop_keep):
+    def forward(ctx, q, mem, q_in, k_lens, w: Weight, w_leaf, b_leaf, wv_aug, H, drop_seed, drop_keep, pack=None):
         Bn, d = q.shape
-        T = mem.shape[1]
+        T = mem.shape[1] if pack is None else pack.T        # (packed rows: mem is [1, R, d]; T stays the dense length)
+        rows = mem.shape[0] * mem.shape[1]
         dh = d // H
         dev = q.device
         lp, ld = w.lp, w.lp.stride(0)                      # plain bf16 shadow [d, 3d]
@@ -1075,12 +1094,16 @@ class CrossQ1Fn(torch.autograd.Function):
         dd = L.Q1memDesc()
         dd.B, dd.T, dd.H, dd.d, dd.dh = Bn, T, H, d, dh
         dd.mem, dd.m_bs, dd.m_rs = mem.data_ptr(), mem.stride(0), mem.stride(1)
+        if pack is not None:
+            if k_lens is None or rows != pack.R:
+                raise ValueError("CrossQ1Fn: packed rows need k_lens and the pack's %d rows (got %d)" % (pack.R, rows))
+            dd.m_bs, dd.row_off = 0, pack.row_off.data_ptr()
         dd.k_lens = k_lens.data_ptr() if k_lens is not None else None
         dd.qp, dd.ctx, dd.ctx_hs = qp.data_ptr(), cx.data_ptr(), d + 8
         dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
         if PROFILE is not None:    # algorithmic bytes: the memory rows once, q' in, (ctx | sum P) out
-            PROFILE.setdefault("q1mem_bytes", []).append(float(Bn * T * d * 2 + Bn * H * d * 2 + Bn * H * (d + 8) * 2))
-        with _Timed("q1mem", 4.0 * Bn * H * T * d):
+            PROFILE.setdefault("q1mem_bytes", []).append(float(rows * d * 2 + Bn * H * d * 2 + Bn * H * (d + 8) * 2))
+        with _Timed("q1mem", 4.0 * rows * H * d):
             L.call("dmt_q1mem_fwd", C.byref(dd), stream_ptr())
         # out[:, hc] = (ctx_h | S_h) (Wv[:, hc] ; bv_h) + q_in[:, hc]
         out = torch.empty((Bn, d), dtype=BF16, device=dev)
@@ -1088,6 +1111,7 @@ class CrossQ1Fn(torch.autograd.Function):
              b_bs=dh * wv_aug.stride(0), c_bs=dh, resid_bs=dh)
         ctx.save_for_backward(q, mem, k_lens, qp, cx)
         ctx.w, ctx.leaves, ctx.dims, ctx.desc = w, (w_leaf, b_leaf), (H, d, dh, T), dd
+        ctx.pack, ctx.mem_shape = pack, tuple(mem.shape)
         return out
 
     @staticmethod
@@ -1103,14 +1127,15 @@ class CrossQ1Fn(torch.autograd.Function):
         dctx = torch.empty((Bn, H, d), dtype=BF16, device=dev)
         gemm(dout, d, 1, lp[:, 2 * d:], 1, lp.stride(0), Bn, d, dh, dctx, H * d, batch=H, a_bs=dh, b_bs=dh, c_bs=d)
         dqp = torch.empty((Bn, H, d), dtype=BF16, device=dev)
-        dmem = torch.empty((Bn, T, d), dtype=BF16, device=dev)
+        dmem = torch.empty(ctx.mem_shape, dtype=BF16, device=dev)          # ([B, T, d], or [1, R, d] packed rows: every row is written)
+        rows = ctx.mem_shape[0] * ctx.mem_shape[1]
         dd = ctx.desc
         dd.dctx, dd.dout, dd.do_bs = dctx.data_ptr(), dout.data_ptr(), d
         dd.bv = b_leaf.data_ptr() + 4 * 2 * d
-        dd.dqp, dd.dmem, dd.dm_bs, dd.dm_rs = dqp.data_ptr(), dmem.data_ptr(), T * d, d
+        dd.dqp, dd.dmem, dd.dm_bs, dd.dm_rs = dqp.data_ptr(), dmem.data_ptr(), (0 if ctx.pack is not None else T * d), d
         if PROFILE is not None:    # algorithmic bytes: the memory rows once, d mem written once, q' / d ctx in, d q' out
-            PROFILE.setdefault("q1mem_bytes", []).append(float(2 * Bn * T * d * 2 + 3 * Bn * H * d * 2 + Bn * d * 2))
-        with _Timed("q1mem", 8.0 * Bn * H * T * d):
+            PROFILE.setdefault("q1mem_bytes", []).append(float(2 * rows * d * 2 + 3 * Bn * H * d * 2 + Bn * d * 2))
+        with _Timed("q1mem", 8.0 * rows * H * d):
             L.call("dmt_q1mem_bwd", C.byref(dd), stream_ptr())
         # d Q_h = d q'_h Wk[:, hc]  -> [B, d] bf16   (B operand k-contiguous: the transposed shadow rows d + hc)
         dq = torch.empty((Bn, d), dtype=BF16, device=dev)
@@ -1128,7 +1153,7 @@ class CrossQ1Fn(torch.autograd.Function):
         gemm(cx, 1, H * (d + 8), dout, d, 1, d, dh, Bn, gw[:, 2 * d:], ldg, split_k=split, accumulate=True, batch=H, a_bs=d + 8, b_bs=dh, c_bs=dh)
         gemm(cx[:, :, d:], 1, H * (d + 8), dout, d, 1, 1, dh, Bn, gb[2 * d:], dh, split_k=split, accumulate=True, batch=H, a_bs=d + 8, b_bs=dh,
              c_bs=dh)
-        return dq, dmem, dout, None, None, None, None, None, None, None, None
+        return dq, dmem, dout, None, None, None, None, None, None, None, None, None
 
 
 class SelfAttnBlockFn(torch.autograd.Function):
@@ -1187,8 +1212,9 @@ def mhsa_image_build(wqkv_f32, image):
     L.call("dmt_mhsa_image_build", p(wqkv_f32), wqkv_f32.stride(0), p(image), stream_ptr())
 
 
-def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_keep, want_side=True):
-    """y, s, stats, qkv = fused multihead_attention(x, x, x) + ln (dmt_mhsa_block_fwd); side outputs None when not wanted."""
+def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_keep, want_side=True, pack=None):
+    """y, s, stats, qkv = fused multihead_attention(x, x, x) + ln (dmt_mhsa_block_fwd); side outputs None when not wanted.
+    pack (engine.SeqPack): x is [1, R, d] packed rows, and so are the outputs."""
     B, T, d = x.shape
     dev = x.device
     y = torch.empty((B, T, d), dtype=BF16, device=dev)
@@ -1196,6 +1222,14 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     stats = torch.empty((B * T, 2), dtype=F32, device=dev) if want_side else None
     qkv = torch.empty((B, T, 3 * d), dtype=BF16, device=dev) if want_side else None
     dd = L.MhsaDesc()
+    if pack is not None:
+        rows = T                                    # (x.shape = (1, R, d))
+        if rows != pack.R:
+            raise ValueError("mhsa_block_fwd: %d packed rows given, the pack holds %d" % (rows, pack.R))
+        B, T = pack.B, pack.T                       # the dense dimensions (dropout index)
+        dd.blocks, dd.n_tiles, dd.n_rows = pack.blocks.data_ptr(), pack.n_tiles, pack.R
+    else:
+        rows = B * T
     dd.d_model, dd.num_heads, dd.B, dd.T = d, H, B, T
     dd.x, dd.lens, dd.image = x.data_ptr(), lens.data_ptr(), image.data_ptr()
     dd.bias, dd.gamma, dd.beta, dd.eps = bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
@@ -1203,11 +1237,11 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     dd.s_out, dd.y_out = (s.data_ptr() if s is not None else None), y.data_ptr()
     dd.stats = stats.data_ptr() if stats is not None else None
     dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
-    flops = 2.0 * B * T * d * 3 * d + 4.0 * B * T * T * d
+    flops = 2.0 * rows * d * 3 * d + 4.0 * rows * (T if pack is None else max(1, rows // max(B, 1))) * d
     with _Timed("mhsa_block", flops):
         L.call("dmt_mhsa_block_fwd", C.byref(dd), stream_ptr())
     if PROFILE is not None:
-        PROFILE.setdefault("mhsa_block_bytes", []).append(float(B * T * d * 2 * (3 + (3 if want_side else 0)) + image.numel()))
+        PROFILE.setdefault("mhsa_block_bytes", []).append(float(rows * d * 2 * (3 + (3 if want_side else 0)) + image.numel()))
     return y, s, stats, qkv
 
 
@@ -1216,15 +1250,16 @@ class MhsaBlockFn(torch.autograd.Function):
     launch.  Backward: LayerNorm gradient, attention gradient from the saved (Q | K | V), dx = dqkv Wqkv^T + ds, weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_leaf, b_leaf, w: Weight, gamma, beta, lens, H, image, drop_seed, drop_keep, eps):
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, gamma, beta, lens, H, image, drop_seed, drop_keep, eps, pack=None):
         _chk3(x, "x")
         if not x.is_contiguous():
             x = x.contiguous()
         train = any(ctx.needs_input_grad[:6])
-        y, s, stats, qkv = mhsa_block_fwd(x, lens, image, b_leaf, gamma, beta, eps, H, drop_seed, drop_keep, want_side=train)
+        y, s, stats, qkv = mhsa_block_fwd(x, lens, image, b_leaf, gamma, beta, eps, H, drop_seed, drop_keep, want_side=train, pack=pack)
         if train:
             ctx.save_for_backward(x, qkv, s, stats, lens)
         ctx.w, ctx.leaves, ctx.gb, ctx.H, ctx.drop = w, (w_leaf, b_leaf), (gamma, beta), H, (int(drop_seed), float(drop_keep))
+        ctx.pack = pack
         return y
 
     @staticmethod
@@ -1254,11 +1289,11 @@ class MhsaBlockFn(torch.autograd.Function):
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:]
-        attn_core_bwd(q, k, v, lens, lens, None, ds3, dq, dk, dv, ctx.H, *ctx.drop)
+        attn_core_bwd(q, k, v, lens, lens, None, ds3, dq, dk, dv, ctx.H, *ctx.drop, pack=ctx.pack)
         dz = dqkv.view(M, 3 * d)
         dx = linear_backward_input(dz, ctx.w, resid=ds).view(B, T, d) if ctx.needs_input_grad[0] else None
         dW, dbq = linear_backward_weight(x.view(M, d), dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
-        return dx, dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None
+        return dx, dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

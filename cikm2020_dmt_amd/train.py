@@ -38,7 +38,7 @@ class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
                  dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None,
-                 wgrad320_min_rows=None):
+                 wgrad320_min_rows=None, packed_rows=None):
         """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
         same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
         back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
@@ -64,6 +64,8 @@ class Trainer:
         self.dropout, self.dropout_seed = dropout, dropout_seed
         if fused_mhsa is not None:
             self.engine.use_mhsa = bool(fused_mhsa)
+        if packed_rows is not None:          # (default: on, DMT_PACKED_ROWS; engine.DMTEngine.seq_pack decides per batch and sequence)
+            self.engine.packed_rows = bool(packed_rows)
         if dp_exchange not in ("owner", "allgather"):
             raise ValueError("dp_exchange must be 'owner' or 'allgather'")
         self.dp_exchange = dp_exchange     # how the embedding-gradient rows cross ranks (parallel.py)

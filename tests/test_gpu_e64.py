@@ -57,11 +57,14 @@ def _params(so, seed=11):
     return P
 
 
-def _setup(cuda, dtype, B, seed=5, lengths="ragged", weights="random", dropout=False, dropout_seed=1, fused_mhsa=None):
+def _setup(cuda, dtype, B, seed=5, lengths="ragged", weights="random", dropout=False, dropout_seed=1, fused_mhsa=None, packed_rows=False):
+    """packed_rows False: the dense [B, T, d] layout (what these tests covered before round 5); True: sequences with >= 10 % padding run
+    on their real rows only (engine.SeqPack) -- the same oracle comparison then covers the packed forms of the kernels."""
     so, sp = e64_specs()
     P = _params(so)
     inputs, mask, label = make_batch(sp, B, seed=seed, lengths=lengths, weights=weights)
-    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=dropout, dropout_seed=dropout_seed, fused_mhsa=fused_mhsa)
+    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=dropout, dropout_seed=dropout_seed, fused_mhsa=fused_mhsa,
+                 packed_rows=packed_rows)
     tr.store.load_state(P)
     return so, sp, P, inputs, mask, tr, tr.make_batch(inputs, mask, label)
 
@@ -104,14 +107,18 @@ def _assert_routes(counts, wanted=E64_ROUTES):
 
 
 @pytest.mark.parametrize("B,lengths,weights,fused", [(24, "ragged", "random", True), (24, "full", "ones", True), (352, "ragged", "random", True),
-                                                     (24, "ragged", "random", False), (352, "ragged", "random", False)])
+                                                     (24, "ragged", "random", False), (352, "ragged", "random", False),
+                                                     (24, "ragged", "random", "packed"), (352, "ragged", "random", "packed")])
 def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch, B, lengths, weights, fused):
     """B = 352: the L = 50 sequences have M = 17600 >= WGRAD320_MIN_ROWS rows, so every dispatch rule is the benchmark's own;
     B = 24: the row threshold of the wide-block weight-gradient kernel is lowered so it still runs."""
-    if B * 50 < ops.WGRAD320_MIN_ROWS:
-        monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 1024)
+    packed = fused == "packed"       # "packed": the fused block on packed rows (round 5), against the same oracle
+    if B * 50 < ops.WGRAD320_MIN_ROWS or packed:
+        # (packed rows: about half of B * 50 rows exist -- the wide-block weight-gradient kernel must still be the one that runs)
+        monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 256 if (packed and B * 50 < ops.WGRAD320_MIN_ROWS) else 1024)
     dtype = torch.bfloat16
-    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype, B, lengths=lengths, weights=weights, fused_mhsa=fused)
+    fused = bool(fused)
+    so, sp, P, inputs, mask, tr, batch = _setup(cuda, dtype, B, lengths=lengths, weights=weights, fused_mhsa=fused, packed_rows=packed)
     loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
     if B <= 24:        # the literal numpy restatement agrees with the torch one (the two oracles, at these dims)
         (c2, o2), yb2 = O.inference(inputs, P, so)
@@ -119,7 +126,13 @@ def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch
     with L.route_trace() as rt:
         loss = tr.forward_backward(batch)
         torch.cuda.synchronize()
-    _assert_routes(rt.counts, E64_ROUTES if fused else E64_ROUTES_UNFUSED)
+    if packed:
+        assert all(tr.engine.intermediates["pack_%d" % i] is not None for i in range(3))
+        _assert_routes(rt.counts, tuple(r for r in E64_ROUTES if r != "dmt_mhsa_block_fwd") + ("dmt_mhsa_block_fwd(packed)", "dmt_colsum_rows_packed"))
+        assert rt.counts.get("dmt_mhsa_block_fwd", 0) == 0
+    else:
+        _assert_routes(rt.counts, E64_ROUTES if fused else E64_ROUTES_UNFUSED)
+        assert rt.counts.get("dmt_mhsa_block_fwd(packed)", 0) == 0
     (c, o), yb = tr.last["out"]
     t = TOL[dtype]
     errs = [np.abs(x.detach().float().cpu().numpy() - r).max() for x, r in ((c, c_ref), (o, o_ref), (yb, yb_ref))]

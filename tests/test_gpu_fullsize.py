@@ -182,7 +182,12 @@ def test_full_size_dropout_on_uniform_ids_ragged_lengths(cuda):
     tr.engine.dropout_step_seed = 12345
     X, _tar, _z = tr.engine.gather(tr.make_batch(inputs, mask))
     x0 = X[0]
-    lens = tr.make_batch(inputs, mask).feats[sp["attention_embed_pairs"][0][-1][0]].lens
-    live = (torch.arange(x0.shape[1], device=cuda)[None, :] < lens[:, None])
-    frac = (x0[live] == 0).float().mean().item()
+    if tr.engine._last_packs[0] is not None:
+        # packed rows (engine.SeqPack: this ragged batch has ~50 % padding): every row of [1, R, d] is a live position
+        assert x0.shape[1] == tr.engine._last_packs[0].R
+        frac = (x0 == 0).float().mean().item()
+    else:
+        lens = tr.make_batch(inputs, mask).feats[sp["attention_embed_pairs"][0][-1][0]].lens
+        live = (torch.arange(x0.shape[1], device=cuda)[None, :] < lens[:, None])
+        frac = (x0[live] == 0).float().mean().item()
     assert abs(frac - 0.1) < 2e-3, frac
