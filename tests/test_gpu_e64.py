@@ -102,7 +102,9 @@ def _check_grads(tr, G, dtype, label=""):
 
 
 def _assert_routes(counts, wanted=E64_ROUTES):
-    missing = [r for r in wanted if counts.get(r, 0) == 0]
+    # (a ragged batch runs on packed rows by default -- engine.SeqPack --: the fused block then reports its packed form)
+    alias = {"dmt_mhsa_block_fwd": ("dmt_mhsa_block_fwd(packed)",)}
+    missing = [r for r in wanted if counts.get(r, 0) == 0 and not any(counts.get(a, 0) for a in alias.get(r, ()))]
     assert not missing, "kernels this test claims to cover were not dispatched: %s (took: %s)" % (missing, sorted(counts))
 
 

@@ -147,8 +147,9 @@ def _compare_exact(tr, loss, ref, tol, label):
 @pytest.mark.parametrize("B,lengths,weights,dropout", [(24, "ragged", "random", False), (24, "full", "ones", False), (24, "ragged", "random", True),
                                                        (352, "ragged", "random", False)])
 def test_e64_bf16_every_gradient_within_a_few_percent_of_the_storage_rounding_oracle(cuda, monkeypatch, B, lengths, weights, dropout):
-    if B * 50 < ops.WGRAD320_MIN_ROWS:
-        monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 1024)
+    if B * 50 < ops.WGRAD320_MIN_ROWS or lengths == "ragged":
+        # (ragged: the sequences run on packed rows, about half of B * 50 -- the wide-block weight-gradient kernel must still be the one that runs)
+        monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 256 if (lengths == "ragged" and B < 100) else 1024)
     tr, loss, (P, inputs, mask, so, step_seed) = _run(cuda, B, lengths, weights, dropout)
     ref64 = OT.loss_and_grads(P, inputs, mask, so, step_seed=step_seed, storage="bf16")
     ens = _ensemble(P, inputs, mask, so, step_seed)
