@@ -148,7 +148,19 @@ struct ChainArgs {
   bf16_t* mid_out; long long ld_mid;
   unsigned short* mask;
   int tiles;
+  unsigned long long* trace;   // timing experiments (DBG & 512): per-wavefront cycle sums of the loop's phases, workgroup 0; else null
 };
+
+// shader-cycle stamp (s_memtime; the wait also drains the LDS queue: used only where that queue is empty anyway)
+__device__ __forceinline__ unsigned long long ch_now() {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the lambdas that call this are compiled for the host as well: no device asm there)
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+#else
+  return 0ull;
+#endif
+}
 
 // LDS fragment reads are inline asm on purpose: hipcc makes every LDS access it can see wait vmcnt(0) while an LDS-DMA is in
 // flight (it cannot tell the ring stages apart), which would serialise the weight stream with the multiplies.  LDS returns in
@@ -167,6 +179,8 @@ __device__ __forceinline__ void ch_write128(unsigned addr, u32x4_t v) { asm vola
 template <int N> __device__ __forceinline__ void ch_wait2(bf16x8_t& a, bf16x8_t& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N)); }
 __device__ __forceinline__ void ch_fake(bf16x8_t& r) { asm volatile("" : "=v"(r)); }
 __device__ __forceinline__ void ch_keep(f32x16_t& h) { asm volatile("" : "+v"(h)); }
+__device__ __forceinline__ void ch_keepb(bf16x8_t& h) { asm volatile("" : "+v"(h)); }
+__device__ __forceinline__ void ch_keepu(unsigned& h) { asm volatile("" : "+v"(h)); }
 template <int N> __device__ __forceinline__ void ch_wait8(bf16x8_t (&R)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]) : "i"(N));
 }
@@ -211,8 +225,10 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
   // (h, gate bits: partial-line writes, microseconds under load) retire before it could tell that a stage had landed.  Now a producer
   // never waits on vmcnt in the loop -- the barrier tells it a stage is there -- and the consumers' queue holds ring pieces only.
   constexpr int PER_C = 2 * PER_WAVE;
+  constexpr int PER_C_EFF = (DBG & 2048) ? 10 : PER_C;      // (timing experiment 2048: a 40 KB stage -- what an unpadded image would stream)
   auto issue1 = [&](int buf, int u, int p) {
     if constexpr ((DBG & 1) != 0) return;
+    if constexpr ((DBG & 2048) != 0) { if (p >= PER_C_EFF) return; }
     unsigned char* sb = smem + buf * STAGE + (wave - 4) * 1024 + p * 4096;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rimg, (lds_vp)sb, 16, lane * 16, u * STAGE + (wave - 4) * 1024 + p * 4096, 0, 0);
   };
@@ -251,10 +267,18 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
 
       // top of an iteration, both roles: stage gs has landed (the consumers, which issued its pieces, have seen them retire) and
       // everybody has left stage gs - 1
+      constexpr bool TRACE = (DBG & 1024) != 0;
+      unsigned long long tr_t = 0, tr_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+      if constexpr (TRACE) tr_t = ch_now();
+      auto tr_mark = [&](int ph) {          // phase ph ends here (summed over the stages of a tile; workgroup 0's first tile is reported)
+        if constexpr (TRACE) { const unsigned long long n = ch_now(); tr_acc[ph] += n - tr_t; tr_t = n; }
+      };
       auto top = [&](int u) {
-        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
+        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C_EFF) : "memory");      // at most the pieces of stage gs + 1 are open
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TRACE) tr_mark(0);                                                  // 0: own LDS queue drained (hand-off writes)
         if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
+        if constexpr (TRACE) tr_mark(1);                                                  // 1: barrier
         (void)u;
       };
 
@@ -273,6 +297,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
       }
       unsigned bits_next = 0;
       if constexpr (MODE == DMT_CHAIN_FFN_BWD) bits_next = g.mask[(blk * NJT + 0) * 64 + lane];
+      if constexpr (TRACE) { ch_keepb(X[0]); ch_keepb(X[KC - 1]); tr_mark(5); }     // 5: prologue (rows -> fragments)
 #pragma unroll 1
       for (int u = 0; u < ((DBG & 64) ? 1 : NJT); ++u, ++gs) {
         const int buf = gs % CH_NS;
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
           }
         });
+        if constexpr (TRACE) tr_mark(2);                                                  // 2: fragment reads + MFMA issue
         // ---- mid op on the accumulator: lane (m, hi) holds j = 32 u + 8 q + 4 hi + i in register 4 q + i
         f32x16_t H = Ha;
         if constexpr (MODE == DMT_CHAIN_FFN_LN) {
@@ -355,6 +381,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
         unsigned hb[8], ho[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) hb[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
+        if constexpr (TRACE) { ch_keepu(hb[0]); ch_keepu(hb[7]); tr_mark(3); }   // 3: MFMA drain + mid op + pack
         // hand the tile to the consumer: two B fragments, slot u & 1
         ch_write128(hand_lane + (u & 1) * 2048, u32x4_t{hb[0], hb[1], hb[2], hb[3]});
         ch_write128(hand_lane + (u & 1) * 2048 + 1024, u32x4_t{hb[4], hb[5], hb[6], hb[7]});
@@ -382,10 +409,15 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             }
           }
         }
+        if constexpr (TRACE) tr_mark(4);                                                  // 4: hand-off writes + side-output stores issued
       }
       // (iteration NJT: the consumer multiplies the last mid tile)
       top(NJT);
       ++gs;
+      if constexpr (TRACE) {
+        if (blockIdx.x == 0 && tile == 0 && lane == 0 && g.trace != nullptr)
+          for (int i = 0; i < 6; ++i) g.trace[wave * 8 + i] = tr_acc[i];
+      }
     }
   } else {
     for (int tile = (int)blockIdx.x; tile < g.tiles; tile += G_) {
@@ -397,10 +429,18 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
 
       // top of an iteration, both roles: stage gs has landed (the consumers, which issued its pieces, have seen them retire) and
       // everybody has left stage gs - 1
+      constexpr bool TRACE = (DBG & 1024) != 0;
+      unsigned long long tr_t = 0, tr_acc[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+      if constexpr (TRACE) tr_t = ch_now();
+      auto tr_mark = [&](int ph) {
+        if constexpr (TRACE) { const unsigned long long n = ch_now(); tr_acc[ph] += n - tr_t; tr_t = n; }
+      };
       auto top = [&](int u) {
-        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C) : "memory");      // at most the pieces of stage gs + 1 are open
+        if (!producer) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_C_EFF) : "memory");      // at most the pieces of stage gs + 1 are open
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (TRACE) tr_mark(0);                                                  // 0: my DMA pieces of this stage have landed (vmcnt)
         if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
+        if constexpr (TRACE) tr_mark(1);                                                  // 1: barrier
         (void)u;
       };
 
@@ -444,6 +484,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
           }
         });
       }
+      if constexpr (TRACE) { ch_keep(Y[0]); ch_keep(Y[NOT - 1]); tr_mark(5); }   // 5: prologue (residual rows -> accumulators)
       // (iteration 0: nothing produced yet; the consumer only keeps the ring going)
       top(0);
       {
@@ -502,6 +543,7 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
             else { ch_wait<0>(R1[0], R1[1], R1[2], R1[3], R1[4]); mm(R1, bic); }
           }
         });
+        if constexpr (TRACE) tr_mark(2);                                                  // 2: fragment reads + DMA issue + MFMA issue
       }
 
       // ---- epilogue (consumer): LayerNorm over the row (spread over the lanes m and m + 32), stores
@@ -568,6 +610,11 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
           }
         }
       });
+      if constexpr (TRACE) {
+        tr_mark(3);                                                                       // 3: MFMA drain + epilogue (LayerNorm, stores issued)
+        if (blockIdx.x == 0 && tile == 0 && lane == 0 && g.trace != nullptr)
+          for (int i = 0; i < 6; ++i) g.trace[wave * 8 + i] = tr_acc[i];
+      }
     }
   }
   // the ring runs two stages ahead of the last multiply: let those pieces land before the workgroup (and its LDS) goes away
@@ -586,6 +633,7 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
   a.mid_out = (bf16_t*)d->mid_out; a.ld_mid = d->ld_mid;
   a.mask = (unsigned short*)d->mask;
   a.tiles = (int)cdiv64(d->M, 128);
+  a.trace = nullptr;
   const int grid = a.tiles < 256 ? a.tiles : 256;
 #ifdef DMT_TIMING_EXPERIMENTS   // (scripts/ ablations only: `make EXPERIMENTS=1`; the shipped library reads no environment)
   if constexpr (G::KIN == 320) {
@@ -593,6 +641,26 @@ int launch_chain(const dmt_chain_desc* d, hipStream_t st) {
     const int v = dbg ? atoi(dbg) : 0;
     if (v != 0 && d->mode == DMT_CHAIN_FFN_LN) {
 #define DMT_CHAIN_DBG(V) case V: hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, V>), dim3(grid), dim3(CH_NT), 0, st, a); break;
+      if (v == 2048) { hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 2048>), dim3(grid), dim3(CH_NT), 0, st, a); DMT_CHECK_LAUNCH("dmt_chain2(debug)"); return DMT_OK; }
+      if (v == 1024) {
+        // cycle sums of the loop's phases, per wavefront, of workgroup 0's first tile (printed after the launch: this variant synchronises)
+        static unsigned long long* tr = nullptr;
+        if (tr == nullptr) (void)hipMalloc(&tr, 64 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(tr, 0, 64 * sizeof(unsigned long long), st);
+        a.trace = tr;
+        hipLaunchKernelGGL((chain2_kernel<G, DMT_CHAIN_FFN_LN, 1024>), dim3(grid), dim3(CH_NT), 0, st, a);
+        unsigned long long h[64];
+        (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        static int printed = 0;
+        if (printed++ % 13 == 12) {
+          fprintf(stderr, "chain2 trace (cycles per tile; producer: lgkm | barrier | reads+mfma issue | drain+midop | writes+stores | prologue; consumer: vmcnt | barrier | body | epilogue | - | prologue)\n");
+          for (int w = 0; w < 8; ++w)
+            fprintf(stderr, "  wave %d (%s): %8llu %8llu %8llu %8llu %8llu %8llu\n", w, w < 4 ? "producer" : "consumer", h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2],
+                    h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+        }
+        return DMT_OK;
+      }
       switch (v) {
         DMT_CHAIN_DBG(1) DMT_CHAIN_DBG(2) DMT_CHAIN_DBG(3) DMT_CHAIN_DBG(4) DMT_CHAIN_DBG(8) DMT_CHAIN_DBG(16) DMT_CHAIN_DBG(7) DMT_CHAIN_DBG(11)
         DMT_CHAIN_DBG(15) DMT_CHAIN_DBG(31) DMT_CHAIN_DBG(95) DMT_CHAIN_DBG(223) DMT_CHAIN_DBG(159) DMT_CHAIN_DBG(128) DMT_CHAIN_DBG(130) DMT_CHAIN_DBG(256) DMT_CHAIN_DBG(384)
