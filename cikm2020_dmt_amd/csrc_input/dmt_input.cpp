@@ -11,6 +11,7 @@
 
 #include <string>
 #include <condition_variable>
+#include <algorithm>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -257,6 +258,7 @@ struct dmt_tfrecord_reader {
   int verify;
   std::string path;
   std::vector<uint64_t> offs, lens;   // batch mode: payload offsets / lengths of the records of the current batch
+  uint64_t populated = 0;             // batch mode: bytes [0, populated) of the mapping have been pre-faulted (populate_ahead)
 };
 
 namespace {
@@ -588,8 +590,36 @@ int dmt_parse_batch(const uint8_t* const* payloads, const uint64_t* payload_lens
   return parallel_rows(B, n_threads, [&](int b) { zero_row(cx, b); return parse_one(cx, payloads[b], payload_lens[b], b); });
 }
 
+// Pre-fault the mapping ahead of the header walk, IN PARALLEL: a page of a fresh mapping costs a fault at its first touch, the header
+// walk touches one page per record serially (4 096 faults: ~2 ms of a batch), and 32 parser threads faulting the rest one page at a time
+// queue on the address space's locks -- a serial floor of ~6 ms per 4 096-record batch on the 256-core host (scripts/input_scaling.py:
+// 16 % parallel efficiency at 32 threads).  madvise(MADV_POPULATE_READ) maps a whole range from the page cache in one call; every
+// worker takes a slice of the window.  (Advisory: a kernel without it -- EINVAL -- leaves the lazy faults in place.)
+static void populate_ahead(dmt_tfrecord_reader* r, int n_threads) {
+#ifdef MADV_POPULATE_READ
+  const uint64_t WINDOW = 96ull << 20;                 // >= one batch of the benchmark's records (42 MB) with room to spare
+  if (!r->base || r->populated >= r->size || r->populated >= r->pos + WINDOW / 2) return;
+  const uint64_t lo = r->populated, hi = std::min<uint64_t>(r->size, std::max<uint64_t>(r->pos, lo) + WINDOW);
+  const uint64_t PAGE = 4096;
+  int nt = n_threads < 1 ? 1 : n_threads;
+  const uint64_t pages = (hi - lo + PAGE - 1) / PAGE;
+  if ((uint64_t)nt > pages / 64 + 1) nt = (int)(pages / 64 + 1);
+  const std::function<void(int)> task = [&](int t) {
+    const uint64_t p0 = lo / PAGE + pages * (uint64_t)t / (uint64_t)nt, p1 = lo / PAGE + pages * (uint64_t)(t + 1) / (uint64_t)nt;
+    if (p1 <= p0) return;
+    const uint64_t a = p0 * PAGE, b = std::min<uint64_t>(p1 * PAGE, (r->size + PAGE - 1) / PAGE * PAGE);
+    if (b > a) (void)madvise((void*)(r->base + a), (size_t)(b - a), MADV_POPULATE_READ);
+  };
+  if (nt == 1) task(0); else WorkerPool::get().run(nt, task);
+  r->populated = hi;
+#else
+  (void)r; (void)n_threads;
+#endif
+}
+
 int dmt_tfrecord_parse_batch(dmt_tfrecord_reader* r, int32_t B, const dmt_feature_spec* feats, int32_t n_feats, int32_t n_threads) {
   if (!r || B <= 0 || n_feats < 0 || (n_feats > 0 && !feats)) return fail(DMT_IN_ERR_ARG, "dmt_tfrecord_parse_batch: bad argument");
+  populate_ahead(r, n_threads);
   // serial part: walk up to B record headers; the payload crc and the decode run in the workers, in place on the mapping
   r->offs.clear(); r->lens.clear();
   for (int b = 0; b < B; ++b) {

@@ -132,9 +132,31 @@ class BatchParser:
         self.float_features = list(float_features)
         self.n_threads = n_threads if n_threads > 0 else min(os.cpu_count() or 1, 16)
         self.pinned = False      # set True to get the batch columns in one page-locked buffer (DeviceBatch.from_columns uploads it once)
+        # ring > 0: batches() hands out the SAME `ring` output buffers in turn instead of a fresh one per batch (a fresh 32 MB buffer is
+        # 8 000 first-touch page faults, taken by all parser threads at once, and an munmap when it dies): a batch is then valid until
+        # `ring` more have been produced -- the consumer must have uploaded / copied it by then (DeviceBatch.from_columns does)
+        self.ring = 0
+        self._ring_bufs, self._ring_pos = [], 0
         self._lib = load()
 
     def _alloc(self, B: int):
+        if self.ring > 0:
+            if self._ring_bufs and (self._ring_bufs[0][3] != (B, self.pinned) or len(self._ring_bufs) > self.ring):
+                self._ring_bufs, self._ring_pos = [], 0
+            if len(self._ring_bufs) < self.ring:
+                self._ring_bufs.append(self._alloc_fresh(B) + ((B, self.pinned),))
+                out, specs, keep, _key = self._ring_bufs[-1]
+            else:
+                out, specs, keep, _key = self._ring_bufs[self._ring_pos % self.ring]
+                ev = out["__ring_slot__"].pop("event", None)       # the consumer's asynchronous upload of the batch this buffer held
+                if ev is not None:
+                    ev.synchronize()
+                out["__wts_not_one__"][:] = 0
+            self._ring_pos += 1
+            return out, specs, keep
+        return self._alloc_fresh(B)
+
+    def _alloc_fresh(self, B: int):
         """All output columns of a batch in ONE host buffer (pinned when torch + a GPU are present, so the batch goes up in a single
         asynchronous copy): layout[name] = (byte offset, dtype, shape).  `out` holds numpy views into it."""
         layout, off = {}, 0
@@ -175,6 +197,7 @@ class BatchParser:
             keep.append(nm)
             specs[len(self.id_features) + j] = FeatureSpec(nm, None, n, None, None, None, out[name].ctypes.data, None)
         out["__buffer__"] = (tbuf if tbuf is not None else raw, layout, [f for (f, _v, _t) in self.id_features])
+        out["__ring_slot__"] = {}        # ring mode: DeviceBatch.from_columns leaves the event of its upload here (waited for before reuse)
         return out, specs, keep
 
     def parse(self, payloads: List[bytes]) -> Dict[str, np.ndarray]:

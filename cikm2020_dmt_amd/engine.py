@@ -158,6 +158,12 @@ class DeviceBatch:
             dense = view("features")
             m = view("mask") if "mask" in layout else None
             lb = view("label")[:, 0] if "label" in layout else None
+            slot = cols.get("__ring_slot__")
+            if slot is not None and dbuf.is_cuda:
+                # (BatchParser.ring: the host buffer is reused `ring` batches from now -- not before this copy has read it)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dbuf.device))
+                slot["event"] = ev
             return DeviceBatch(dense.shape[0], feats, dense, m, lb)
         dense = torch.as_tensor(cols["features"]).to(device, non_blocking=True)
         B = dense.shape[0]
