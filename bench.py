@@ -108,6 +108,12 @@ def main():
     from cikm2020_dmt_amd import spec as S
     from cikm2020_dmt_amd.data_feed.synthetic import make_batch
     from cikm2020_dmt_amd.train import Trainer
+    # one process per GPU: each rank keeps to its share of the host's cores (its GPU's NUMA node when sysfs tells) -- launcher, autograd
+    # thread and the input stage's parser pool alike (cikm2020_dmt_amd/parallel.py:pin_rank_to_cores; DMT_PIN_CORES=0: off)
+    cpu_plan = {}
+    if world > 1:
+        from cikm2020_dmt_amd import parallel as _par
+        cpu_plan = _par.pin_rank_to_cores(local_rank if os.environ.get("DMT_BENCH_ONE_DEVICE") != "1" else rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local_rank)
 
     sp = S.e64_spec() if args.dims == "e64" else S.default_spec()
     if args.sku_rows:
@@ -306,6 +312,9 @@ def main():
     }
     # "bound by neither": algorithmic MFMA FLOP of every timed family over the step time against the bf16 dense peak, and the counter
     # HBM bytes of EVERY kernel of a step (profiles/rNN_traffic.json "__all__", same sha rule) against 8 TB/s
+    if cpu_plan:
+        cs = cpu_plan["cores"]
+        out["cpu_affinity_rank0"] = {"n_cores": len(cs), "first": cs[0], "last": cs[-1], "numa_node": cpu_plan.get("numa_node")}
     out["host_enqueue_ms_per_step"] = round(host_dt / args.steps * 1e3, 3)   # < ms_per_step: the host runs ahead, the step is GPU-bound
     step_s = dt / args.steps
     flop_step = sum(f["algorithmic_flop_per_launch"] * f["launches_per_step"] for f in fams if f.get("unit") == "TFLOP/s")

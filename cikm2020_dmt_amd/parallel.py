@@ -230,3 +230,51 @@ def mean_scalar(x: torch.Tensor) -> torch.Tensor:
     y = x.detach().clone()
     dist.all_reduce(y, op=dist.ReduceOp.SUM)
     return y / W
+
+
+def _parse_cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int, device_index: int = None):
+    """CPU plan of one rank of a one-process-per-GPU job: this process -- its Python launcher thread, the autograd thread and the native
+    input stage's parser pool (threads inherit the mask) -- is confined to an equal share of the host's cores, taken from the NUMA node
+    the rank's GPU hangs off when sysfs tells (8 ranks x (launcher + 32 parser threads) otherwise wander over all 256 cores of the host,
+    and a parser thread that lands two sockets away from its page cache and its pinned output buffer pays for it on every record).
+    Returns {"cores": [...], "numa_node": n or None}; a no-op ({}) where sched_setaffinity does not exist.  DMT_PIN_CORES=0 disables."""
+    import os
+    if os.environ.get("DMT_PIN_CORES", "1") == "0" or not hasattr(os, "sched_setaffinity") or local_world < 1:
+        return {}
+    allowed = sorted(os.sched_getaffinity(0))
+    node, node_cores = None, None
+    try:
+        if device_index is not None and torch.cuda.is_available():
+            bdf = torch.cuda.get_device_properties(device_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else None
+            if bdf:
+                path = "/sys/bus/pci/devices/%s/numa_node" % bdf.lower()
+                if os.path.exists(path):
+                    n = int(open(path).read().strip())
+                    if n >= 0:
+                        cl = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read())
+                        node, node_cores = n, [c for c in cl if c in set(allowed)]
+    except Exception:
+        node, node_cores = None, None
+    share = max(1, len(allowed) // local_world)
+    if node_cores and len(node_cores) >= share:
+        # the ranks whose GPUs share this node split ITS cores: position of this rank among them = its index modulo ranks per node
+        per_node = max(1, len(node_cores) // share)
+        k = local_rank % per_node
+        cores = node_cores[k * share:(k + 1) * share]
+    else:
+        cores = allowed[local_rank * share:(local_rank + 1) * share]
+    if not cores:
+        return {}
+    os.sched_setaffinity(0, cores)
+    return {"cores": cores, "numa_node": node}
+
