@@ -103,23 +103,38 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
   const float** s_ctab = reinterpret_cast<const float**>(smem_raw + ((reinterpret_cast<unsigned char*>(s_red + GT * VEC) - smem_raw + 15) & ~15));   // [d_model / VEC]
   int* s_cstr = reinterpret_cast<int*>(s_ctab + (g.d_model / VEC + 1));   // [d_model / VEC]
 
-  // ---- stage indices and weights (coalesced over t)
+  // ---- stage indices and weights (coalesced over t).  The features' descriptor words go through LDS first (round 5): read per LANE from
+  //      the kernel argument -- g.f[f] with f per lane -- they were a chain of dependent vector loads in front of every id
+  __shared__ int sf_T[MAX_GF], sf_rows[MAX_GF], sf_len[MAX_GF];
+  __shared__ const int32_t* sf_idx[MAX_GF];
+  __shared__ const int32_t* sf_idq[MAX_GF];
+  __shared__ const float* sf_wts[MAX_GF];
+  __shared__ const float* sf_table[MAX_GF];
+  __shared__ int sf_stride[MAX_GF], sf_poff[MAX_GF];
+  if (tid < nf) {
+    const GFeat& F = g.f[tid];
+    int len = F.lens ? F.lens[b] : F.T;
+    sf_len[tid] = len < F.T ? len : F.T;
+    sf_T[tid] = F.T; sf_rows[tid] = F.rows; sf_idx[tid] = F.idx; sf_idq[tid] = F.idx_seq; sf_wts[tid] = F.wts;
+    sf_table[tid] = F.table; sf_stride[tid] = F.stride; sf_poff[tid] = F.pooled_off;
+  }
+  __syncthreads();
   for (int i = tid; i < nf * Tmax; i += GT) {
     const int f = i / Tmax, t = i - f * Tmax;
-    const GFeat& F = g.f[f];
-    int len = F.lens ? F.lens[b] : F.T;
-    len = len < F.T ? len : F.T;
+    const int fT = sf_T[f], frows = sf_rows[f];
     int id = 0, idq = 0;
     float w = 0.f;
-    if (t < len) {
-      id = F.idx[(long long)b * F.T + t];
-      id = id < 0 ? 0 : (id >= F.rows ? F.rows - 1 : id);
+    if (t < sf_len[f]) {
+      id = sf_idx[f][(long long)b * fT + t];
+      id = id < 0 ? 0 : (id >= frows ? frows - 1 : id);
       idq = id;
-      if (F.idx_seq) {
-        idq = F.idx_seq[(long long)b * F.T + t];
-        idq = idq < 0 ? 0 : (idq > F.rows ? F.rows : idq);
+      const int32_t* iq = sf_idq[f];
+      if (iq) {
+        idq = iq[(long long)b * fT + t];
+        idq = idq < 0 ? 0 : (idq > frows ? frows : idq);
       }
-      w = F.wts ? F.wts[(long long)b * F.T + t] : 1.f;
+      const float* wp = sf_wts[f];
+      w = wp ? wp[(long long)b * fT + t] : 1.f;
     }
     s_idx[i] = id;
     s_idq[i] = idq;
@@ -210,9 +225,10 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
       int f = 0;
       if (c < g.npc && r < R) {
         f = s_chunkfeat[c];
-        const GFeat& F = g.f[f];
         const int cc = s_chunkcol[c];
-        const int Tf = F.T < Tmax ? F.T : Tmax;
+        const int fT_ = sf_T[f], fstride = sf_stride[f];
+        const float* ftable = sf_table[f];
+        const int Tf = fT_ < Tmax ? fT_ : Tmax;
         // four rows in flight, branch-free (w == 0 for padding / past-the-end steps; their ids are valid rows)
         for (int t0 = r; t0 < Tf; t0 += 4 * R) {
           float v[4][VEC], w[4];
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
             const int t = t0 + u * R;
             const int tc = t < Tf ? t : Tf - 1;
             w[u] = t < Tf ? s_w[f * Tmax + tc] : 0.f;
-            ld_row<VEC>(F.table + (long long)s_idx[f * Tmax + tc] * F.stride + cc, v[u]);
+            ld_row<VEC>(ftable + (long long)s_idx[f * Tmax + tc] * fstride + cc, v[u]);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
@@ -236,13 +252,12 @@ __global__ __launch_bounds__(GT) void gather_group_kernel(const GGroup g) {
       }
       __syncthreads();
       if (r == 0 && c < g.npc) {
-        const GFeat& F = g.f[f];
         const float ws = s_wsum[f];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
           float s = 0.f;
           for (int rr = 0; rr < R; ++rr) s += s_red[(rr * CP + (tid % CP)) * VEC + k];
-          stf<OutT>(prow + F.pooled_off + s_chunkcol[c] + k, ws != 0.f ? s / ws : 0.f);
+          stf<OutT>(prow + sf_poff[f] + s_chunkcol[c] + k, ws != 0.f ? s / ws : 0.f);
         }
       }
     }
@@ -274,8 +289,18 @@ struct KeysArgs {
 
 __global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_desc d, uint32_t* __restrict__ keys,
                                                            uint32_t* __restrict__ vals, long long n) {
+  // per-feature words of the descriptor, staged once per workgroup (round 5): read per LANE from the kernel argument -- d.feat[f] with f
+  // per lane -- they were eight dependent vector loads in front of every thread's two useful ones: 170-300 us for 30 MB of traffic
   __shared__ int s_base[DMT_MAX_FEATURES + 1];
+  __shared__ int s_T[DMT_MAX_FEATURES], s_po[DMT_MAX_FEATURES], s_rows[DMT_MAX_FEATURES], s_rb[DMT_MAX_FEATURES];
+  __shared__ const int32_t* s_lens[DMT_MAX_FEATURES];
+  __shared__ const int32_t* s_idx[DMT_MAX_FEATURES];
   if (threadIdx.x <= d.n_features) s_base[threadIdx.x] = d.entry_base[threadIdx.x];
+  if (threadIdx.x < d.n_features) {
+    const dmt_gather_feature& F = d.feat[threadIdx.x];
+    s_T[threadIdx.x] = F.T; s_po[threadIdx.x] = F.pooled_off; s_rows[threadIdx.x] = F.rows; s_rb[threadIdx.x] = d.row_base[threadIdx.x];
+    s_lens[threadIdx.x] = F.lens; s_idx[threadIdx.x] = F.idx;
+  }
   __syncthreads();
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -288,25 +313,26 @@ __global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_des
     }
     f = lo_;
   }
-  const dmt_gather_feature& F = d.feat[f];
+  const int fT = s_T[f], frows = s_rows[f];
   uint32_t r = (uint32_t)(e - s_base[f]);            // (entry counts are below 2^31: entry_base is int32)
-  const uint32_t per = (uint32_t)d.B * (uint32_t)F.T;
+  const uint32_t per = (uint32_t)d.B * (uint32_t)fT;
   int kind = 0;
-  if (F.pooled_off >= 0) {
+  if (s_po[f] >= 0) {
     if (r >= per) { kind = 1; r -= per; }
   } else {
     kind = 1;
   }
-  const int b = (int)(r / (uint32_t)F.T), t = (int)(r - (uint32_t)b * (uint32_t)F.T);
-  int len = F.lens ? F.lens[b] : F.T;
+  const int b = (int)(r / (uint32_t)fT), t = (int)(r - (uint32_t)b * (uint32_t)fT);
+  const int32_t* lens = s_lens[f];
+  int len = lens ? lens[b] : fT;
   uint32_t key = (uint32_t)d.total_rows;
   if (t < len) {
-    int id = F.idx[(long long)b * F.T + t];
-    id = id < 0 ? 0 : (id >= F.rows ? F.rows - 1 : id);
+    int id = s_idx[f][(long long)b * fT + t];
+    id = id < 0 ? 0 : (id >= frows ? frows - 1 : id);
     if (kind == 0)
-      key = (uint32_t)(d.row_base[f] + id);
+      key = (uint32_t)(s_rb[f] + id);
     else if (id > 0)
-      key = (uint32_t)(d.row_base[f] + id - 1);
+      key = (uint32_t)(s_rb[f] + id - 1);
   }
   keys[e] = key;
   vals[e] = (uint32_t)e;
