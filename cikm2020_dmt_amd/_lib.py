@@ -173,6 +173,7 @@ _SIGS = {
     "dmt_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_colsum": [c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i32, c_vp],
     "dmt_colsum_drop": [c_i32, c_i64, c_i64, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
+    "dmt_gemm_dw_batched": [C.POINTER(GemmDesc), c_i32, c_vp],
     "dmt_colsum_rows_packed": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, C.c_uint32, c_f32, c_i32, c_vp],
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
     "dmt_confusion_counts": [c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //     the latency of its operand stream, i.e. by the bytes in flight per CU: <64, 2> keeps one 32 KB stage in flight per
 //     workgroup, <32, 4> three 16 KB stages.
 template <int BKS, int NS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dw_glds_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_dw_glds_body(const GemmArgs& g, const int bid, const int G) {
   constexpr int OPB = BKS * 256;     // bytes of one operand image: [BKS k][128 rows] bf16
   constexpr int STAGE = 2 * OPB;     // A image | B image
   constexpr int RND = BKS / 16;      // DMA rounds per operand and stage (a round = 16 k rows = 4 per wave)
@@ -1005,9 +1005,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   const T* Ag = reinterpret_cast<const T*>(g.A);
   const T* Bg = reinterpret_cast<const T*>(g.B);
-  const int G = (int)gridDim.x;
   // issue cursor: runs NS-1 k-steps ahead of the compute cursor through the same (tile, k-step) sequence, across tile ends
-  int iL = (int)blockIdx.x, ik = 0, ik_end = 0, istage = 0, inflight = 0;
+  int iL = bid, ik = 0, ik_end = 0, istage = 0, inflight = 0;
   bool ivalid = false;
   __amdgpu_buffer_rsrc_t ira = rsrc_of(Ag, g.a_cs, 0, M_real), irb = rsrc_of(Bg, g.b_rs, 0, g.N);
   auto itile = [&]() {
@@ -1032,7 +1031,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0) issue_next();
   int cur = 0;
-  for (int L = (int)blockIdx.x; L < g.total_blocks; L += G) {
+  for (int L = bid; L < g.total_blocks; L += G) {
     const TileCoord t = decode_tile(g, L);
     if (!t.valid) continue;
     const int m0 = t.m0, n0 = t.n0, ks = t.ks;
@@ -1088,6 +1087,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     (void)ks;
   }
+}
+
+template <int BKS, int NS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dw_glds_kernel(const GemmArgs g) {
+  gemm_dw_glds_body<BKS, NS>(g, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several reduction GEMMs of this class in ONE launch (dmt_gemm_dw_batched): the B-row weight gradients of a decoder -- six launches
+// of 13-17 us on one lane, each alone on a chip it cannot fill (8-50 workgroups) -- run side by side.  The jobs travel in the kernel
+// argument (no table in memory, no copy); workgroup b belongs to the job whose range [start[j], start[j + 1]) holds it and walks that
+// job's work ids from its local position with the job's own stride.
+constexpr int DW_MAX_JOBS = 12;
+struct DwJobs {
+  int n;
+  int start[DW_MAX_JOBS + 1];
+  GemmArgs job[DW_MAX_JOBS];
+};
+static_assert(sizeof(DwJobs) <= 3800, "the job pack travels in the kernel argument segment (4 KB)");
+
+template <int BKS, int NS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_dw_glds_jobs_kernel(const DwJobs p) {
+  const int b = (int)blockIdx.x;
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < p.n && b >= p.start[j + 1]) ++j;
+  gemm_dw_glds_body<BKS, NS>(p.job[j], b - p.start[j], p.start[j + 1] - p.start[j]);
 }
 
 template <typename T>
@@ -1213,7 +1238,10 @@ int pick_mode(const void* P, long long rs, long long cs, int esz, int epv) {
 
 }  // namespace
 
-extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
+enum GemmRoute { GR_GENERIC = 0, GR_SMALL = 1, GR_DW_GLDS = 2, GR_GLDS = 3 };
+
+// descriptor -> kernel arguments + the kernel that takes them (shared by dmt_gemm and dmt_gemm_dw_batched)
+static int gemm_prepare(const dmt_gemm_desc* d, GemmArgs& g, int& route, long long& nblk_out) {
   DMT_CHECK_ARG(d != nullptr, "dmt_gemm: null descriptor");
   DMT_CHECK_ARG(d->in_dtype == DMT_F32 || d->in_dtype == DMT_BF16, "dmt_gemm: bad in_dtype");
   DMT_CHECK_ARG(d->out_dtype == DMT_F32 || d->out_dtype == DMT_BF16, "dmt_gemm: bad out_dtype");
@@ -1226,7 +1254,6 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   DMT_CHECK_ARG(!d->a_ones_row || d->c_last != nullptr, "dmt_gemm: a_ones_row needs c_last");
   DMT_CHECK_ARG(!d->a_ones_row || d->M >= 2, "dmt_gemm: a_ones_row needs M >= 2");
   DMT_CHECK_ARG(d->in_dtype == d->out_dtype || d->out_dtype == DMT_F32, "dmt_gemm: bf16 output needs bf16 operands");
-  GemmArgs g;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.A = d->A; g.a_rs = d->a_rs; g.a_cs = d->a_cs;
   g.B = d->B; g.b_rs = d->b_rs; g.b_cs = d->b_cs;
@@ -1254,8 +1281,6 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   const long long nblk = 8ll * g.inner * ((g.panels + 7) / 8);
   DMT_CHECK_ARG(nblk < 0x7FFFFFFFll, "dmt_gemm: grid too large");
   g.total_blocks = (int)nblk;
-  dim3 grid((unsigned)(nblk < PERSIST_GRID ? nblk : PERSIST_GRID));
-  hipStream_t st = (hipStream_t)stream;
   // vectorised epilogue: bf16 in/out, no split / ones row, every row of C / gate / resid 16-byte aligned
   auto al16 = [](const void* q, long long ld, long long bs) { return q == nullptr || (((uintptr_t)q) % 16 == 0 && ld % 8 == 0 && bs % 8 == 0); };
   g.vec_epi = (d->in_dtype == DMT_BF16 && d->out_dtype == DMT_BF16 && split == 1 && !d->accumulate && !d->a_ones_row && al16(d->C, d->ldc, d->c_bs) &&
@@ -1278,6 +1303,21 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   const bool dw_glds = d->in_dtype == DMT_BF16 && g.out_f32 && g.a_mode == 1 && g.b_mode == 1 && g.fast_ok &&
                        (d->K % 64 == 0) && d->bias == nullptr && d->gate == nullptr && d->resid == nullptr && d->act_ncols == 0;
   const bool small = small_shape && !glds && !dw_glds;
+  route = small ? GR_SMALL : (dw_glds ? GR_DW_GLDS : (glds ? GR_GLDS : GR_GENERIC));
+  nblk_out = nblk;
+  return DMT_OK;
+}
+
+extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
+  GemmArgs g;
+  int route = GR_GENERIC;
+  long long nblk = 0;
+  const int prc = gemm_prepare(d, g, route, nblk);
+  if (prc != DMT_OK) return prc;
+  const int split = g.split_k, batch = g.batch;
+  const bool small = route == GR_SMALL, dw_glds = route == GR_DW_GLDS, glds = route == GR_GLDS;
+  dim3 grid((unsigned)(nblk < PERSIST_GRID ? nblk : PERSIST_GRID));
+  hipStream_t st = (hipStream_t)stream;
   if (small) {
     // the attribute belongs to the (function, device) pair: set it on every device this process launches from (a host-side table
     // lookup per call after the first; no process-wide flag that a second GPU or a second host thread could find already set)
@@ -1318,3 +1358,37 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
   DMT_CHECK_LAUNCH("dmt_gemm");
   return DMT_OK;
 }
+
+// n reduction GEMMs of the weight-gradient class (bf16 operands with the reduction dimension as their ROW index, fp32 C, K % 64 == 0,
+// no bias / relu / gate / residual: what dmt_gemm routes to gemm_dw_glds_kernel<64, 2>) in one launch.  All or nothing: a descriptor of
+// another class makes the call fail with DMT_ERR_UNSUPPORTED before anything is launched (the caller then launches them one by one).
+// Two jobs must not write the same elements of C unless both accumulate (then they meet in fp32 atomics, like the splits of one job).
+extern "C" int dmt_gemm_dw_batched(const dmt_gemm_desc* descs, int32_t n, void* stream) {
+  DMT_CHECK_ARG(descs != nullptr && n > 0, "dmt_gemm_dw_batched: no jobs");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < n; j0 += DW_MAX_JOBS) {
+    DwJobs p;
+    p.n = (n - j0) < DW_MAX_JOBS ? (n - j0) : DW_MAX_JOBS;
+    int at = 0;
+    for (int j = 0; j < p.n; ++j) {
+      int route = GR_GENERIC;
+      long long nblk = 0;
+      const int prc = gemm_prepare(&descs[j0 + j], p.job[j], route, nblk);
+      if (prc != DMT_OK) return prc;
+      const long long kps = (long long)descs[j0 + j].K / (p.job[j].split_k > 1 ? p.job[j].split_k : 1);
+      if (route != GR_DW_GLDS || kps > 4096) {
+        dmt_set_error("dmt_gemm_dw_batched: job %d (M %d, N %d, K %d) is not of the B-row weight-gradient class", j0 + j, descs[j0 + j].M, descs[j0 + j].N, descs[j0 + j].K);
+        return DMT_ERR_UNSUPPORTED;
+      }
+      const int nb = (int)(nblk < GL_GRID ? nblk : GL_GRID);
+      p.start[j] = at;
+      at += nb;
+    }
+    p.start[p.n] = at;
+    for (int j = p.n + 1; j <= DW_MAX_JOBS; ++j) p.start[j] = at;
+    hipLaunchKernelGGL((gemm_dw_glds_jobs_kernel<64, 2>), dim3((unsigned)at), dim3(NT), 0, st, p);
+    DMT_CHECK_LAUNCH("dmt_gemm_dw_batched");
+  }
+  return DMT_OK;
+}
+

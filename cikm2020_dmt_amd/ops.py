@@ -124,8 +124,62 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
         byt = nb * ((M * K + K * N) * esz + M * N * osz * max(split_k, 1))
         byt += nb * M * N * esz * ((gate is not None) + (resid is not None))
         PROFILE.setdefault("gemm_bytes", []).append(float(byt))
+    if (_state.dw_batch is not None and accumulate and A.dtype == BF16 and out.dtype == F32 and a_cs != 1 and b_rs != 1 and K % 64 == 0
+            and K // max(split_k, 1) <= 4096 and bias is None and act_ncols == 0 and gate is None and resid is None and not DETERMINISTIC):
+        # a B-row weight gradient accumulated into the gradient arena: nothing reads it before the optimizer, so it waits for the others
+        # of its stream and leaves with them in one launch (flush_dw_batches; dmt_gemm_dw_batched)
+        st = torch.cuda.current_stream(A.device)
+        lst = _state.dw_batch.setdefault(st, [])
+        lst.append((d, (A, Bm, out, c_last), 2.0 * M * N * K * max(batch, 1)))
+        if len(lst) >= DW_BATCH_MAX:
+            _flush_dw_stream(st)
+        return
     with _Timed("gemm_%s" % ("bf16" if A.dtype == BF16 else "f32"), 2.0 * M * N * K * max(batch, 1)):
         L.call("dmt_gemm", C.byref(d), stream_ptr())
+
+
+DW_BATCH_MAX = 12          # jobs per launch (the job pack travels in the kernel argument: csrc/dmt_gemm.hip DW_MAX_JOBS)
+
+
+def begin_dw_batching():
+    """From now on the B-row weight-gradient GEMMs that accumulate into the gradient arena are COLLECTED per stream and launched together
+    (flush_dw_batches()): a decoder's six of them are 13-17 us launches on a chip none of them fills."""
+    _state.dw_batch = {}
+
+
+def _flush_dw_stream(st):
+    lst = _state.dw_batch.pop(st, None) if _state.dw_batch is not None else None
+    if not lst:
+        return 0
+    n = len(lst)
+    arr = (L.GemmDesc * n)(*[d for (d, _keep, _w) in lst])
+    with torch.cuda.stream(st):
+        with _Timed("gemm_bf16", sum(w for (_d, _k, w) in lst)):
+            rc = L.load().dmt_gemm_dw_batched(arr, n, stream_ptr())
+            if rc == L.DMT_ERR_UNSUPPORTED:          # (a job of another class slipped in: one by one, any class)
+                for (d, _keep, _w) in lst:
+                    L.call("dmt_gemm", C.byref(d), stream_ptr())
+            else:
+                L.check(rc, "dmt_gemm_dw_batched")
+        for (_d, keep, _w) in lst:                   # (the operands may have been allocated on another stream)
+            for t in keep:
+                if t is not None and t.is_cuda:
+                    t.record_stream(st)
+    return n
+
+
+def flush_dw_batches(end=False):
+    """Launch what begin_dw_batching() collected, every stream's jobs on that stream; -> the streams that got a launch.  end: stop
+    collecting."""
+    if _state.dw_batch is None:
+        return []
+    out = []
+    for st in list(_state.dw_batch.keys()):
+        if _flush_dw_stream(st):
+            out.append(st)
+    if end:
+        _state.dw_batch = None
+    return out
 
 
 def _pick_split(tiles: int, red: int) -> int:
@@ -230,7 +284,7 @@ class StepState:
     Trainers with different deferral needs in one process do not see each other's (round-3 review: these were module globals).  The
     autograd engine runs backward on its own thread: the active state is a module-level pointer, not a thread-local -- steps of
     different Trainers may alternate in one process, they may not run concurrently."""
-    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws", "unit_loss_grad")
+    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws", "unit_loss_grad", "dw_batch")
 
     def __init__(self, wgrad320_min_rows=None):
         self.deferred = None          # list of closures while the step collects its long-row weight gradients
@@ -239,6 +293,7 @@ class StepState:
         self.wgrad320_min_rows = wgrad320_min_rows      # None: the module default above (tests lower it)
         self.mmoe_ws = {}             # device -> workspace of the split expert kernels (_mmoe_workspace)
         self.unit_loss_grad = False   # Trainer.forward_backward: the loss's incoming gradient is exactly 1 (no scaling launch)
+        self.dw_batch = None          # stream -> [(GemmDesc, operands kept alive)] while B-row weight gradients are being batched
 
     def min_rows(self):
         return WGRAD320_MIN_ROWS if self.wgrad320_min_rows is None else self.wgrad320_min_rows
@@ -746,6 +801,10 @@ class FFNLNChainFn(torch.autograd.Function):
         x2, s, stats, h, mask = ctx.saved_tensors
         M, d = x2.shape
         geo = ctx.chain["geo"]
+        if _state.dw_batch is not None and M >= _state.min_rows():
+            # an encoder's backward begins on this lane: the decoder's B-row weight gradients collected so far leave now, in one launch,
+            # in front of the long kernels (at the very end of backward they would sit beside the HBM-bound embedding tail)
+            _flush_dw_stream(torch.cuda.current_stream(x2.device))
         dy2 = dy.reshape(-1, d)
         if dy2.stride(-1) != 1:
             dy2 = dy2.contiguous()

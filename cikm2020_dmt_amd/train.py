@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -64,6 +65,7 @@ class Trainer:
         self.dropout, self.dropout_seed = dropout, dropout_seed
         if fused_mhsa is not None:
             self.engine.use_mhsa = bool(fused_mhsa)
+        self.batch_dw = os.environ.get("DMT_BATCH_DW", "1") == "1"      # B-row weight gradients of the one-GPU backward: one launch per lane
         if packed_rows is not None:          # (default: on, DMT_PACKED_ROWS; engine.DMTEngine.seq_pack decides per batch and sequence)
             self.engine.packed_rows = bool(packed_rows)
         if dp_exchange not in ("owner", "allgather"):
@@ -485,6 +487,12 @@ class Trainer:
             if pool:
                 fork_lane = pool[-1]
                 ops.begin_fork_wgrads(fork_lane, self.store.leaves["mmoe_layers/l0_cat_weights"].offset)
+        # one-GPU step: the B-row weight gradients (decoders, MMoE, towers: 25 launches of 13-17 us that accumulate into the gradient arena
+        # and that nothing reads before the optimizer) are collected per lane and leave in one launch each (ops.flush_dw_batches below).
+        # In a data-parallel step the arena's tail is all-reduced from the dL/dz hook while backward runs: they stay in place there.
+        batch_dw = (not dp) and self.batch_dw and self.device.type == "cuda"
+        if batch_dw:
+            ops.begin_dw_batching()
         try:
             # d loss / d loss = 1: a cached scalar instead of the ones_like() fill autograd would launch, and the loss kernel's saved
             # logit gradients are handed on as they are (ops.StepState.unit_loss_grad) instead of through a `* 1` launch
@@ -504,6 +512,13 @@ class Trainer:
         finally:
             self.engine.defer_sparse = False
             forked = ops.end_fork_wgrads()
+            if batch_dw and sys.exc_info()[0] is not None:
+                self.engine.step_state.dw_batch = None         # (a step that raised: drop what it collected)
+        if batch_dw:
+            cur = torch.cuda.current_stream(self.device)
+            for st in ops.flush_dw_batches(end=True):
+                if st != cur:
+                    cur.wait_stream(st)                         # the batched weight gradients are part of this backward
         if fork_lane is not None and forked is not None and forked["n"]:
             torch.cuda.current_stream(self.device).wait_stream(fork_lane)     # the forked weight gradients are part of this backward
         self.n_forked = forked["n"] if forked is not None else 0

@@ -245,6 +245,12 @@ typedef struct {
 } dmt_gemm_desc;
 
 int dmt_gemm(const dmt_gemm_desc* d, void* stream);
+/* revision 5: n GEMMs of the weight-gradient class -- C[M, N] (fp32) (+)= A^T B with bf16 operands whose ROW index is the reduction
+ * dimension (a_cs != 1, b_rs != 1 in the descriptor's terms: dW = X^T dY), K % 64 == 0, K / split_k <= 4096, no epilogue -- in ONE launch
+ * (the decoders' B-row weight gradients: six 15 us launches per sequence, none of which fills the chip).  All or nothing:
+ * DMT_ERR_UNSUPPORTED when a descriptor is of another class (nothing has been launched then).  Jobs that write the same elements of C must
+ * all have `accumulate` set.                                                                                                            */
+int dmt_gemm_dw_batched(const dmt_gemm_desc* descs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Short-sequence multi-head attention core (one wavefront per (example, head)).
