@@ -197,12 +197,15 @@ __global__ __launch_bounds__(DW_NT, 2) void wgrad320_kernel(const DwArgs g) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(DW_PPW) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // ... and for all of them; everybody has left stage s - 1, whose buffer stage s + 2 refills
+    // The fragment reads go out FIRST, the ring's refill behind them (round 5): an LDS-DMA instruction holds its wavefront 100-300 cycles
+    // at issue -- with the five of them in front, the reads' round trip started only after ~1000 cycles in which this wavefront offered
+    // the matrix pipe nothing; now the reads are in flight under the DMA issue.
     // (past the last stage the pieces fall outside the descriptors' range and read as zero into a buffer nobody multiplies)
-    issue(buf == 0 ? 2 : buf - 1, s + 2);
     const unsigned so = (unsigned)buf * DW_STAGE;
     KFrag f0, f1;
     rd(f0, so, std::integral_constant<int, 0>{});
     rd(f1, so, std::integral_constant<int, 1>{});
+    issue(buf == 0 ? 2 : buf - 1, s + 2);
     dw_wait<14>(f0);
     mm(f0);
     dw_wait<0>(f1);
