@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--law", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--lengths", default="full", choices=["full", "ragged"], help="sequence lengths of the synthetic batches: full = every history at its "
                     "maximum (the headline, roofline runs); ragged = len ~ U{1..L} per example and sequence (SURVEY.md section 8d variant (ii))")
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd", "adagrad", "adadelta", "rmsprop", "ftrl"],
+                    help="get_optimizer branch (model/inference_mlp.py:264-280); the metric is quoted on adam (dmt.conf:70)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the train-mode dropout of the reference (0.1 / 0.5)")
     ap.add_argument("--long-seq", type=int, default=0, help="BASELINE long-seq variant: click / order histories of this length (e.g. 200) instead of 50")
@@ -124,14 +126,14 @@ def main():
         seq_lens = {grp[0][0]: args.long_seq for grp in sp["attention_embed_pairs"][:2]}
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tr = Trainer(sp, device=dev, compute_dtype=cdt, seed=1234, dropout=not args.no_dropout, force_dp=force_dp,
-                 table_layout="sharded" if args.shard_tables else "replicated", attn_dtype=args.attn_dtype)
+                 table_layout="sharded" if args.shard_tables else "replicated", attn_dtype=args.attn_dtype, optimizer=args.optimizer)
     nb = max(2, args.fresh_batches)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:      # (numpy releases the GIL: ~0.15 s per batch on 8 threads)
         raw = list(ex.map(lambda i: make_batch(sp, args.batch, seed=20200101 + 1000 * rank + i, lengths=args.lengths, law=args.law, seq_lens=seq_lens), range(nb)))
     batches = [tr.make_batch(inputs, mask, label) for (inputs, mask, label) in raw]
     del raw
-    age_info = age_tables(tr, sp, args, seq_lens) if args.age_tables > 0 else None
+    age_info = age_tables(tr, sp, args, seq_lens) if args.age_tables > 0 and args.optimizer == "adam" else None
 
     def barrier():
         if world > 1:
@@ -254,7 +256,7 @@ def main():
     # (the newest committed counter file whose kernel-source sha is this build's: profiles/rNN_traffic.json)
     import glob
     default_cfg = (args.dims == "e64" and args.dtype == "bf16" and args.batch == 4096 and not args.long_seq and not args.shard_tables and not args.sku_rows
-                   and args.fresh_batches == 64 and args.age_tables == 100000 and args.lengths == "full")
+                   and args.fresh_batches == 64 and args.age_tables == 100000 and args.lengths == "full" and args.optimizer == "adam")
     tj, traffic_stale, tname = {}, None, None
     if default_cfg:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")), reverse=True)
@@ -298,14 +300,15 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "full DMT train step (3 seq-Transformers + MMoE + bias tower, CTR+CTVR), %s dims d_model=%d d_ff=%d heads=%d, "
-                               "per-GPU batch %d, L=%s %s%s, %s ids over %s/500/12k/190k/230k vocab%s, TF-Adam (exact lazy rows), train-mode dropout %s, "
+                               "per-GPU batch %d, L=%s %s%s, %s ids over %s/500/12k/190k/230k vocab%s, %s, train-mode dropout %s, "
                                "%d distinct resident batches, tables %s"
                                % (args.dims, sp["d_model"], sp["d_ff"], sp["num_heads"], args.batch, ("%d/%d/10" % (args.long_seq, args.long_seq)) if args.long_seq else "50/50/10", "full" if args.lengths == "full" else "ragged (len ~ U{1..L})",
                                   (" (flash-style attention kernels, %s MFMA forward%s)" % (args.attn_dtype, ": e4m3 attention DOES NOT MEET north_star's 1e-4 AUC bar (BASELINE.md section 5)" if args.attn_dtype == "fp8" else "")) if args.long_seq > 64 else "", args.law,
                                   ("%dM" % (args.sku_rows // 1000000)) if args.sku_rows >= 1000000 else ("%d" % args.sku_rows if args.sku_rows else "5M"),
                                   " (tables ROW-SHARDED over the ranks: %.1f GB of table+Adam state per rank)" % (tr.store.tab_p.numel() * 12 / 1e9) if args.shard_tables else "",
+                                  "TF-Adam (exact lazy rows)" if args.optimizer == "adam" else "tf.train %s (sparse rows, lazily decayed slots)" % args.optimizer,
                                   "off" if args.no_dropout else "on (0.1 Transformer / 0.5 bias tower)", max(2, args.fresh_batches),
-                                  ("pre-aged to step %d (per-row last-touch gaps from the id law: the lazy Adam replays them)" % args.age_tables) if args.age_tables > 0 else "fresh (nothing for the lazy Adam to replay)"),
+                                  ("pre-aged to step %d (per-row last-touch gaps from the id law: the lazy Adam replays them)" % args.age_tables) if args.age_tables > 0 and args.optimizer == "adam" else "fresh (nothing for the lazy rows to replay)"),
                    "global_batch": args.batch * world, "parallelism": ("dp%d" % world) + (" + row-sharded tables" if args.shard_tables else "") + (" (forced exchange path, one-rank RCCL group)" if force_dp else "")},
         "step_phases_ms": phases(diag, steps_k, world, tr), "lazy_adam": age_info,
         "roofline": roofline, "other_mfma_kernels": [f for f in fams if f["key"] != roofline.get("key")], "gather_roofline": gather, "final_loss": round(float(loss), 5),

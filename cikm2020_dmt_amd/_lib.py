@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdmt_hip.so")
 
 DMT_F32, DMT_BF16, DMT_FP8_E4M3 = 0, 1, 2
+DMT_OPT_SGD, DMT_OPT_ADAGRAD, DMT_OPT_ADADELTA, DMT_OPT_RMSPROP, DMT_OPT_FTRL = 1, 2, 3, 4, 5
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
@@ -165,6 +166,10 @@ _SIGS = {
     "dmt_rows_stamp": [C.POINTER(TableMap), c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "dmt_adam_flush_rows": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp],
     "dmt_adam_rebase": [c_vp, c_vp, c_i64, c_vp],
+    "dmt_opt_dense": [c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
+    "dmt_opt_sparse_rows": [c_i32, C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32, c_i32, c_f32, c_f32,
+                            c_f32, c_f32, c_vp],
+    "dmt_opt_flush_rows": [c_i32, C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_vp],
     "dmt_rows_gather": [C.POINTER(TableMap), c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],

@@ -444,3 +444,238 @@ extern "C" int dmt_rows_gather(const dmt_table_map* tm, const float* p, const ui
   DMT_CHECK_LAUNCH("dmt_rows_gather");
   return DMT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The other five optimizers get_optimizer can return (model/inference_mlp.py:264-280), with the constructor defaults TF 1.12 gives
+// them (the reference passes the learning rate only).  One update function per kind, shared by the dense sweep, the sparse-row
+// update and the replay of zero-gradient steps, as for Adam above.  What a zero-gradient step does to an element, per kind:
+//   sgd, adagrad       nothing (the accumulator only grows by g*g);
+//   ftrl               recomputes var from (accum, linear): the value it already holds for a row that has been updated before, and
+//                      ZERO for a row that never has (linear == 0): the reference's dense ApplyFtrl wipes every table row the first
+//                      step does not touch -- dmt_opt_flush_rows after the first step does the same;
+//   rmsprop            ms decays by `decay`, mom = momentum * mom = 0 (the default momentum 0.0 is the only one built): var unchanged;
+//   adadelta           accum and accum_update decay by rho: var unchanged.
+// So var never needs a replay before it is READ (no catch-up in front of the gather); rmsprop / adadelta replay the decay of their
+// slots when the row is next UPDATED (or flushed): serially for up to DMT_OPT_EXACT_TAIL steps (bit-identical to the dense sweep),
+// in closed form beyond.
+namespace {
+
+struct OptHP { float lr, h0, h1, h2; };
+constexpr int DMT_OPT_EXACT_TAIL = 64;
+
+template <int KIND>
+__device__ __forceinline__ void opt_update(float& p, float& s0, float& s1, float g, const OptHP& hp) {
+  if constexpr (KIND == DMT_OPT_SGD) {                  // ApplyGradientDescent: var -= grad * lr
+    p = fmaf(-hp.lr, g, p);
+  } else if constexpr (KIND == DMT_OPT_ADAGRAD) {       // ApplyAdagrad: accum += g*g; var -= g * lr * rsqrt(accum)
+    s0 = fmaf(g, g, s0);
+    p = fmaf(-(g * hp.lr), __builtin_amdgcn_rsqf(s0), p);
+  } else if constexpr (KIND == DMT_OPT_ADADELTA) {      // ApplyAdadelta (rho = h0, epsilon = h1)
+    s0 = fmaf(s0, hp.h0, g * g * (1.f - hp.h0));
+    const float upd = __builtin_amdgcn_sqrtf(s1 + hp.h1) * __builtin_amdgcn_rsqf(s0 + hp.h1) * g;
+    p = fmaf(-hp.lr, upd, p);
+    s1 = fmaf(s1, hp.h0, upd * upd * (1.f - hp.h0));
+  } else if constexpr (KIND == DMT_OPT_RMSPROP) {       // ApplyRMSProp (decay = h0, momentum = 0, epsilon = h2): s1 is `mom`
+    s0 = fmaf(fmaf(g, g, -s0), 1.f - hp.h0, s0);
+    s1 = (g * hp.lr) * __builtin_amdgcn_rsqf(s0 + hp.h2);
+    p -= s1;
+  } else {                                              // ApplyFtrl, learning_rate_power = -0.5 (l1 = h0, l2 = h1): s0 accum, s1 linear
+    const float na = fmaf(g, g, s0);
+    const float rs = __builtin_amdgcn_sqrtf(na);
+    const float sigma = (rs - __builtin_amdgcn_sqrtf(s0)) / hp.lr;
+    s1 += g - sigma * p;
+    const float quad = rs / hp.lr + 2.f * hp.h1;
+    const float x = (s1 > 0.f ? hp.h0 : -hp.h0) - s1;
+    p = fabsf(s1) > hp.h0 ? x / quad : 0.f;
+    s0 = na;
+  }
+}
+
+__device__ __forceinline__ float decay_k(float x, float r, int k) {
+  int i = 0;
+  for (; i < k && i < DMT_OPT_EXACT_TAIL; ++i) x *= r;
+  if (i < k) x *= pow_int(r, k - i);
+  return x;
+}
+
+// k zero-gradient steps on the slots of one element (var is not touched by any of them, see above)
+template <int KIND>
+__device__ __forceinline__ void opt_idle(float& s0, float& s1, int k, const OptHP& hp) {
+  if (k <= 0) return;
+  if constexpr (KIND == DMT_OPT_ADADELTA) {
+    s0 = decay_k(s0, hp.h0, k);
+    s1 = decay_k(s1, hp.h0, k);
+  } else if constexpr (KIND == DMT_OPT_RMSPROP) {
+    int i = 0;
+    for (; i < k && i < DMT_OPT_EXACT_TAIL; ++i) s0 = fmaf(-s0, 1.f - hp.h0, s0);    // ms += (0 - ms) * (1 - decay)
+    if (i < k) s0 *= pow_int(hp.h0, k - i);
+    s1 = 0.f;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_dense_kernel(long long n, float* __restrict__ p, float* __restrict__ s0, float* __restrict__ s1,
+                                                        const float* __restrict__ g, float gscale, OptHP hp, bf16_t* __restrict__ lp) {
+  constexpr bool U0 = KIND != DMT_OPT_SGD, U1 = KIND == DMT_OPT_ADADELTA || KIND == DMT_OPT_RMSPROP || KIND == DMT_OPT_FTRL;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float pv = p[i], a = U0 ? s0[i] : 0.f, b = U1 ? s1[i] : 0.f;
+    opt_update<KIND>(pv, a, b, g[i] * gscale, hp);
+    p[i] = pv;
+    if (U0) s0[i] = a;
+    if (U1) s1[i] = b;
+    if (lp) lp[i] = f2bf(pv);
+  }
+}
+
+// as adam_sparse_kernel: a 16-lane group per distinct row, 16-byte pieces
+template <int KIND, typename GT>
+__global__ __launch_bounds__(256) void opt_sparse_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ s0,
+                                                         float* __restrict__ s1, int* __restrict__ last_step,
+                                                         const uint32_t* __restrict__ uniq, const int* __restrict__ n_uniq,
+                                                         const GT* __restrict__ grad_rows, int max_dim, float gscale, int step, OptHP hp) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+  const long long n = n_uniq[0];
+  const long long groups = (long long)gridDim.x * 16;
+  for (long long u = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + grp; u < n; u += groups) {
+    const int row = (int)uniq[u];
+    if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables]) continue;
+    const int t = find_table(tm, row);
+    const int dim = tm.dim[t];
+    if (!tm_owned(tm, row)) continue;
+    const int lsi = row / tm_sw(tm);
+    const int idle = step - 1 - last_step[lsi];
+    const long long base = tm_elem(tm, t, row, dim);
+    const GT* gr = grad_rows + u * max_dim;
+    if ((dim & 3) == 0 && (max_dim & 3) == 0) {
+      for (int j = c * 4; j < dim; j += 64) {
+        float4 pv = ld4(p + base + j), a = ld4(s0 + base + j), b = ld4(s1 + base + j);
+        const float4 gv = ldg4(gr + j);
+        opt_idle<KIND>(a.x, b.x, idle, hp); opt_idle<KIND>(a.y, b.y, idle, hp); opt_idle<KIND>(a.z, b.z, idle, hp); opt_idle<KIND>(a.w, b.w, idle, hp);
+        opt_update<KIND>(pv.x, a.x, b.x, gv.x * gscale, hp);
+        opt_update<KIND>(pv.y, a.y, b.y, gv.y * gscale, hp);
+        opt_update<KIND>(pv.z, a.z, b.z, gv.z * gscale, hp);
+        opt_update<KIND>(pv.w, a.w, b.w, gv.w * gscale, hp);
+        st4(p + base + j, pv); st4(s0 + base + j, a); st4(s1 + base + j, b);
+      }
+    } else {
+      for (int j = c; j < dim; j += 16) {
+        float pv = p[base + j], a = s0[base + j], b = s1[base + j];
+        opt_idle<KIND>(a, b, idle, hp);
+        opt_update<KIND>(pv, a, b, ldg1(gr + j) * gscale, hp);
+        p[base + j] = pv; s0[base + j] = a; s1[base + j] = b;
+      }
+    }
+    if (c == 0) last_step[lsi] = step;
+  }
+}
+
+// every local row brought to `step` (a wavefront per row): slots decayed (rmsprop / adadelta); ftrl: rows never updated are zeroed
+template <int KIND>
+__global__ __launch_bounds__(256) void opt_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ s0,
+                                                        float* __restrict__ s1, int* __restrict__ last_step, int step, OptHP hp,
+                                                        long long n_local) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (long long lsi = (long long)blockIdx.x * 4 + wv; lsi < n_local; lsi += (long long)gridDim.x * 4) {
+    const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
+    if (row >= tm.row_base[tm.n_tables]) break;
+    const int last = last_step[lsi];
+    if (last >= step) continue;
+    const int t = find_table(tm, (int)row);
+    const int dim = tm.dim[t];
+    for (int j = lane; j < dim; j += 64) {
+      const long long off = tm_elem(tm, t, row, dim) + j;
+      if constexpr (KIND == DMT_OPT_FTRL) {
+        if (last == 0) p[off] = 0.f;
+      } else {
+        float a = s0[off], b = s1[off];
+        opt_idle<KIND>(a, b, step - last, hp);
+        s0[off] = a; s1[off] = b;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) last_step[lsi] = step;
+  }
+}
+
+template <int KIND>
+int opt_dense_launch(int64_t n, float* p, float* s0, float* s1, const float* g, float gscale, OptHP hp, void* lp, hipStream_t st) {
+  long long nb = cdiv64(n, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(opt_dense_kernel<KIND>, dim3((unsigned)nb), dim3(256), 0, st, (long long)n, p, s0, s1, g, gscale, hp, (bf16_t*)lp);
+  DMT_CHECK_LAUNCH("dmt_opt_dense");
+  return DMT_OK;
+}
+
+template <int KIND>
+int opt_sparse_launch(const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, const uint32_t* uniq, const int32_t* n_uniq,
+                      int32_t max_uniq, const void* rows, int bf16, int32_t max_dim, float gscale, int32_t step, OptHP hp, hipStream_t st) {
+  const long long need = cdiv64(max_uniq, 16);
+  const unsigned nb = (unsigned)(need < SPARSE_GRID ? need : SPARSE_GRID);
+  if (bf16)
+    hipLaunchKernelGGL((opt_sparse_kernel<KIND, bf16_t>), dim3(nb), dim3(256), 0, st, *tm, p, s0, s1, last_step, uniq, n_uniq,
+                       reinterpret_cast<const bf16_t*>(rows), max_dim, gscale, step, hp);
+  else
+    hipLaunchKernelGGL((opt_sparse_kernel<KIND, float>), dim3(nb), dim3(256), 0, st, *tm, p, s0, s1, last_step, uniq, n_uniq,
+                       reinterpret_cast<const float*>(rows), max_dim, gscale, step, hp);
+  DMT_CHECK_LAUNCH("dmt_opt_sparse_rows");
+  return DMT_OK;
+}
+
+template <int KIND>
+int opt_flush_launch(const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, int32_t step, OptHP hp, hipStream_t st) {
+  const long long total = tm->row_base[tm->n_tables];
+  const long long n_local = tm->shard_w > 1 ? cdiv64(total, tm->shard_w) : total;
+  long long nb = cdiv64(n_local, 4);
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(opt_flush_kernel<KIND>, dim3((unsigned)nb), dim3(256), 0, st, *tm, p, s0, s1, last_step, step, hp, n_local);
+  DMT_CHECK_LAUNCH("dmt_opt_flush_rows");
+  return DMT_OK;
+}
+
+bool opt_kind_ok(int kind) { return kind >= DMT_OPT_SGD && kind <= DMT_OPT_FTRL; }
+
+}  // namespace
+
+#define DMT_OPT_DISPATCH(kind, CALL)                                  \
+  switch (kind) {                                                     \
+    case DMT_OPT_SGD: return CALL(DMT_OPT_SGD);                       \
+    case DMT_OPT_ADAGRAD: return CALL(DMT_OPT_ADAGRAD);               \
+    case DMT_OPT_ADADELTA: return CALL(DMT_OPT_ADADELTA);             \
+    case DMT_OPT_RMSPROP: return CALL(DMT_OPT_RMSPROP);               \
+    default: return CALL(DMT_OPT_FTRL);                               \
+  }
+
+extern "C" int dmt_opt_dense(int32_t kind, int64_t n, float* p, float* s0, float* s1, const float* g, float grad_scale, float lr, float h0,
+                             float h1, float h2, void* lp_bf16, void* stream) {
+  DMT_CHECK_ARG(opt_kind_ok(kind), "dmt_opt_dense: unknown optimizer kind");
+  DMT_CHECK_ARG(n > 0 && p && s0 && s1 && g, "dmt_opt_dense: bad argument");
+  const OptHP hp{lr, h0, h1, h2};
+#define CALL(K) opt_dense_launch<K>(n, p, s0, s1, g, grad_scale, hp, lp_bf16, (hipStream_t)stream)
+  DMT_OPT_DISPATCH(kind, CALL)
+#undef CALL
+}
+
+extern "C" int dmt_opt_sparse_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step,
+                                   const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const void* grad_rows,
+                                   int32_t grad_is_bf16, int32_t max_dim, float grad_scale, int32_t step, float lr, float h0, float h1,
+                                   float h2, void* stream) {
+  DMT_CHECK_ARG(opt_kind_ok(kind), "dmt_opt_sparse_rows: unknown optimizer kind");
+  DMT_CHECK_ARG(tm && p && s0 && s1 && last_step && uniq_keys && n_uniq && grad_rows, "dmt_opt_sparse_rows: null argument");
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && max_uniq > 0 && step > 0, "dmt_opt_sparse_rows: bad table map / max_uniq / step");
+  DMT_CHECK_ARG(!grad_is_bf16 || (max_dim % 4 == 0 && ((uintptr_t)grad_rows & 7) == 0), "dmt_opt_sparse_rows: bf16 rows must be 8-byte aligned, max_dim % 4 == 0");
+  const OptHP hp{lr, h0, h1, h2};
+#define CALL(K) opt_sparse_launch<K>(tm, p, s0, s1, last_step, uniq_keys, n_uniq, max_uniq, grad_rows, grad_is_bf16, max_dim, grad_scale, step, hp, (hipStream_t)stream)
+  DMT_OPT_DISPATCH(kind, CALL)
+#undef CALL
+}
+
+extern "C" int dmt_opt_flush_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, int32_t step,
+                                  float h0, float h1, float h2, void* stream) {
+  DMT_CHECK_ARG(opt_kind_ok(kind), "dmt_opt_flush_rows: unknown optimizer kind");
+  DMT_CHECK_ARG(tm && p && s0 && s1 && last_step && step >= 0, "dmt_opt_flush_rows: bad argument");
+  const OptHP hp{0.f, h0, h1, h2};
+#define CALL(K) opt_flush_launch<K>(tm, p, s0, s1, last_step, step, hp, (hipStream_t)stream)
+  DMT_OPT_DISPATCH(kind, CALL)
+#undef CALL
+}

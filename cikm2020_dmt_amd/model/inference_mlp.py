@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 
 from .. import ops
-from ..optim import TFAdam
+from ..optim import TFSlotOptimizer, make_optimizer
 from . import runtime as R
 
 
@@ -108,7 +108,7 @@ class Inference(object):
 
     def get_optimizer(self, optimizer, learning_rate):
         print("Use the optimizer: {}".format(optimizer))
-        if optimizer == "adam":
-            return TFAdam(self.rt.store, learning_rate)
+        if optimizer == "adam" or optimizer in TFSlotOptimizer.KINDS:
+            return make_optimizer(optimizer, self.rt.store, learning_rate)
         print("Unknow optimizer, exit now")
-        raise SystemExit(1)                          # inference_mlp.py:278-280 (only adam is configured / implemented)
+        raise SystemExit(1)                          # inference_mlp.py:278-280

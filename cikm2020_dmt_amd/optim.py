@@ -200,3 +200,141 @@ class TFAdam:
             sl = slice(info.offset, info.offset + info.numel)
             L.call("dmt_adam_dense", info.numel, ops.p(s.tab_p[sl]), ops.p(s.tab_m[sl]), ops.p(s.tab_v[sl]), ops.p(g), float(grad_scale),
                    ops.p(self.state), self.b1, self.b2, self.eps, None, ops.stream_ptr())
+
+
+class TFSlotOptimizer:
+    """tf.train.{GradientDescent, Adagrad, Adadelta, RMSProp, Ftrl}Optimizer(learning_rate) -- the other branches of get_optimizer
+    (model/inference_mlp.py:264-280), each with TF 1.12's constructor defaults since the reference passes the learning rate only
+    (include/dmt_hip.h: dmt_opt_*, oracle/dmt_oracle.py:TFOptimizer).  Same calling sequence as TFAdam (the Trainer drives either).
+
+    None of these moves a variable at a zero-gradient step (FTRL: after the first step, see below), so the embedding rows need no
+    catch-up in front of the gather: catch_up / catch_up_early / stamp_rows are no-ops, and the slots' idle decay (rmsprop, adadelta)
+    is replayed when the row is next updated or flushed.  FTRL's dense update zeroes every element whose gradient has been zero so far
+    (linear == 0 -> var = 0): the reference, which densifies the embedding gradients (run_dnn.py:45-80), wipes every table row the
+    first batch did not read.  end() of the first step after the slots were (re)initialised does the same."""
+    KINDS = {"sgd": L.DMT_OPT_SGD, "adagrad": L.DMT_OPT_ADAGRAD, "adadelta": L.DMT_OPT_ADADELTA, "rmsprop": L.DMT_OPT_RMSPROP,
+             "ftrl": L.DMT_OPT_FTRL}
+    HP = {"sgd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 0.0), "adadelta": (0.95, 1e-8, 0.0), "rmsprop": (0.9, 0.0, 1e-10),
+          "ftrl": (0.0, 0.0, 0.0)}
+    SLOT0_INIT = {"adagrad": 0.1, "ftrl": 0.1, "rmsprop": 1.0}
+
+    def __init__(self, kind, store, learning_rate=(0.001, 0.0001), step_boundary=(300000000,)):
+        if kind not in self.KINDS:
+            raise ValueError("unknown optimizer %r" % (kind,))
+        self.kind, self.code, self.hp = kind, self.KINDS[kind], self.HP[kind]
+        self.store = store
+        self.lrs = list(learning_rate) if isinstance(learning_rate, (list, tuple)) else [float(learning_rate)]
+        self.bounds = list(step_boundary)[: len(self.lrs) - 1]
+        self.global_step = 0
+        self._step_base = 0
+        self._begun = self._applied = False
+        self._broken = None
+        self.stamp = None
+        self.tm = store.fill_table_map(L.TableMap())
+        self._init_slots()
+
+    current_lr = TFAdam.current_lr
+
+    def _init_slots(self):
+        s = self.store
+        v0 = self.SLOT0_INIT.get(self.kind, 0.0)
+        for t in (s.adam_m, s.tab_m):
+            t.fill_(v0)
+        for t in (s.adam_v, s.tab_v, s.last_step):
+            t.zero_()
+
+    def begin(self):
+        if self._begun:
+            return
+        if self._broken is not None:
+            raise RuntimeError(self._broken)
+        self._applied = False
+        self._begun = True
+
+    def end(self):
+        first = self.step_in_flight() == 1
+        self.global_step += 1
+        self._begun = False
+        if first and self.kind == "ftrl":
+            self.flush_tables()
+
+    def abort_step(self):
+        if not self._begun:
+            return
+        self._begun = False
+        if self._applied:
+            self._broken = ("TFSlotOptimizer: a step failed after its parameter update had been enqueued (step %d); the optimizer state "
+                            "cannot be rolled back -- restore from a checkpoint" % (self.global_step + 1))
+
+    def step_in_flight(self) -> int:
+        assert self._begun
+        return self.global_step - self._step_base + 1
+
+    def stamp_rows(self, uniq, n_uniq, cap):
+        pass
+
+    def catch_up(self, uniq, n_uniq, cap):
+        pass
+
+    def catch_up_early(self, uniq, n_uniq, cap, to_step: int):
+        pass
+
+    def apply_dense(self, grad_scale: float = 1.0):
+        s = self.store
+        self._applied = True
+        L.call("dmt_opt_dense", self.code, s.P, ops.p(s.params), ops.p(s.adam_m), ops.p(s.adam_v), ops.p(s.grads), float(grad_scale),
+               float(self.current_lr()), *self.hp, None, ops.stream_ptr())
+
+    def apply_sparse(self, sparse, grad_scale: float = 1.0):
+        s = self.store
+        uniq, n_uniq, grad_rows, cap = sparse
+        if int(cap) == 0:
+            return
+        self._applied = True
+        L.call("dmt_opt_sparse_rows", self.code, C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(grad_rows), int(grad_rows.dtype == torch.bfloat16), int(grad_rows.shape[1]),
+               float(grad_scale), self.step_in_flight(), float(self.current_lr()), *self.hp, ops.stream_ptr())
+
+    def step(self, sparse=None, grad_scale: float = 1.0):
+        self.begin()
+        self.apply_dense(grad_scale)
+        if sparse is not None:
+            self.apply_sparse(sparse, grad_scale)
+        self.end()
+        self.store.refresh_shadows()
+
+    def flush_tables(self):
+        """Every row's slots brought to the last completed step (FTRL: never-updated rows zeroed), before a checkpoint / export."""
+        s = self.store
+        L.call("dmt_opt_flush_rows", self.code, C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
+               self.global_step - self._step_base, *self.hp, ops.stream_ptr())
+
+    def reset_slots(self, global_step: int = 0):
+        """As TFAdam.reset_slots: the reference's Saver keeps no slots (run_dnn.py:258-261); global_step keeps driving the schedule."""
+        self._init_slots()
+        self.global_step = int(global_step)
+        self._step_base = int(global_step)
+        self._begun = False
+
+    def rebase(self):
+        pass
+
+    def apply_dense_tables(self, dense_grads: dict, grad_scale: float = 1.0):
+        """Test hook (as TFAdam.apply_dense_tables): the literal dense sweep over whole tables, between begin() and end()."""
+        s = self.store
+        for name, g in dense_grads.items():
+            info = s.tables[name]
+            sl = slice(info.offset, info.offset + info.numel)
+            L.call("dmt_opt_dense", self.code, info.numel, ops.p(s.tab_p[sl]), ops.p(s.tab_m[sl]), ops.p(s.tab_v[sl]), ops.p(g),
+                   float(grad_scale), float(self.current_lr()), *self.hp, None, ops.stream_ptr())
+            base, nr = s.table_rows[name]
+            s.last_step[base: base + nr] = self.step_in_flight()        # (swept densely: nothing pending on these rows)
+
+
+def make_optimizer(name, store, learning_rate=(0.001, 0.0001), step_boundary=(300000000,), max_steps=1 << 20):
+    """get_optimizer(optimizer, learning_rate) (model/inference_mlp.py:264-280) on the flat arenas."""
+    if name == "adam":
+        return TFAdam(store, learning_rate, step_boundary, max_steps=max_steps)
+    if name in TFSlotOptimizer.KINDS:
+        return TFSlotOptimizer(name, store, learning_rate, step_boundary)
+    raise ValueError("Unknow optimizer %r (sgd, adadelta, adagrad, adam, ftrl, rmsprop)" % (name,))

@@ -17,7 +17,7 @@ import torch
 from . import _lib as L
 from . import ops, parallel, streams
 from .engine import DeviceBatch, DMTEngine
-from .optim import TFAdam
+from .optim import make_optimizer
 from .variables import VariableStore
 
 
@@ -39,7 +39,7 @@ class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
                  dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None,
-                 wgrad320_min_rows=None, packed_rows=None):
+                 wgrad320_min_rows=None, packed_rows=None, optimizer: str = "adam"):
         """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
         same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
         back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
@@ -57,7 +57,8 @@ class Trainer:
         self.engine.step_state = ops.StepState(wgrad320_min_rows)
         # BASELINE configs[4]: the long-sequence (64 < T <= 256) attention forward of THIS trainer multiplies in OCP e4m3
         self.engine.kopts = ops.KernelOptions(attn_mma_fp8=(attn_dtype == "fp8"))
-        self.opt = TFAdam(self.store, learning_rate, step_boundary, max_steps=max_steps)
+        # get_optimizer(optimizer, learning_rate) (model/inference_mlp.py:264-280): adam (dmt.conf:70) or one of the other five
+        self.opt = make_optimizer(optimizer, self.store, learning_rate, step_boundary, max_steps=max_steps)
         self.last = {}
         self.diag = None       # dict: train_step brackets its phases with HIP events (key -> [(start, end)]); bench.py's step_phases_ms
         # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in

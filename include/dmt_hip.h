@@ -420,6 +420,30 @@ int dmt_adam_flush_rows(const dmt_table_map* tm, float* p, float* m, float* v, i
 /* After dmt_adam_flush_rows: restart the device-side step counter that indexes lr_hist (state[3] = 0, last_step[:] = 0), so a run
  * longer than the history's capacity -- or one resumed from model.ckpt-<large N> -- keeps going.  Values are untouched. */
 int dmt_adam_rebase(float* state, int32_t* last_step, int64_t rows, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * The other optimizers get_optimizer returns (model/inference_mlp.py:264-280: sgd, adadelta, adagrad, ftrl, rmsprop), each with the
+ * constructor defaults of TF 1.12 (the reference passes the learning rate only); see oracle/dmt_oracle.py:TFOptimizer.
+ *   kind      s0                     s1                   h0           h1            h2
+ *   SGD       -                      -                    -            -             -
+ *   ADAGRAD   accumulator (init 0.1) -                    -            -             -
+ *   ADADELTA  accum                  accum_update         rho 0.95     epsilon 1e-8  -
+ *   RMSPROP   rms (init 1.0)         momentum (== 0.0)    decay 0.9    momentum 0.0  epsilon 1e-10
+ *   FTRL      accum (init 0.1)       linear               l1 0.0       l2 0.0        -          (learning_rate_power -0.5)
+ * s0 / s1 always point at storage (the Adam slot arenas are reused); lr is this step's learning rate, `step` the 1-based local step
+ * number that indexes last_step (0 = never updated).  Sparse rows: the zero-gradient steps last_step[row]+1 .. step-1 are replayed on
+ * the slots (they never move var, so nothing has to run in front of the gather), then step `step` is applied.  dmt_opt_flush_rows
+ * brings every row's slots to `step`; for FTRL it zeroes the rows that have never been updated -- what the reference's dense
+ * ApplyFtrl does to them at its first step (linear == 0 -> var = 0): call it after the first step.
+ * ------------------------------------------------------------------------------------------------ */
+enum { DMT_OPT_SGD = 1, DMT_OPT_ADAGRAD = 2, DMT_OPT_ADADELTA = 3, DMT_OPT_RMSPROP = 4, DMT_OPT_FTRL = 5 };
+int dmt_opt_dense(int32_t kind, int64_t n, float* p, float* s0, float* s1, const float* g, float grad_scale, float lr, float h0,
+                  float h1, float h2, void* lp_bf16, void* stream);
+int dmt_opt_sparse_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step,
+                        const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq, const void* grad_rows,
+                        int32_t grad_is_bf16, int32_t max_dim, float grad_scale, int32_t step, float lr, float h0, float h1,
+                        float h2, void* stream);
+int dmt_opt_flush_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, int32_t step,
+                       float h0, float h1, float h2, void* stream);
 /* Row-sharded tables, owner side of the forward exchange: out[u, :] = p[row keys[u]] for u < n (fp32, row stride max_dim, columns
  * past the table's dim zeroed; keys this rank does not own give zero rows).  The all-to-all that answers the index exchange of
  * BASELINE configs[3] sends these rows back to the ranks that asked for them (replaces the /cpu:0 embedding_lookup of base.py:81-91

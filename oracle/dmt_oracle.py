@@ -593,6 +593,64 @@ class TFAdam:
         self.b2p = self.b2p * self.b2
 
 
+class TFOptimizer:
+    """The other optimizers get_optimizer returns (model/inference_mlp.py:264-280), built with the learning rate only, so every other
+    hyper-parameter is TF 1.12's constructor default; applied DENSELY to every variable (run_dnn.py:203-207 on the densified
+    gradients of run_dnn.py:45-80).  Arithmetic of tensorflow==1.12 core/kernels/training_ops.cc (un-vendored):
+      sgd       ApplyGradientDescent   var -= lr * g
+      adagrad   ApplyAdagrad           accum (init 0.1) += g*g;  var -= lr * g / sqrt(accum)
+      adadelta  ApplyAdadelta          rho 0.95, epsilon 1e-8:  accum = rho accum + (1-rho) g*g;
+                                       update = sqrt(accum_update + eps) / sqrt(accum + eps) * g;  var -= lr * update;
+                                       accum_update = rho accum_update + (1-rho) update^2
+      rmsprop   ApplyRMSProp           decay 0.9, momentum 0.0, epsilon 1e-10, rms slot init 1.0:
+                                       ms += (g*g - ms) (1-decay);  mom = momentum mom + lr g / sqrt(ms + eps);  var -= mom
+      ftrl      ApplyFtrl              learning_rate_power -0.5, initial_accumulator_value 0.1, l1 = l2 = 0:
+                                       new = accum + g*g;  linear += g - (sqrt(new) - sqrt(accum)) / lr * var;
+                                       var = (sign(linear) l1 - linear) / (sqrt(new) / lr + 2 l2) if |linear| > l1 else 0;  accum = new
+                                       (so an element whose gradient has been zero at every step so far -- an embedding row no batch
+                                        has read -- becomes ZERO at the first step: that is what the reference's dense update does)
+    """
+    KINDS = ("sgd", "adagrad", "adadelta", "rmsprop", "ftrl")
+
+    def __init__(self, kind, lr, dtype=np.float64):
+        assert kind in self.KINDS, kind
+        self.kind, self.dt, self.lr = kind, dtype, dtype(lr)
+        self.s0, self.s1 = {}, {}
+
+    def apply(self, P: Dict[str, np.ndarray], G: Dict[str, np.ndarray]):
+        dt, lr, kind = self.dt, self.lr, self.kind
+        for k, g in G.items():
+            g = g.astype(dt)
+            if k not in self.s0:
+                init0 = {"adagrad": 0.1, "ftrl": 0.1, "rmsprop": 1.0}.get(kind, 0.0)
+                self.s0[k] = np.full_like(P[k], init0, dtype=dt)
+                self.s1[k] = np.zeros_like(P[k], dtype=dt)
+            a, b = self.s0[k], self.s1[k]
+            if kind == "sgd":
+                P[k] -= (lr * g).astype(P[k].dtype)
+            elif kind == "adagrad":
+                a += g * g
+                P[k] -= (lr * g / np.sqrt(a)).astype(P[k].dtype)
+            elif kind == "adadelta":
+                rho, eps = dt(0.95), dt(1e-8)
+                a[...] = rho * a + (dt(1) - rho) * g * g
+                upd = np.sqrt(b + eps) / np.sqrt(a + eps) * g
+                P[k] -= (lr * upd).astype(P[k].dtype)
+                b[...] = rho * b + (dt(1) - rho) * upd * upd
+            elif kind == "rmsprop":
+                decay, eps = dt(0.9), dt(1e-10)
+                a += (g * g - a) * (dt(1) - decay)
+                b[...] = lr * g / np.sqrt(a + eps)                 # momentum 0.0
+                P[k] -= b.astype(P[k].dtype)
+            else:
+                l1, l2 = dt(0.0), dt(0.0)
+                new = a + g * g
+                b += g - (np.sqrt(new) - np.sqrt(a)) / lr * P[k].astype(dt)
+                quad = np.sqrt(new) / lr + dt(2) * l2
+                P[k][...] = np.where(np.abs(b) > l1, (np.sign(b) * l1 - b) / quad, dt(0)).astype(P[k].dtype)
+                a[...] = new
+
+
 # --------------------------------------------------------------------------------------------- metrics
 def tf_metrics_auc(labels, predictions, num_thresholds=200):
     """tf.metrics.auc(curve='ROC', summation_method='trapezoidal') as used at run_dnn.py:228-241
