@@ -169,7 +169,7 @@ _SIGS = {
     "dmt_opt_dense": [c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp],
     "dmt_opt_sparse_rows": [c_i32, C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_f32, c_i32, c_f32, c_f32,
                             c_f32, c_f32, c_vp],
-    "dmt_opt_flush_rows": [c_i32, C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_vp],
+    "dmt_opt_flush_rows": [c_i32, C.POINTER(TableMap), c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp],
     "dmt_rows_gather": [C.POINTER(TableMap), c_vp, c_vp, c_i64, c_vp, c_i32, c_vp],
     "dmt_cast_bf16": [c_i64, c_vp, c_vp, c_vp],
     "dmt_cast_transpose_bf16": [c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],

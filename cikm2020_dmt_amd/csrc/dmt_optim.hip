@@ -450,9 +450,11 @@ extern "C" int dmt_rows_gather(const dmt_table_map* tm, const float* p, const ui
 // them (the reference passes the learning rate only).  One update function per kind, shared by the dense sweep, the sparse-row
 // update and the replay of zero-gradient steps, as for Adam above.  What a zero-gradient step does to an element, per kind:
 //   sgd, adagrad       nothing (the accumulator only grows by g*g);
-//   ftrl               recomputes var from (accum, linear): the value it already holds for a row that has been updated before, and
-//                      ZERO for a row that never has (linear == 0): the reference's dense ApplyFtrl wipes every table row the first
-//                      step does not touch -- dmt_opt_flush_rows after the first step does the same;
+//   ftrl               recomputes var from (accum, linear, lr): the value it already holds for a row updated before at the same
+//                      learning rate, a RESCALED one after the schedule has changed lr, and ZERO for a row that never has been
+//                      updated (linear == 0): the reference's dense ApplyFtrl wipes every table row the first step does not touch
+//                      -- dmt_opt_flush_rows after the first step, and after every step whose lr differs from the one before, does
+//                      the same;
 //   rmsprop            ms decays by `decay`, mom = momentum * mom = 0 (the default momentum 0.0 is the only one built): var unchanged;
 //   adadelta           accum and accum_update decay by rho: var unchanged.
 // So var never needs a replay before it is READ (no catch-up in front of the gather); rmsprop / adadelta replay the decay of their
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(256) void opt_sparse_kernel(const dmt_table_map tm,
   }
 }
 
-// every local row brought to `step` (a wavefront per row): slots decayed (rmsprop / adadelta); ftrl: rows never updated are zeroed
+// every local row brought to `step` (a wavefront per row): slots decayed (rmsprop / adadelta); ftrl: var recomputed from the slots
 template <int KIND>
 __global__ __launch_bounds__(256) void opt_flush_kernel(const dmt_table_map tm, float* __restrict__ p, float* __restrict__ s0,
                                                         float* __restrict__ s1, int* __restrict__ last_step, int step, OptHP hp,
@@ -580,13 +582,18 @@ __global__ __launch_bounds__(256) void opt_flush_kernel(const dmt_table_map tm, 
     const long long row = tm.shard_w > 1 ? lsi * tm.shard_w + tm.shard_r : lsi;
     if (row >= tm.row_base[tm.n_tables]) break;
     const int last = last_step[lsi];
-    if (last >= step) continue;
+    if (KIND != DMT_OPT_FTRL && last >= step) continue;
     const int t = find_table(tm, (int)row);
     const int dim = tm.dim[t];
     for (int j = lane; j < dim; j += 64) {
       const long long off = tm_elem(tm, t, row, dim) + j;
       if constexpr (KIND == DMT_OPT_FTRL) {
-        if (last == 0) p[off] = 0.f;
+        // what a zero-gradient ApplyFtrl leaves: var as a function of (accum, linear) and THIS step's learning rate (the same
+        // expression, on the same values, as the tail of opt_update: a row that is current is rewritten with what it holds)
+        const float a = s0[off], b = s1[off];
+        const float quad = __builtin_amdgcn_sqrtf(a) / hp.lr + 2.f * hp.h1;
+        const float x = (b > 0.f ? hp.h0 : -hp.h0) - b;
+        p[off] = fabsf(b) > hp.h0 ? x / quad : 0.f;
       } else {
         float a = s0[off], b = s1[off];
         opt_idle<KIND>(a, b, step - last, hp);
@@ -671,10 +678,11 @@ extern "C" int dmt_opt_sparse_rows(int32_t kind, const dmt_table_map* tm, float*
 }
 
 extern "C" int dmt_opt_flush_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, int32_t step,
-                                  float h0, float h1, float h2, void* stream) {
+                                  float lr, float h0, float h1, float h2, void* stream) {
   DMT_CHECK_ARG(opt_kind_ok(kind), "dmt_opt_flush_rows: unknown optimizer kind");
   DMT_CHECK_ARG(tm && p && s0 && s1 && last_step && step >= 0, "dmt_opt_flush_rows: bad argument");
-  const OptHP hp{0.f, h0, h1, h2};
+  DMT_CHECK_ARG(kind != DMT_OPT_FTRL || lr > 0.f, "dmt_opt_flush_rows: ftrl needs the learning rate of the last step");
+  const OptHP hp{lr, h0, h1, h2};
 #define CALL(K) opt_flush_launch<K>(tm, p, s0, s1, last_step, step, hp, (hipStream_t)stream)
   DMT_OPT_DISPATCH(kind, CALL)
 #undef CALL

@@ -209,9 +209,11 @@ class TFSlotOptimizer:
 
     None of these moves a variable at a zero-gradient step (FTRL: after the first step, see below), so the embedding rows need no
     catch-up in front of the gather: catch_up / catch_up_early / stamp_rows are no-ops, and the slots' idle decay (rmsprop, adadelta)
-    is replayed when the row is next updated or flushed.  FTRL's dense update zeroes every element whose gradient has been zero so far
-    (linear == 0 -> var = 0): the reference, which densifies the embedding gradients (run_dnn.py:45-80), wipes every table row the
-    first batch did not read.  end() of the first step after the slots were (re)initialised does the same."""
+    is replayed when the row is next updated or flushed.  FTRL's dense update recomputes EVERY element from (accum, linear, lr) at every
+    step: zero for an element whose gradient has been zero so far (linear == 0) -- the reference, which densifies the embedding
+    gradients (run_dnn.py:45-80), wipes every table row the first batch did not read -- and a rescaled value once the schedule changes
+    the learning rate.  end() of the first step after the slots were (re)initialised, and of every step whose learning rate differs
+    from the previous step's, sweeps the tables for that."""
     KINDS = {"sgd": L.DMT_OPT_SGD, "adagrad": L.DMT_OPT_ADAGRAD, "adadelta": L.DMT_OPT_ADADELTA, "rmsprop": L.DMT_OPT_RMSPROP,
              "ftrl": L.DMT_OPT_FTRL}
     HP = {"sgd": (0.0, 0.0, 0.0), "adagrad": (0.0, 0.0, 0.0), "adadelta": (0.95, 1e-8, 0.0), "rmsprop": (0.9, 0.0, 1e-10),
@@ -231,6 +233,7 @@ class TFSlotOptimizer:
         self._broken = None
         self.stamp = None
         self.tm = store.fill_table_map(L.TableMap())
+        self._last_lr = None                     # learning rate of the last completed step (FTRL's var depends on it)
         self._init_slots()
 
     current_lr = TFAdam.current_lr
@@ -252,10 +255,12 @@ class TFSlotOptimizer:
         self._begun = True
 
     def end(self):
-        first = self.step_in_flight() == 1
+        lr = float(self.current_lr())            # (of the step that ends: global_step has not moved yet)
+        refresh = self.kind == "ftrl" and lr != self._last_lr
+        self._last_lr = lr
         self.global_step += 1
         self._begun = False
-        if first and self.kind == "ftrl":
+        if refresh:                              # the first step, and every step the schedule changed the learning rate at
             self.flush_tables()
 
     def abort_step(self):
@@ -307,11 +312,13 @@ class TFSlotOptimizer:
         """Every row's slots brought to the last completed step (FTRL: never-updated rows zeroed), before a checkpoint / export."""
         s = self.store
         L.call("dmt_opt_flush_rows", self.code, C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
-               self.global_step - self._step_base, *self.hp, ops.stream_ptr())
+               self.global_step - self._step_base, float(self._last_lr if self._last_lr is not None else self.current_lr()), *self.hp,
+               ops.stream_ptr())
 
     def reset_slots(self, global_step: int = 0):
         """As TFAdam.reset_slots: the reference's Saver keeps no slots (run_dnn.py:258-261); global_step keeps driving the schedule."""
         self._init_slots()
+        self._last_lr = None
         self.global_step = int(global_step)
         self._step_base = int(global_step)
         self._begun = False

@@ -432,8 +432,9 @@ int dmt_adam_rebase(float* state, int32_t* last_step, int64_t rows, void* stream
  * s0 / s1 always point at storage (the Adam slot arenas are reused); lr is this step's learning rate, `step` the 1-based local step
  * number that indexes last_step (0 = never updated).  Sparse rows: the zero-gradient steps last_step[row]+1 .. step-1 are replayed on
  * the slots (they never move var, so nothing has to run in front of the gather), then step `step` is applied.  dmt_opt_flush_rows
- * brings every row's slots to `step`; for FTRL it zeroes the rows that have never been updated -- what the reference's dense
- * ApplyFtrl does to them at its first step (linear == 0 -> var = 0): call it after the first step.
+ * brings every row's slots to `step`; for FTRL it recomputes var from (accum, linear) and `lr` -- what the reference's dense ApplyFtrl
+ * does to every element at every step: zero for rows never updated (linear == 0), a rescaled value when the schedule has changed the
+ * learning rate, the value already held otherwise: call it after the first step and after every step whose lr differs from the last.
  * ------------------------------------------------------------------------------------------------ */
 enum { DMT_OPT_SGD = 1, DMT_OPT_ADAGRAD = 2, DMT_OPT_ADADELTA = 3, DMT_OPT_RMSPROP = 4, DMT_OPT_FTRL = 5 };
 int dmt_opt_dense(int32_t kind, int64_t n, float* p, float* s0, float* s1, const float* g, float grad_scale, float lr, float h0,
@@ -443,7 +444,7 @@ int dmt_opt_sparse_rows(int32_t kind, const dmt_table_map* tm, float* p, float* 
                         int32_t grad_is_bf16, int32_t max_dim, float grad_scale, int32_t step, float lr, float h0, float h1,
                         float h2, void* stream);
 int dmt_opt_flush_rows(int32_t kind, const dmt_table_map* tm, float* p, float* s0, float* s1, int32_t* last_step, int32_t step,
-                       float h0, float h1, float h2, void* stream);
+                       float lr, float h0, float h1, float h2, void* stream);
 /* Row-sharded tables, owner side of the forward exchange: out[u, :] = p[row keys[u]] for u < n (fp32, row stride max_dim, columns
  * past the table's dim zeroed; keys this rank does not own give zero rows).  The all-to-all that answers the index exchange of
  * BASELINE configs[3] sends these rows back to the ranks that asked for them (replaces the /cpu:0 embedding_lookup of base.py:81-91

@@ -3,8 +3,8 @@ tests/test_gpu_ops.py / test_gpu_boundary.py / test_gpu_model.py), cikm2020_dmt_
 
   * the dense sweep against oracle/dmt_oracle.py:TFOptimizer (TF 1.12's ApplyXxx arithmetic in float64);
   * the sparse-row update with lazily replayed slots against the SAME kernel swept densely over whole tables, as the reference does
-    with its densified embedding gradients (run_dnn.py:45-80): var bit for bit, slots bit for bit up to the exact-replay length and
-    to 1e-5 relative beyond; FTRL: rows never read are zero after the first step;
+    with its densified embedding gradients (run_dnn.py:45-80): var and slots bit for bit for rows idle up to the exact-replay length,
+    slots to 1e-5 relative (and the update they feed to 1e-6) beyond; FTRL: rows never read are zero after the first step;
   * three train steps of the whole path per optimizer against the oracle's loss_and_grads + TFOptimizer.
 """
 import numpy as np
@@ -99,10 +99,21 @@ def test_lazy_rows_equal_the_dense_table_sweep(cuda, kind, wire):
     oa.flush_tables()
     torch.cuda.synchronize()
     pa, pb = a.tab_p.cpu().numpy(), b.tab_p.cpu().numpy()
-    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), (kind, float(np.abs(pa - pb).max()))
+    # the eight rare rows sat idle for 148 steps: beyond the exact replay length their rmsprop / adadelta slots come from the closed form
+    # (1e-5 relative), and the last step's update inherits that; every other element is bit for bit the dense sweep's
+    names, bases, dims, offs = a.table_map()
+    rare_el = np.zeros(pa.shape, bool)
+    for name, base, dim, off in zip(names, bases, dims, offs):
+        for r in rare[(rare >= base) & (rare < base + a.table_rows[name][1])] - base:
+            rare_el[off + r * dim: off + (r + 1) * dim] = True
+    same = pa.view(np.uint32) == pb.view(np.uint32)
+    assert same[~rare_el].all(), (kind, float(np.abs(pa - pb)[~rare_el].max()))
+    if kind in ("rmsprop", "adadelta"):
+        assert np.abs(pa - pb)[rare_el].max() <= 1e-6, (kind, float(np.abs(pa - pb)[rare_el].max()))
+    else:
+        assert same.all()
     assert not np.array_equal(pa, p_init)
     # rows no batch read: untouched -- except under FTRL, whose first dense step sets them to zero
-    names, bases, dims, offs = a.table_map()
     for name, base, dim, off in zip(names, bases, dims, offs):
         nr = a.table_rows[name][1]
         sel = never[(never >= base) & (never < base + nr)] - base
@@ -144,7 +155,11 @@ def test_train_steps_with_each_optimizer_match_oracle_fp32(cuda, kind):
     for k in Pn:
         moved = float(np.abs(Pn[k] - P[k]).max())
         err = float(np.abs(got[k] - Pn[k]).max())
-        worst.append((err / max(moved, 1e-9), err, moved, k))
+        worst.append((err, moved, k))
+    # (the K bias of an attention block has no gradient in exact arithmetic -- it shifts every score of a softmax alike --: what moves it
+    #  is rounding noise, 1e-19 here; errors are measured against the tensor's own move or 1e-4 of the largest move of any tensor)
+    top = max(w[1] for w in worst)
+    worst = [(e / max(mv, 1e-4 * top), e, mv, k) for (e, mv, k) in worst]
     worst.sort(reverse=True)
     print(kind, "worst (error / largest move of the tensor, error, move):", worst[:4])
     # gradients agree with the oracle's to ~2e-3 of the tensor's norm (tests/test_gpu_model.py), and every update rule here is smooth
