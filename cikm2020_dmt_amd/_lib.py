@@ -183,6 +183,8 @@ _SIGS = {
     "dmt_auc_hist": [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp],
     "dmt_confusion_counts": [c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],
     "dmt_l2_unique_rows": [c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "dmt_l2_unique_rows_count": [c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "dmt_l2_rows_add": [C.POINTER(TableMap), c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
     "dmt_chain_image_bytes": [c_i32, c_i32, c_i32, C.POINTER(c_i64)],
     "dmt_chain_image_build": [c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp],
     "dmt_chain2": [C.POINTER(ChainDesc), c_vp],

@@ -687,3 +687,38 @@ extern "C" int dmt_opt_flush_rows(int32_t kind, const dmt_table_map* tm, float* 
   DMT_OPT_DISPATCH(kind, CALL)
 #undef CALL
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Gradient of l2_norm (model/net/mmoe_transformer_unbias.py:42-60) on the reduced embedding-gradient rows: every embedding_list
+// entry whose batch holds a row adds  coef * E[row]  to that row's gradient (coef = dLoss/dl2 * l2_emb_lambda / batch_size;
+// mult[row] = the number of such entries, counted by dmt_l2_unique_rows_count).
+namespace {
+__global__ __launch_bounds__(256) void l2_rows_add_kernel(const dmt_table_map tm, const float* __restrict__ p, const uint32_t* __restrict__ uniq,
+                                                          const int* __restrict__ n_uniq, const int* __restrict__ mult,
+                                                          const float* __restrict__ coef, float* __restrict__ grad_rows, int max_dim) {
+  const int lane = threadIdx.x & 63;
+  const long long n = n_uniq[0];
+  const float c = coef[0];
+  for (long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); u < n; u += (long long)gridDim.x * 4) {
+    const int row = (int)uniq[u];
+    if ((uint32_t)row >= (uint32_t)tm.row_base[tm.n_tables]) continue;
+    const int k = mult[row];
+    if (k == 0) continue;
+    const int t = find_table(tm, row);
+    const int dim = tm.dim[t];
+    const long long base = tm_elem(tm, t, row, dim);
+    for (int j = lane; j < dim; j += 64) grad_rows[u * max_dim + j] += c * (float)k * p[base + j];
+  }
+}
+}  // namespace
+
+extern "C" int dmt_l2_rows_add(const dmt_table_map* tm, const float* p, const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq,
+                               const int32_t* mult, const float* coef, float* grad_rows, int32_t max_dim, void* stream) {
+  DMT_CHECK_ARG(tm && p && uniq_keys && n_uniq && mult && coef && grad_rows && max_uniq > 0 && max_dim > 0, "dmt_l2_rows_add: bad argument");
+  DMT_CHECK_ARG(tm->n_tables > 0 && tm->n_tables <= DMT_MAX_TABLES && tm->shard_w <= 1, "dmt_l2_rows_add: bad table map (replicated tables only)");
+  const long long need = cdiv64(max_uniq, 4);
+  hipLaunchKernelGGL(l2_rows_add_kernel, dim3((unsigned)(need < 4096 ? need : 4096)), dim3(256), 0, (hipStream_t)stream, *tm, p, uniq_keys,
+                     n_uniq, mult, coef, grad_rows, max_dim);
+  DMT_CHECK_LAUNCH("dmt_l2_rows_add");
+  return DMT_OK;
+}

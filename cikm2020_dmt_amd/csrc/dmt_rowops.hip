@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(int B, const float* __re
 // a row is counted by the first entry that sets its bit in `seen` (rows / 32 words, zeroed by the caller)
 __global__ __launch_bounds__(256) void l2_unique_kernel(int B, int T, const int* __restrict__ idx, const int* __restrict__ lens,
                                                         const float* __restrict__ table, int rows, int dim, unsigned* __restrict__ seen,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int* __restrict__ mult) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
   if (e < (long long)B * T) {
@@ -772,6 +772,7 @@ __global__ __launch_bounds__(256) void l2_unique_kernel(int B, int T, const int*
         if (!(old & bit)) {
           const float* row = table + (long long)r * dim;
           for (int c = 0; c < dim; ++c) acc += row[c] * row[c];
+          if (mult) atomicAdd(&mult[r], 1);        // one more embedding_list entry whose batch holds this row (the term's gradient)
         }
       }
     }
@@ -1095,7 +1096,17 @@ extern "C" int dmt_l2_unique_rows(int32_t B, int32_t T, const int32_t* idx, cons
   DMT_CHECK_ARG(B > 0 && T > 0 && idx && lens && table && seen && out && rows > 0 && dim > 0, "dmt_l2_unique_rows: bad argument");
   const long long n = (long long)B * T;
   hipLaunchKernelGGL(l2_unique_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, T, idx, lens, table, rows, dim,
-                     seen, out);
+                     seen, out, (int*)nullptr);
   DMT_CHECK_LAUNCH("dmt_l2_unique_rows");
+  return DMT_OK;
+}
+
+extern "C" int dmt_l2_unique_rows_count(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows,
+                                        int32_t dim, uint32_t* seen, float* out, int32_t* mult, void* stream) {
+  DMT_CHECK_ARG(B > 0 && T > 0 && idx && lens && table && seen && out && mult && rows > 0 && dim > 0, "dmt_l2_unique_rows_count: bad argument");
+  const long long n = (long long)B * T;
+  hipLaunchKernelGGL(l2_unique_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, T, idx, lens, table, rows, dim,
+                     seen, out, mult);
+  DMT_CHECK_LAUNCH("dmt_l2_unique_rows_count");
   return DMT_OK;
 }

@@ -399,12 +399,45 @@ def sp_units(spec):
     return (spec["hidden_units_bottom"][-1],)
 
 
+class L2NormFn(torch.autograd.Function):
+    """l2_norm of the reference (model/net/mmoe_transformer_unbias.py:42-60; added to the loss when wnd_wd > 1e-5, run_dnn.py:174-175).
+    `anchor` is any leaf that requires grad (it only ties the node into the graph; its gradient is None)."""
+
+    @staticmethod
+    def forward(ctx, engine, batch, scale, anchor):
+        st, sp = engine.store, engine.spec
+        if st.shard is not None and st.shard[1] > 1:
+            raise NotImplementedError("l2_norm on row-sharded tables")
+        dev = st.device
+        if engine._l2_mult is None:
+            engine._l2_mult = torch.zeros(st.total_rows, dtype=torch.int32, device=dev)
+        else:
+            engine._l2_mult.zero_()
+        out = torch.zeros(1, dtype=F32, device=dev)
+        for (name, rows, dim, feat, _side) in sp["embedding_list"]:
+            tf_name = "embedding_trans/%s/embedding" % name
+            col = batch.feats[feat]
+            base = st.table_rows[tf_name][0]
+            seen = torch.zeros(rows // 32 + 1, dtype=torch.int32, device=dev)
+            L.call("dmt_l2_unique_rows_count", batch.B, col.T, ops.p(col.idx), ops.p(col.lens), ops.p(st.table[tf_name]), rows, dim, ops.p(seen),
+                   ops.p(out), ops.p(engine._l2_mult[base: base + rows]), ops.stream_ptr())
+        ctx.engine, ctx.scale = engine, scale
+        return out[0] * scale
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.engine._l2_coef = (gout.detach().to(F32) * ctx.scale).reshape(1).contiguous()
+        return None, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ engine
 class DMTEngine:
     def __init__(self, spec: dict, store: VariableStore):
         self.spec, self.store = spec, store
         self.plan = _GatherPlan(spec, store)
-        self.sparse = None           # (uniq_keys, n_uniq, grad_rows) of the last backward
+        self._sparse = None          # (uniq_keys, n_uniq, grad_rows, cap) of the last backward
+        self._l2_coef = None         # device scalar: a backward pass went through l2_norm (L2NormFn): its row gradients are still to be added
+        self._l2_mult = None         # int32 [total rows]: embedding_list entries whose batch holds the row (L2NormFn.forward)
         self._ws = {}
         dev = store.device
         self.w_ctr = torch.tensor(spec["weight_ctr"], dtype=F32, device=dev)
@@ -469,6 +502,29 @@ class DMTEngine:
     @staticmethod
     def _wslice(w: Weight, a, b) -> Weight:
         return Weight(w.f32[:, a:b], w.lp[:, a:b] if w.lp is not None else None, w.lp_t[a:b, :] if w.lp_t is not None else None)
+
+    @property
+    def sparse(self):
+        """(uniq_keys, n_uniq, grad_rows, cap) of the last backward.  The gradient of l2_norm (if the loss went through it) is added
+        here, on first use: its backward node and the gather's run in no fixed order, both are done when anybody asks for the rows."""
+        if self._l2_coef is not None and self._sparse is not None:
+            coef, self._l2_coef = self._l2_coef, None
+            uniq, n_uniq, rows, cap = self._sparse
+            if int(cap) > 0:
+                tm = self.store.fill_table_map(L.TableMap())
+                L.call("dmt_l2_rows_add", C.byref(tm), ops.p(self.store.tab_p), ops.p(uniq), ops.p(n_uniq), int(cap), ops.p(self._l2_mult),
+                       ops.p(coef), ops.p(rows), int(rows.shape[1]), ops.stream_ptr())
+        return self._sparse
+
+    @sparse.setter
+    def sparse(self, value):
+        self._sparse = value
+
+    def l2_norm(self, batch: DeviceBatch, scale: float):
+        """scale * sum over the embedding_list entries of l2_loss(E[distinct ids of the entry's feature]) (mmoe_transformer_unbias.py:42-60)
+        with its gradient: scale * E[row] per entry on every distinct row, added to the sparse rows of the same backward pass."""
+        pos = self._lf(trans_prefix(0) + "positional_encoding_k_position_learn/embedding_position_learn")
+        return L2NormFn.apply(self, batch, float(scale), pos)
 
     # ---- stages
     def gather(self, batch: DeviceBatch):

@@ -117,20 +117,13 @@ class mmoe_transformer_unbias(base):
 
     def l2_norm(self, inputs):
         """mmoe_transformer_unbias.py:42-60: sum over the embedding_list entries of l2_loss(E[unique ids of the feature]) times
-        l2_emb_lambda / batch_size (tf.losses.get_regularization_losses() is empty: no layer registers a regularizer).
-        The VALUE is computed on the GPU (dmt_l2_unique_rows); it is only reached when wnd_wd > 1e-5 (run_dnn.py:174-175, dmt.conf has
-        0.0), and its gradient -- lambda / batch_size times the row, on every distinct row of the batch -- is not propagated here."""
-        eng, sp = self.rt.engine, self.rt.spec
+        l2_emb_lambda / batch_size (tf.losses.get_regularization_losses() is empty: no layer registers a regularizer).  Reached only
+        when wnd_wd > 1e-5 (run_dnn.py:174-175; dmt.conf has 0.0).  Value and gradient on the GPU (engine.L2NormFn): the gradient --
+        lambda / batch_size times the row, per entry, on every distinct row of the batch -- joins the sparse embedding-gradient rows of
+        the same backward pass (DMTEngine.sparse)."""
+        eng = self.rt.engine
         batch = self.rt.as_batch(inputs)
-        dev = eng.store.device
-        out = torch.zeros(1, dtype=torch.float32, device=dev)
-        for (name, rows, dim, feat, _side) in sp["embedding_list"]:
-            col = batch.feats[feat]
-            table = eng.store.table["embedding_trans/%s/embedding" % name]
-            seen = torch.zeros(rows // 32 + 1, dtype=torch.int32, device=dev)
-            L.call("dmt_l2_unique_rows", batch.B, col.T, ops.p(col.idx), ops.p(col.lens), ops.p(table), rows, dim, ops.p(seen), ops.p(out),
-                   ops.stream_ptr())
         m = self.wnd_conf["model"] if self.wnd_conf is not None else {}
         lam = float(m.get("l2_emb_lambda", 0.01)) if isinstance(m, dict) else 0.01
         bs = float(m.get("batch_size", batch.B)) if isinstance(m, dict) else float(batch.B)
-        return out[0] * (lam / bs)
+        return eng.l2_norm(batch, lam / bs)

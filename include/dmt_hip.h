@@ -640,6 +640,15 @@ int dmt_confusion_counts(int32_t B, const float* pred, const float* label, float
  * (model/net/mmoe_transformer_unbias.py:42-60: tf.nn.l2_loss(tf.gather(E, tf.unique(ids)))).  seen: rows / 32 + 1 zeroed words. */
 int dmt_l2_unique_rows(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows, int32_t dim,
                        uint32_t* seen, float* out, void* stream);
+/* The same, and mult[id] += 1 for every distinct id (mult: int32 [rows] of THIS table, zeroed by the caller before the first entry):
+ * after all embedding_list entries, mult[row] = the number of entries whose batch holds the row = the weight of E[row] in the
+ * gradient of l2_norm.  dmt_l2_rows_add then adds  coef[0] * mult[row] * E[row]  to the reduced embedding-gradient row of every
+ * listed global row (uniq_keys / n_uniq / grad_rows as dmt_embgrad_reduce leaves them; mult indexed by GLOBAL row; coef on the device:
+ * dLoss/dl2 * l2_emb_lambda / batch_size).  Replicated tables only.                                                               */
+int dmt_l2_unique_rows_count(int32_t B, int32_t T, const int32_t* idx, const int32_t* lens, const float* table, int32_t rows, int32_t dim,
+                             uint32_t* seen, float* out, int32_t* mult, void* stream);
+int dmt_l2_rows_add(const dmt_table_map* tm, const float* p, const uint32_t* uniq_keys, const int32_t* n_uniq, int32_t max_uniq,
+                    const int32_t* mult, const float* coef, float* grad_rows, int32_t max_dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused expert-MLP + gate kernels of the MMoE bottom (bf16; expert widths 512 -> 256 -> 128).

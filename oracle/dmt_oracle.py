@@ -593,6 +593,24 @@ class TFAdam:
         self.b2p = self.b2p * self.b2
 
 
+def l2_norm(inputs, P: Dict[str, np.ndarray], spec: dict, l2_emb_lambda: float, batch_size: float):
+    """l2_norm (model/net/mmoe_transformer_unbias.py:42-60), added to the tower loss when wnd_wd > 1e-5 (run_dnn.py:174-175):
+    sum over the embedding_list entries of tf.nn.l2_loss(tf.gather(E, tf.unique(ids of the entry's feature))) = sum(row^2) / 2 over
+    the DISTINCT ids, times l2_emb_lambda / batch_size (tf.losses.get_regularization_losses() is empty: no layer registers one).
+    Returns (value, {table tf_name: d value / d E}): lambda / batch_size * E[id] per entry on each of its distinct ids -- a table that
+    two entries read gets both terms."""
+    val, grads = 0.0, {}
+    for (name, _rows, _dim, feat, _side) in spec["embedding_list"]:
+        tf_name = "embedding_trans/%s/embedding" % name
+        E = P[tf_name].astype(np.float64)
+        ids = np.unique(np.asarray(inputs[feat].values).astype(np.int64))
+        val += 0.5 * float((E[ids] ** 2).sum())
+        g = grads.setdefault(tf_name, np.zeros_like(E))
+        g[ids] += E[ids]
+    k = float(l2_emb_lambda) / float(batch_size)
+    return val * k, {n: g * k for n, g in grads.items()}
+
+
 class TFOptimizer:
     """The other optimizers get_optimizer returns (model/inference_mlp.py:264-280), built with the learning rate only, so every other
     hyper-parameter is TF 1.12's constructor default; applied DENSELY to every variable (run_dnn.py:203-207 on the densified

@@ -54,7 +54,7 @@ def test_inference_and_losses(cuda):
     rel_logits = inf.inference(inputs, is_train=False, is_predict=True)
     assert len(rel_logits) == 2 and np.abs(_np(rel_logits[0]) - c_ref).max() < 2e-4
     with pytest.raises(SystemExit):
-        inf.get_optimizer("sgd", 0.1)
+        inf.get_optimizer("lamb", 0.1)               # (the six names of inference_mlp.py:264-280: tests/test_gpu_optimizers.py)
     assert inf.get_optimizer("adam", 0.001) is not None
 
 
