@@ -39,7 +39,8 @@ class Trainer:
     def __init__(self, spec: dict, device="cuda", compute_dtype=torch.float32, seed: int = 0, learning_rate=(0.001, 0.0001),
                  step_boundary=(300000000,), init: bool = True, max_steps: int = 1 << 20, dropout: bool = True, dropout_seed: int = 1,
                  dp_exchange: str = "owner", force_dp: bool = False, fused_mhsa=None, table_layout: str = "replicated", attn_dtype=None,
-                 wgrad320_min_rows=None, packed_rows=None, optimizer: str = "adam"):
+                 wgrad320_min_rows=None, packed_rows=None, optimizer: str = "adam", wnd_wd: float = 0.0, l2_emb_lambda: float = 0.01,
+                 l2_batch_size=None):
         """table_layout: "replicated" (every rank holds every embedding table; gradient rows are exchanged and every rank applies the
         same update) or "sharded" (BASELINE configs[3]: rank r holds the rows with id % world == r; ids travel to the owners and rows
         back before the forward pass, gradient rows travel to the owners after the backward pass, only owners run Adam)."""
@@ -59,6 +60,9 @@ class Trainer:
         self.engine.kopts = ops.KernelOptions(attn_mma_fp8=(attn_dtype == "fp8"))
         # get_optimizer(optimizer, learning_rate) (model/inference_mlp.py:264-280): adam (dmt.conf:70) or one of the other five
         self.opt = make_optimizer(optimizer, self.store, learning_rate, step_boundary, max_steps=max_steps)
+        # run_dnn.py:174-175: tower_train_loss += inf.l2_norm(features) when wnd_wd > 1e-5 (dmt.conf: 0.0); the term is scaled by
+        # l2_emb_lambda / batch_size of the conf (mmoe_transformer_unbias.py:58-59; l2_batch_size None: the batch at hand)
+        self.wnd_wd, self.l2_emb_lambda, self.l2_batch_size = float(wnd_wd), float(l2_emb_lambda), l2_batch_size
         self.last = {}
         self.diag = None       # dict: train_step brackets its phases with HIP events (key -> [(start, end)]); bench.py's step_phases_ms
         # is_train semantics of the reference: Transformer dropout 0.1 and bias-tower dropout 0.5 are ALWAYS active in
@@ -455,6 +459,8 @@ class Trainer:
         self.engine.dropout_step_seed = (self.dropout_seed + self.opt.global_step + 7919 * rank) if self.dropout else None
         out = self.engine.inference(batch)
         loss, p_ctr, p_cvr = self.engine.loss_unbias(out, batch.mask)
+        if self.wnd_wd > 1e-5:
+            loss = loss + self.engine.l2_norm(batch, self.l2_emb_lambda / float(self.l2_batch_size or batch.B))
         if prefetch is not None and prefetch is not batch:
             self.prefetch(prefetch)
         defer = (not join) and self.sparse_lane and self.device.type == "cuda" and self._index_stream() is not None

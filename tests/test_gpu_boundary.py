@@ -122,6 +122,30 @@ def test_l2_norm_gradient_joins_the_sparse_rows(cuda):
     assert max(entries.values()) >= 2
 
 
+def test_trainer_adds_l2_norm_when_wnd_wd_is_set(cuda):
+    """run_dnn.py:174-175 through the Trainer (wnd_wd > 1e-5): loss and embedding-gradient rows differ from the plain step's by the
+    oracle's l2 term; a whole train_step (sparse rows finished on the index lane) runs with it."""
+    so, sp = small_specs()
+    P = O.init_params(so, seed=9)
+    B = 17
+    inputs, mask, label = make_batch(sp, B, seed=6, lengths="ragged", weights="ones")
+    res = []
+    for wd in (0.0, 1e-3):
+        tr = Trainer(sp, device=cuda, compute_dtype=torch.float32, init=False, dropout=False, wnd_wd=wd, l2_emb_lambda=0.5)
+        tr.store.load_state(P)
+        loss = float(tr.forward_backward(tr.make_batch(inputs, mask, label)))
+        res.append((loss, sparse_to_dense_tables(tr.store, tr.engine.sparse), tr))
+    val, want = O.l2_norm(inputs, P, so, 0.5, B)
+    assert abs((res[1][0] - res[0][0]) - val) <= 1e-4 * val
+    for name, g0 in res[0][1].items():
+        ref = want.get(name, np.zeros_like(g0))
+        assert np.abs(res[1][1][name] - g0 - ref).max() <= 1e-4 * max(np.abs(ref).max(), 1e-9) + 2e-8, name
+    tr = res[1][2]
+    l1 = float(tr.train_step(tr.make_batch(inputs, mask, label)))
+    l2 = float(tr.train_step(tr.make_batch(inputs, mask, label)))
+    assert abs(l1 - res[1][0]) <= 1e-5 * l1 and l2 < l1
+
+
 def test_streaming_precision_recall_matches_the_tf_metrics_rule(cuda):
     rng = np.random.default_rng(0)
     m = StreamingPrecisionRecall(cuda)
