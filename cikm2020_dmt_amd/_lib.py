@@ -119,6 +119,13 @@ class WgradDesc(C.Structure):
                 ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32), ("det_ws", c_vp), ("det_ws_bytes", C.c_uint64)]
 
 
+class LnFinishJob(C.Structure):      # include/dmt_hip.h: dmt_ln_finish_job
+    _fields_ = [("partials", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("n_part", C.c_int32), ("d", C.c_int32)]
+
+
+LN_FINISH_MAX = 16
+
+
 class TableMap(C.Structure):
     _fields_ = [("n_tables", c_i32), ("row_base", c_i32 * (DMT_MAX_TABLES + 1)), ("dim", c_i32 * DMT_MAX_TABLES),
                 ("elem_off", c_i64 * DMT_MAX_TABLES), ("shard_w", c_i32), ("shard_r", c_i32)]
@@ -148,6 +155,7 @@ _SIGS = {
     "dmt_attn_long_bwd": [C.POINTER(AttnBwdDesc), c_vp],
     "dmt_ln_fwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp],
     "dmt_ln_bwd": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "dmt_ln_bwd_finish_batched": [c_vp, c_i32, c_vp],
     "dmt_mmoe_mix_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp],
     "dmt_mmoe_mix_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp],
     "dmt_scale_add_pos": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp],

@@ -220,6 +220,27 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(int nblk, int d, con
   if (lane == 0) { if (c < d) dgamma[c] += s; else dbeta[c - d] += s; }
 }
 
+// the same for a list of LayerNorm gradients in one launch: a step's dgamma / dbeta all finish together.  blockIdx.y = a GROUP of jobs
+// with one destination (the encoder's and the decoder's feed-forward LayerNorm share gamma / beta: tie_ffn), summed one after the
+// other by the same wavefront -- a fixed order, and no two blocks add to one address.
+struct LnFinishJobs { int n_groups; int first[DMT_LN_FINISH_MAX + 1]; dmt_ln_finish_job job[DMT_LN_FINISH_MAX]; };
+__global__ __launch_bounds__(256) void ln_bwd_finish_jobs_kernel(const LnFinishJobs jobs) {
+  const int g = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int d = jobs.job[jobs.first[g]].d;
+  if (c >= 2 * d) return;
+  float s = 0.f;
+  for (int i = jobs.first[g]; i < jobs.first[g + 1]; ++i) {
+    const dmt_ln_finish_job& j = jobs.job[i];
+    float sj = 0.f;
+    for (int b = lane; b < j.n_part; b += 64) sj += j.partials[(long long)b * 2 * d + c];
+    s += wave_sum(sj);
+  }
+  const dmt_ln_finish_job& j0 = jobs.job[jobs.first[g]];
+  if (lane == 0) { if (c < d) j0.dgamma[c] += s; else j0.dbeta[c - d] += s; }
+}
+
 // ------------------------------------------------------------------------------------------ MMoE mix
 template <typename T>
 __global__ __launch_bounds__(128) void mix_fwd_kernel(int B, int E, int U, int nt, const T* __restrict__ expert, long long lde,
@@ -831,14 +852,16 @@ extern "C" int32_t dmt_ln_bwd_partials(int64_t rows) {
 extern "C" int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
                           const float* stats, const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma,
                           float* dbeta, float* partials, void* stream) {
-  DMT_CHECK_ARG(rows > 0 && d > 0 && x && gamma && stats && dy && dx && dgamma && dbeta && partials, "dmt_ln_bwd: bad argument");
+  DMT_CHECK_ARG(rows > 0 && d > 0 && x && gamma && stats && dy && dx && partials, "dmt_ln_bwd: bad argument");
+  DMT_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr), "dmt_ln_bwd: dgamma and dbeta are given together or not at all");
   DMT_CHECK_ARG(dtype == DMT_F32 || dtype == DMT_BF16, "dmt_ln_bwd: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int nb = dmt_ln_bwd_partials(rows);
+  const bool finish = dgamma != nullptr;        // null: the caller reduces `partials` later (dmt_ln_bwd_finish_batched)
   if (ln_v8_ok(dtype, d, x, ldx, dy, lddy, dx, lddx)) {
     hipLaunchKernelGGL(ln_bwd_v8_kernel, dim3(nb), dim3(256), 0, st, (long long)rows, d, (const bf16_t*)x, (long long)ldx, gamma, stats,
                        (const bf16_t*)dy, (long long)lddy, (bf16_t*)dx, (long long)lddx, partials);
-    hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 3) / 4), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
+    if (finish) hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 3) / 4), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
     DMT_CHECK_LAUNCH("dmt_ln_bwd(v8)");
     return DMT_OK;
   }
@@ -854,8 +877,34 @@ extern "C" int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x,
                          (long long)ldx, gamma, stats, (const bf16_t*)dy, (long long)lddy, (bf16_t*)dx, (long long)lddx, partials);
       return 0; });
   if (rc != 0) { dmt_set_error("dmt_ln_bwd: d=%d > 1024 unsupported", d); return DMT_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 3) / 4), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
+  if (finish) hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((2 * d + 3) / 4), dim3(256), 0, st, nb, d, partials, dgamma, dbeta);
   DMT_CHECK_LAUNCH("dmt_ln_bwd");
+  return DMT_OK;
+}
+
+extern "C" int dmt_ln_bwd_finish_batched(const dmt_ln_finish_job* jobs, int32_t n, void* stream) {
+  DMT_CHECK_ARG(jobs && n > 0 && n <= DMT_LN_FINISH_MAX, "dmt_ln_bwd_finish_batched: 1 .. DMT_LN_FINISH_MAX jobs");
+  LnFinishJobs pack;
+  int dmax = 0, ng = 0, filled = 0;
+  bool taken[DMT_LN_FINISH_MAX] = {false};
+  for (int i = 0; i < n; ++i) {
+    DMT_CHECK_ARG(jobs[i].partials && jobs[i].dgamma && jobs[i].dbeta && jobs[i].n_part > 0 && jobs[i].d > 0, "dmt_ln_bwd_finish_batched: bad job");
+    if (jobs[i].d > dmax) dmax = jobs[i].d;
+  }
+  for (int i = 0; i < n; ++i) {              // groups of equal destination, in order of first appearance
+    if (taken[i]) continue;
+    pack.first[ng++] = filled;
+    for (int k = i; k < n; ++k)
+      if (!taken[k] && jobs[k].dgamma == jobs[i].dgamma) {
+        DMT_CHECK_ARG(jobs[k].dbeta == jobs[i].dbeta && jobs[k].d == jobs[i].d, "dmt_ln_bwd_finish_batched: jobs share dgamma but not dbeta / d");
+        pack.job[filled++] = jobs[k];
+        taken[k] = true;
+      }
+  }
+  pack.first[ng] = filled;
+  pack.n_groups = ng;
+  hipLaunchKernelGGL(ln_bwd_finish_jobs_kernel, dim3((2 * dmax + 3) / 4, ng), dim3(256), 0, (hipStream_t)stream, pack);
+  DMT_CHECK_LAUNCH("dmt_ln_bwd_finish_batched");
   return DMT_OK;
 }
 

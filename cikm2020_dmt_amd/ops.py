@@ -182,6 +182,44 @@ def flush_dw_batches(end=False):
     return out
 
 
+def begin_ln_finish_batching():
+    """From now on a LayerNorm gradient whose dgamma / dbeta go straight into the gradient arena leaves its column partials behind and
+    the reduction of ALL of them is one launch (flush_ln_finish()): a train step has twelve, each a 8 us kernel between two long ones."""
+    _state.ln_finish = []
+
+
+def ln_bwd(dtype_code, rows, d, x, ldx, gamma, stats, dy, lddy, dx, lddx, dg, db, partials, direct):
+    """dmt_ln_bwd, with the dgamma / dbeta finish either inside the call or collected for flush_ln_finish()."""
+    lst = _state.ln_finish
+    if lst is not None and direct:
+        L.call("dmt_ln_bwd", dtype_code, rows, d, p(x), ldx, p(gamma), p(stats), p(dy), lddy, p(dx), lddx, None, None, p(partials), stream_ptr())
+        lst.append((L.LnFinishJob(partials.data_ptr(), dg.data_ptr(), db.data_ptr(), int(partials.shape[0]), int(d)), (partials, dg, db),
+                    torch.cuda.current_stream(partials.device)))
+        return
+    L.call("dmt_ln_bwd", dtype_code, rows, d, p(x), ldx, p(gamma), p(stats), p(dy), lddy, p(dx), lddx, p(dg), p(db), p(partials), stream_ptr())
+
+
+def flush_ln_finish(end=False):
+    """The collected dgamma / dbeta reductions on the CURRENT stream (which is made to wait for the streams their gradients ran on)."""
+    lst = _state.ln_finish
+    if lst is None:
+        return 0
+    _state.ln_finish = None if end else []
+    if not lst:
+        return 0
+    cur = torch.cuda.current_stream(lst[0][1][0].device)
+    for st in {st for (_j, _k, st) in lst}:
+        if st != cur:
+            cur.wait_stream(st)
+    for i in range(0, len(lst), L.LN_FINISH_MAX):
+        part = lst[i: i + L.LN_FINISH_MAX]
+        arr = (L.LnFinishJob * len(part))(*[j for (j, _k, _s) in part])
+        L.call("dmt_ln_bwd_finish_batched", arr, len(part), stream_ptr())
+    for (_j, keep, _s) in lst:
+        keep[0].record_stream(cur)               # (the partials were allocated on a lane)
+    return len(lst)
+
+
 def _pick_split(tiles: int, red: int) -> int:
     """Split-K factor of a weight-gradient GEMM.  Splitting only pays while the output tiles alone cannot fill the 256 CUs:
     every extra split adds one fp32 atomic pass over the whole output (MMoE layer-0 dW, 25 MB: split 2 is 4x slower than 1)."""
@@ -284,7 +322,7 @@ class StepState:
     Trainers with different deferral needs in one process do not see each other's (round-3 review: these were module globals).  The
     autograd engine runs backward on its own thread: the active state is a module-level pointer, not a thread-local -- steps of
     different Trainers may alternate in one process, they may not run concurrently."""
-    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws", "unit_loss_grad", "dw_batch")
+    __slots__ = ("deferred", "deferred_limit", "fork", "wgrad320_min_rows", "mmoe_ws", "unit_loss_grad", "dw_batch", "ln_finish")
 
     def __init__(self, wgrad320_min_rows=None):
         self.deferred = None          # list of closures while the step collects its long-row weight gradients
@@ -294,6 +332,7 @@ class StepState:
         self.mmoe_ws = {}             # device -> workspace of the split expert kernels (_mmoe_workspace)
         self.unit_loss_grad = False   # Trainer.forward_backward: the loss's incoming gradient is exactly 1 (no scaling launch)
         self.dw_batch = None          # stream -> [(GemmDesc, operands kept alive)] while B-row weight gradients are being batched
+        self.ln_finish = None         # [(LnFinishJob, tensors kept alive, stream)] while the LayerNorm gradients' dgamma / dbeta sums wait
 
     def min_rows(self):
         return WGRAD320_MIN_ROWS if self.wgrad320_min_rows is None else self.wgrad320_min_rows
@@ -819,8 +858,7 @@ class FFNLNChainFn(torch.autograd.Function):
         db = gbv if direct else torch.zeros((d,), dtype=F32, device=x2.device)
         npart = L.load().dmt_ln_bwd_partials(M)
         partials = torch.empty((npart, 2 * d), dtype=F32, device=x2.device)
-        L.call("dmt_ln_bwd", L.DMT_BF16, M, d, p(s), s.stride(0), p(gamma), p(stats), p(dy2), _row_major2d(dy2, "dy"), p(ds), d, p(dg), p(db),
-               p(partials), stream_ptr())
+        ln_bwd(L.DMT_BF16, M, d, s, s.stride(0), gamma, stats, dy2, _row_major2d(dy2, "dy"), ds, d, dg, db, partials, direct)
         # ---- dh = (ds W2^T) * [h > 0], dx = dh W1^T + ds
         dx = torch.empty((M, d), dtype=BF16, device=x2.device)
         dh = torch.empty((M, geo[1]), dtype=BF16, device=x2.device)
@@ -1341,8 +1379,7 @@ class MhsaBlockFn(torch.autograd.Function):
         db = gbv if direct else torch.zeros((d,), dtype=F32, device=x.device)
         npart = L.load().dmt_ln_bwd_partials(M)
         partials = torch.empty((npart, 2 * d), dtype=F32, device=x.device)
-        L.call("dmt_ln_bwd", L.DMT_BF16, M, d, p(s2), d, p(gamma), p(stats), p(dy2), _row_major2d(dy2, "dy"), p(ds), d, p(dg), p(db), p(partials),
-               stream_ptr())
+        ln_bwd(L.DMT_BF16, M, d, s2, d, gamma, stats, dy2, _row_major2d(dy2, "dy"), ds, d, dg, db, partials, direct)
         # ---- attention gradient
         ds3 = ds.view(B, T, d)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
@@ -1389,8 +1426,7 @@ class LNFn(torch.autograd.Function):
         partials = torch.empty((npart, 2 * d), dtype=F32, device=x2.device)
         if dy2.dtype != x2.dtype:
             dy2 = dy2.to(x2.dtype)
-        L.call("dmt_ln_bwd", dt_code(x2.dtype), rows, d, p(x2), _row_major2d(x2, "x"), p(gamma), p(stats), p(dy2),
-               _row_major2d(dy2, "dy"), p(dx), d, p(dg), p(db), p(partials), stream_ptr())
+        ln_bwd(dt_code(x2.dtype), rows, d, x2, _row_major2d(x2, "x"), gamma, stats, dy2, _row_major2d(dy2, "dy"), dx, d, dg, db, partials, direct)
         if direct:
             return dx.reshape(ctx.xshape), None, None, None
         return dx.reshape(ctx.xshape), dg, db, None

@@ -500,6 +500,7 @@ class Trainer:
         batch_dw = (not dp) and self.batch_dw and self.device.type == "cuda"
         if batch_dw:
             ops.begin_dw_batching()
+            ops.begin_ln_finish_batching()         # (the twelve dgamma / dbeta reductions of the step: one launch behind backward)
         try:
             # d loss / d loss = 1: a cached scalar instead of the ones_like() fill autograd would launch, and the loss kernel's saved
             # logit gradients are handed on as they are (ops.StepState.unit_loss_grad) instead of through a `* 1` launch
@@ -521,7 +522,9 @@ class Trainer:
             forked = ops.end_fork_wgrads()
             if batch_dw and sys.exc_info()[0] is not None:
                 self.engine.step_state.dw_batch = None         # (a step that raised: drop what it collected)
+                self.engine.step_state.ln_finish = None
         if batch_dw:
+            ops.flush_ln_finish(end=True)
             cur = torch.cuda.current_stream(self.device)
             for st in ops.flush_dw_batches(end=True):
                 if st != cur:

@@ -321,6 +321,12 @@ int32_t dmt_ln_bwd_partials(int64_t rows);
 int dmt_ln_bwd(int32_t dtype, int64_t rows, int32_t d, const void* x, int64_t ldx, const float* gamma,
                const float* stats, const void* dy, int64_t lddy, void* dx, int64_t lddx, float* dgamma,
                float* dbeta, float* partials, void* stream);
+/* dgamma == dbeta == NULL: only dx and `partials` are written; the caller finishes a list of such gradients in ONE launch
+ * (a train step has twelve): job i adds the column sums of partials_i [n_part_i, 2 d_i] to dgamma_i / dbeta_i, in a fixed order; jobs
+ * that name the same dgamma (shared LayerNorm parameters) are summed by the same wavefront, one after the other.                   */
+#define DMT_LN_FINISH_MAX 16
+typedef struct { const float* partials; float* dgamma; float* dbeta; int32_t n_part; int32_t d; } dmt_ln_finish_job;
+int dmt_ln_bwd_finish_batched(const dmt_ln_finish_job* jobs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MMoE mixture: gate softmax + weighted sum of expert outputs and its gradient
