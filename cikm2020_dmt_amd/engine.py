@@ -532,6 +532,7 @@ class DMTEngine:
                for i in range(len(self.spec["attention_embed_pairs"]))]
         packs = [self.seq_pack(batch, s) for s in range(len(pos))]
         self._last_packs = packs
+        self._l2_coef = None         # (a new forward pass: an l2 row term nobody asked the rows for belongs to the previous one)
         outs = GatherFn.apply(self, batch, packs, *pos)
         n = len(pos)
         return list(outs[:n]), outs[n], outs[n + 1]
