@@ -1,7 +1,7 @@
 """Host-side cost of one train step: how long the Python / ctypes / autograd side takes to ENQUEUE a step when nothing holds it back
 (queues empty after a synchronize, a burst of n steps, n small enough that no queue fills), against the GPU time of the same steps.
 
-    python scripts/host_time.py [burst]
+    python scripts/host_time.py [burst] [full|ragged]
 """
 import os
 import sys
@@ -16,10 +16,10 @@ from cikm2020_dmt_amd.data_feed.synthetic import make_batch  # noqa: E402
 from cikm2020_dmt_amd.train import Trainer                  # noqa: E402
 
 
-def main(burst):
+def main(burst, lengths="full"):
     sp = S.e64_spec()
     tr = Trainer(sp, device="cuda:0", compute_dtype=torch.bfloat16, seed=1234, dropout=True)
-    batches = [tr.make_batch(*make_batch(sp, 4096, seed=7 + i, lengths="full", law="zipf")) for i in range(4)]
+    batches = [tr.make_batch(*make_batch(sp, 4096, seed=7 + i, lengths=lengths, law="zipf")) for i in range(4)]
 
     def step(i):
         b, nxt = batches[i % 4], batches[(i + 1) % 4]
@@ -45,7 +45,8 @@ def main(burst):
     pr.disable()
     torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 3, sys.argv[2] if len(sys.argv) > 2 else "full")
