@@ -333,10 +333,11 @@ class GatherFn(torch.autograd.Function):
         engine, batch = ctx.engine, ctx.batch
         spec = engine.spec
         n_seq = len(spec["attention_embed_pairs"])
-        if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None for pl in ctx.pos_leaves):
+        if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None or not pl.requires_grad
+                                                                              for pl in ctx.pos_leaves):
             # Trainer.train_step finishes this node itself (finish_sparse_backward), on the index lane, beside the deferred weight gradients
             engine._pending_sparse = (ctx, grads)
-            return (None, None, None) + (None,) * n_seq
+            return (None, None, None) + (None,) * len(ctx.pos_leaves)
         return GatherFn._finish(ctx, grads)
 
     @staticmethod
@@ -357,6 +358,9 @@ class GatherFn(torch.autograd.Function):
         # learned positions: dP[t] = sum_b dX[b, t]   (lookup by range(T), TransformerModel_util.py:296-306)
         dpos = []
         for s in range(n_seq):
+            if not ctx.pos_leaves[s].requires_grad:      # position_sin_cos: a constant table, nothing to accumulate
+                dpos.append(None)
+                continue
             # accumulate straight into the position table's gradient arena when it is reachable (no zero-fill, no autograd add)
             gv = ops._grad_view(ctx.pos_leaves[s])
             direct = gv is not None and gv.is_contiguous() and tuple(gv.shape) == ctx.pos_shapes[s]
@@ -373,7 +377,7 @@ class GatherFn(torch.autograd.Function):
                 ops.colsum(dX[s].view(B, ctx.seq_T[s] * d), 1.0, out=g.view(-1)[: ctx.seq_T[s] * d])
             dpos.append(None if direct else g)
         engine.embedding_backward(batch, ctx.inv, ctx.seq_T, dX, dtar, dz, ctx.drop, packs)
-        return (None, None, None, *dpos)
+        return (None, None, None, *dpos) + (None,) * (len(ctx.pos_leaves) - n_seq)      # (+ the anchor of a constant position table)
 
 
 class AssembleFn(torch.autograd.Function):
@@ -523,17 +527,37 @@ class DMTEngine:
     def l2_norm(self, batch: DeviceBatch, scale: float):
         """scale * sum over the embedding_list entries of l2_loss(E[distinct ids of the entry's feature]) (mmoe_transformer_unbias.py:42-60)
         with its gradient: scale * E[row] per entry on every distinct row, added to the sparse rows of the same backward pass."""
-        pos = self._lf(trans_prefix(0) + "positional_encoding_k_position_learn/embedding_position_learn")
-        return L2NormFn.apply(self, batch, float(scale), pos)
+        return L2NormFn.apply(self, batch, float(scale), self._lf(trans_prefix(0) + "num_blocks_0/positionwise_feedforward/ln/gamma"))
+
+    def position_tables(self):
+        """The [maxlen_k, d_model] table added to every scaled sequence row (TransformerModel.py:60-69): the learned variable of each
+        sequence (position_learn, dmt.conf:50) or the reference's sinusoid, a constant (position_sin_cos: TransformerModel_util.py:238-279,
+        computed in float64 on the host as there)."""
+        n = len(self.spec["attention_embed_pairs"])
+        if self.spec.get("position_encoding_method", "position_learn") == "position_learn":
+            return [self._lf(trans_prefix(i) + "positional_encoding_k_position_learn/embedding_position_learn") for i in range(n)]
+        tab = getattr(self, "_sincos", None)
+        if tab is None:
+            E, maxlen = self.spec["d_model"], self.spec["maxlen_k"]
+            i = np.arange(E)
+            enc = np.arange(maxlen, dtype=np.float64)[:, None] / np.power(10000.0, (i - i % 2) / float(E))[None, :]
+            enc[:, 0::2] = np.sin(enc[:, 0::2])
+            enc[:, 1::2] = np.cos(enc[:, 1::2])
+            tab = self._sincos = torch.tensor(enc.astype(np.float32), device=self.store.device)
+        return [tab] * n
 
     # ---- stages
     def gather(self, batch: DeviceBatch):
-        pos = [self._lf(trans_prefix(i) + "positional_encoding_k_position_learn/embedding_position_learn")
-               for i in range(len(self.spec["attention_embed_pairs"]))]
+        pos = self.position_tables()
         packs = [self.seq_pack(batch, s) for s in range(len(pos))]
         self._last_packs = packs
         self._l2_coef = None         # (a new forward pass: an l2 row term nobody asked the rows for belongs to the previous one)
+        if not any(pl.requires_grad for pl in pos):
+            # position_sin_cos: no input of the node requires a gradient, and autograd would not run its backward (the embedding gradient):
+            # one more input, any leaf, ties it into the graph (its gradient is None)
+            pos = pos + [self._lf(trans_prefix(0) + "num_blocks_0/positionwise_feedforward/ln/gamma")]
         outs = GatherFn.apply(self, batch, packs, *pos)
+        pos = pos[: len(packs)]
         n = len(pos)
         return list(outs[:n]), outs[n], outs[n + 1]
 

@@ -116,7 +116,8 @@ class VariableStore:
             self._table("%s/embedding" % name, rows, dim)
         for i in range(len(sp["attention_embed_pairs"])):
             pre = trans_prefix(i)
-            self._simple(pre + "positional_encoding_k_position_learn/embedding_position_learn", (sp["maxlen_k"], d), "xavier")
+            if sp.get("position_encoding_method", "position_learn") == "position_learn":      # (position_sin_cos adds a constant: no variable)
+                self._simple(pre + "positional_encoding_k_position_learn/embedding_position_learn", (sp["maxlen_k"], d), "xavier")
             blk = pre + "num_blocks_0/"
             for att in ("self-attention", "vanilla_attention"):
                 wq, bq = blk + att + "/qkv_kernel", blk + att + "/qkv_bias"

@@ -134,7 +134,8 @@ def param_shapes(spec) -> Dict[str, tuple]:
     shp = dict(table_shapes(spec))
     for i in range(len(spec["attention_embed_pairs"])):
         p = trans_prefix(i)
-        shp[p + "positional_encoding_k_position_learn/embedding_position_learn"] = (spec["maxlen_k"], d)
+        if spec.get("position_encoding_method", "position_learn") == "position_learn":
+            shp[p + "positional_encoding_k_position_learn/embedding_position_learn"] = (spec["maxlen_k"], d)
         for att in ("self-attention", "vanilla_attention"):
             for dn in ("dense", "dense_1", "dense_2"):
                 shp[p + "num_blocks_0/%s/%s/kernel" % (att, dn)] = (d, d)
@@ -301,13 +302,26 @@ def ff(inputs, P, scope):
     return ln(o, P[scope + "ln/gamma"], P[scope + "ln/beta"])
 
 
+def position_table(P, prefix, spec):
+    """TransformerModel.py:60-69 position_encode: the learned [maxlen_k, d] variable (position_learn, dmt.conf:50) or the sinusoid of
+    TransformerModel_util.py:238-279 (position_sin_cos): PE[pos, i] = pos / 10000^((i - i % 2) / E), sin on even columns, cos on odd ones,
+    a float32 constant there (tf.convert_to_tensor(position_enc, tf.float32))."""
+    if spec.get("position_encoding_method", "position_learn") == "position_learn":
+        return P[prefix + "positional_encoding_k_position_learn/embedding_position_learn"]
+    E, maxlen = spec["d_model"], spec["maxlen_k"]
+    enc = np.array([[pos / np.power(10000, (i - i % 2) / E) for i in range(E)] for pos in range(maxlen)])
+    enc[:, 0::2] = np.sin(enc[:, 0::2])
+    enc[:, 1::2] = np.cos(enc[:, 1::2])
+    return enc.astype(np.float32).astype(np.float64)
+
+
 def encode(seq_emb, seqlens, P, prefix, spec, step_seed=None, seq_index=0):
     """TransformerModel.py:84-123 with position_learn (dmt.conf:50); dropout (rate spec['dropout_rate']) when step_seed given."""
     T = seq_emb.shape[1]
     rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
     enc = seq_emb * (spec["d_model"] ** 0.5)
-    pos = P[prefix + "positional_encoding_k_position_learn/embedding_position_learn"]
-    enc = enc + pos[np.arange(T)][None, :, :]                          # positional_encoding_learn, util:281-316
+    pos = position_table(P, prefix, spec)
+    enc = enc + pos[np.arange(T)][None, :, :]                          # positional_encoding_learn, util:281-316 / positional_encoding :238-279
     enc = dropout(enc, rate, step_seed, 10 * seq_index + 0)            # TransformerModel.py:101
     for i in range(spec["num_blocks_encode"]):
         blk = prefix + "num_blocks_%d/" % i

@@ -210,7 +210,14 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         tar = torch.cat(tar_parts, -1)
         T = seq_emb.shape[1]
         rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
-        x = seq_emb * (d ** 0.5) + P[pre + "positional_encoding_k_position_learn/embedding_position_learn"][:T][None]
+        if spec.get("position_encoding_method", "position_learn") == "position_learn":
+            pos_tab = P[pre + "positional_encoding_k_position_learn/embedding_position_learn"]
+        else:
+            # position_sin_cos (TransformerModel_util.py:238-279), vectorised: angle[pos, i] = pos / 10000^((i - i % 2) / E)
+            ii = torch.arange(d, dtype=torch.float64)
+            ang = torch.arange(spec["maxlen_k"], dtype=torch.float64)[:, None] / torch.pow(torch.tensor(10000.0, dtype=torch.float64), (ii - ii % 2) / d)[None, :]
+            pos_tab = torch.where((torch.arange(d) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang)).float().to(seq_emb.dtype)
+        x = seq_emb * (d ** 0.5) + pos_tab[:T][None]
         x = st.R(_drop(x, rate, step_seed, 10 * i + 0))
         blk = pre + "num_blocks_0/"
         x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)

@@ -93,6 +93,24 @@ def test_conf_parser_matches_the_reference_parse():
     assert conf.zero_pad == g["model"]["zero_pad"] == "true"
 
 
+def test_conf_transformer_options_the_engine_takes_and_refuses():
+    """position_learn (dmt.conf) and position_sin_cos reach the engine's spec; the options that would need other graphs are refused by
+    name instead of being ignored."""
+    conf = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
+    assert conf.to_spec()["position_encoding_method"] == "position_learn"
+    conf.position_encoding_method = "position_sin_cos"
+    sp = conf.to_spec()
+    assert sp["position_encoding_method"] == "position_sin_cos"
+    st = VariableStore(S.scaled_spec(sp, {"Sku": 500, "Brand": 50, "Shopid": 50, "Cid3": 20}), "cpu", torch.float32, seed=0)
+    assert not any("position_learn" in k for k in st.state_dict())
+    for attr, val in (("position_encoding_method", "time_add"), ("is_trans_input_by_mlp", True), ("is_trans_out_concat_item", True),
+                      ("is_decoder_add_pos_emb", True), ("num_blocks_encode", 2)):
+        c2 = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
+        setattr(c2, attr, val)
+        with pytest.raises(NotImplementedError):
+            c2.to_spec()
+
+
 def test_product_spec_equals_oracle_spec():
     for suffix in ("12m_50", "12m_10"):
         so, sp = O.default_spec(suffix), S.default_spec(suffix)
