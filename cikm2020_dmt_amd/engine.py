@@ -732,10 +732,21 @@ class DMTEngine:
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(s, blk + ffs)
 
+    def decoder_query(self, tar):
+        """The decoder's one-step query from the scaled target rows: + row 0 of the sinusoid (sin(0) on the even columns, cos(0) on the
+        odd ones) when is_decoder_add_pos_emb (TransformerModel.py:148-149: dec += positional_encoding(dec, maxlen_q); dmt.conf: false)."""
+        if not self.spec.get("is_decoder_add_pos_emb"):
+            return tar
+        pe0 = getattr(self, "_pe0", None)
+        if pe0 is None or pe0.dtype != tar.dtype:
+            pe0 = self._pe0 = (torch.arange(self.spec["d_model"], device=tar.device) % 2).to(tar.dtype)
+        return tar + pe0
+
     def embedding_trans(self, batch: DeviceBatch):
         X, tar, zbuf = self.gather(batch)
         packs = self._last_packs
         n_seq = len(self.spec["attention_embed_pairs"])
+        tar = self.decoder_query(tar)
         # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
         # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
         # of one sequence's decoder fill the tails of another's big kernels.

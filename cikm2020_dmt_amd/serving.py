@@ -100,6 +100,7 @@ class CandidateScorer:
             b1 = self._row0(batch)
             X1, _tar1, _z1 = eng.gather(b1)
             tar, zbuf = eng.gather_pooled(batch)
+            tar = eng.decoder_query(tar)
             us = []
             for i, pairs in enumerate(spec["attention_embed_pairs"]):
                 lens1 = b1.feats[pairs[-1][0]].lens

@@ -332,9 +332,15 @@ def encode(seq_emb, seqlens, P, prefix, spec, step_seed=None, seq_index=0):
 
 
 def decode(query_emb, query_length, key_emb, key_length, P, prefix, spec, step_seed=None, seq_index=0):
-    """TransformerModel.py:125-171 (is_decoder_add_pos_emb=false)."""
+    """TransformerModel.py:125-171 (dmt.conf: is_decoder_add_pos_emb = false)."""
     rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
     dec = query_emb * (spec["d_model"] ** 0.5)
+    if spec.get("is_decoder_add_pos_emb"):                             # TransformerModel.py:148-149: sinusoid rows 0 .. Tq-1 (maxlen_q >= Tq)
+        E, Tq = spec["d_model"], query_emb.shape[1]
+        pe = np.array([[pos / np.power(10000, (i - i % 2) / E) for i in range(E)] for pos in range(Tq)])
+        pe[:, 0::2] = np.sin(pe[:, 0::2])
+        pe[:, 1::2] = np.cos(pe[:, 1::2])
+        dec = dec + pe.astype(np.float32).astype(np.float64)[None, :, :]
     dec = dropout(dec, rate, step_seed, 10 * seq_index + 1)            # TransformerModel.py:151
     for i in range(spec["num_blocks_decode"]):
         blk = prefix + "num_blocks_%d/" % i

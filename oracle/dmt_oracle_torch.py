@@ -222,7 +222,10 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         blk = pre + "num_blocks_0/"
         x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)
         mem = _ff(x, P, blk + "positionwise_feedforward/", st)
-        y = st.R(tar * (d ** 0.5))[:, None, :]
+        y = tar * (d ** 0.5)
+        if spec.get("is_decoder_add_pos_emb"):      # one-step query: sinusoid row 0 = (0, 1, 0, 1, ...)
+            y = y + (torch.arange(d) % 2).to(y.dtype)
+        y = st.R(y)[:, None, :]
         if rate and step_seed is not None:
             y = st.R(_drop(y, rate, step_seed, 10 * i + 1))
         if st.on:
