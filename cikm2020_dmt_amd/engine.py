@@ -215,7 +215,8 @@ class _GatherPlan:
             pooled_off += dim
         self.K = mmoe_input_width(spec)
         self.interest_off = pooled_off
-        assert self.interest_off + len(spec["attention_embed_pairs"]) * d == self.K
+        self.interest_blocks = len(spec["attention_embed_pairs"]) * (2 if spec.get("is_trans_out_concat_item") else 1)
+        assert self.interest_off + self.interest_blocks * d == self.K
         self.bias_off = (self.K + 3) // 4 * 4
         boff = self.bias_off
         for (name, rows, dim, feat, _side) in spec["embedding_list_bias"]:
@@ -732,6 +733,15 @@ class DMTEngine:
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(s, blk + ffs)
 
+    def interest_blocks(self, us, tar_scaled):
+        """The d_model-wide blocks of interest_state: user_stat per sequence, each followed by the RAW target embedding when
+        is_trans_out_concat_item (mmoe_transformer_unbias.py:212-219; the gather hands out the decoder's copy, scaled by sqrt(d_model):
+        undone here with one rounding in the compute dtype)."""
+        if not self.spec.get("is_trans_out_concat_item"):
+            return us
+        raw = tar_scaled * (1.0 / float(self.spec["d_model"]) ** 0.5)
+        return [t for u in us for t in (u, raw)]
+
     def decoder_query(self, tar):
         """The decoder's one-step query from the scaled target rows: + row 0 of the sinusoid (sin(0) on the even columns, cos(0) on the
         odd ones) when is_decoder_add_pos_emb (TransformerModel.py:148-149: dec += positional_encoding(dec, maxlen_q); dmt.conf: false)."""
@@ -746,6 +756,7 @@ class DMTEngine:
         X, tar, zbuf = self.gather(batch)
         packs = self._last_packs
         n_seq = len(self.spec["attention_embed_pairs"])
+        tar_scaled = tar
         tar = self.decoder_query(tar)
         # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
         # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
@@ -789,7 +800,7 @@ class DMTEngine:
             # (MMoE layer 0, experts, towers, loss and back) and most of the chip is idle -- Trainer._catch_up_early starts there
             self.junction_event = torch.cuda.Event()
             self.junction_event.record(main)
-        z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *us)
+        z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *self.interest_blocks(us, tar_scaled))
         self.intermediates["zbuf"] = z
         return z
 

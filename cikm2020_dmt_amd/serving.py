@@ -99,15 +99,15 @@ class CandidateScorer:
         try:
             b1 = self._row0(batch)
             X1, _tar1, _z1 = eng.gather(b1)
-            tar, zbuf = eng.gather_pooled(batch)
-            tar = eng.decoder_query(tar)
+            tar_scaled, zbuf = eng.gather_pooled(batch)
+            tar = eng.decoder_query(tar_scaled)
             us = []
             for i, pairs in enumerate(spec["attention_embed_pairs"]):
                 lens1 = b1.feats[pairs[-1][0]].lens
                 mem1 = eng.encode_prepared(X1[i], lens1, i)                    # [1, T, d], once per request
                 k_lens = lens1.expand(batch.B).contiguous()
                 us.append(eng.decode_shared(tar.unsqueeze(1), mem1, k_lens, i).squeeze(1))
-            z = AssembleFn.apply(zbuf, eng.plan.interest_off, spec["d_model"], *us)
+            z = AssembleFn.apply(zbuf, eng.plan.interest_off, spec["d_model"], *eng.interest_blocks(us, tar_scaled))
             tasks = eng.expert_gate(z, z_is_engine_buffer=True)          # (z is gather_pooled's zero-initialised zbuf)
             return tuple(eng.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         finally:

@@ -68,7 +68,10 @@ def scaled_spec(spec: dict, rows: Dict[str, int]) -> dict:
 
 def mmoe_input_width(spec) -> int:
     w = spec["feature_dimension"] + sum(d for (_n, _r, d, _f, _s) in spec["embedding_list"])
-    return w + len(spec["attention_embed_pairs"]) * spec["d_model"]
+    # interest state per sequence: user_stat [d_model], + the raw target-item embedding when is_trans_out_concat_item
+    # (mmoe_transformer_unbias.py:212-219; dmt.conf: false)
+    per_seq = spec["d_model"] * (2 if spec.get("is_trans_out_concat_item") else 1)
+    return w + len(spec["attention_embed_pairs"]) * per_seq
 
 
 def trans_prefix(i: int) -> str:

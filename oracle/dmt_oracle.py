@@ -120,7 +120,8 @@ def table_shapes(spec) -> Dict[str, tuple]:
 
 def mmoe_input_width(spec) -> int:
     w = spec["feature_dimension"] + sum(d for (_n, _r, d, _f, _s) in spec["embedding_list"])
-    return w + len(spec["attention_embed_pairs"]) * spec["d_model"]
+    per_seq = spec["d_model"] * (2 if spec.get("is_trans_out_concat_item") else 1)      # mmoe_transformer_unbias.py:212-219
+    return w + len(spec["attention_embed_pairs"]) * per_seq
 
 
 def trans_prefix(i: int) -> str:
@@ -390,7 +391,8 @@ def generate_data(inputs, P, spec):
 
 
 def trans_core(seq_data, P, spec, step_seed=None):
-    """mmoe_transformer_unbias.py:189-223 (is_trans_out_concat_item=false)."""
+    """mmoe_transformer_unbias.py:189-223; is_trans_out_concat_item (:212-215, dmt.conf: false): final_state = [user_stat, tar_sku_emb] with the
+    RAW target embedding (the decoder scales its own copy); is_trans_out_by_mlp (the dense on top of the pair) is not restated."""
     states = []
     for i, (mask, lens, seq_emb, tar, _ts) in enumerate(seq_data):
         prefix = trans_prefix(i)
@@ -398,7 +400,7 @@ def trans_core(seq_data, P, spec, step_seed=None):
         q_lens = np.ones(seq_q.shape[0], dtype=np.int64)
         memory = encode(seq_emb, lens, P, prefix, spec, step_seed, i)
         dec = decode(seq_q, q_lens, memory, lens, P, prefix, spec, step_seed, i)
-        states.append(dec[:, 0, :])
+        states.append(np.concatenate([dec[:, 0, :], tar], -1) if spec.get("is_trans_out_concat_item") else dec[:, 0, :])
     return np.concatenate(states, -1)
 
 

@@ -100,12 +100,17 @@ def test_conf_transformer_options_the_engine_takes_and_refuses():
     assert conf.to_spec()["position_encoding_method"] == "position_learn"
     conf.position_encoding_method = "position_sin_cos"
     conf.is_decoder_add_pos_emb = True
+    conf.is_trans_out_concat_item = True
     sp = conf.to_spec()
-    assert sp["position_encoding_method"] == "position_sin_cos" and sp["is_decoder_add_pos_emb"] is True
+    assert sp["position_encoding_method"] == "position_sin_cos" and sp["is_decoder_add_pos_emb"] is True and sp["is_trans_out_concat_item"] is True
+    assert S.mmoe_input_width(sp) == S.mmoe_input_width(dict(sp, is_trans_out_concat_item=False)) + 3 * sp["d_model"]
+    conf.is_trans_out_by_mlp = True
+    with pytest.raises(NotImplementedError):
+        conf.to_spec()
+    conf.is_trans_out_by_mlp = False
     st = VariableStore(S.scaled_spec(sp, {"Sku": 500, "Brand": 50, "Shopid": 50, "Cid3": 20}), "cpu", torch.float32, seed=0)
     assert not any("position_learn" in k for k in st.state_dict())
-    for attr, val in (("position_encoding_method", "time_add"), ("is_trans_input_by_mlp", True), ("is_trans_out_concat_item", True),
-                      ("num_blocks_encode", 2)):
+    for attr, val in (("position_encoding_method", "time_add"), ("is_trans_input_by_mlp", True), ("num_blocks_encode", 2)):
         c2 = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
         setattr(c2, attr, val)
         with pytest.raises(NotImplementedError):
