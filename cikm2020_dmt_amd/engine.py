@@ -215,7 +215,8 @@ class _GatherPlan:
             pooled_off += dim
         self.K = mmoe_input_width(spec)
         self.interest_off = pooled_off
-        self.interest_blocks = len(spec["attention_embed_pairs"]) * (2 if spec.get("is_trans_out_concat_item") else 1)
+        self.interest_blocks = len(spec["attention_embed_pairs"]) * (2 if (spec.get("is_trans_out_concat_item")
+                                                                           and not spec.get("is_trans_out_by_mlp")) else 1)
         assert self.interest_off + self.interest_blocks * d == self.K
         self.bias_off = (self.K + 3) // 4 * 4
         boff = self.bias_off
@@ -740,7 +741,13 @@ class DMTEngine:
         if not self.spec.get("is_trans_out_concat_item"):
             return us
         raw = tar_scaled * (1.0 / float(self.spec["d_model"]) ** 0.5)
-        return [t for u in us for t in (u, raw)]
+        if not self.spec.get("is_trans_out_by_mlp"):
+            return [t for u in us for t in (u, raw)]
+        out = []
+        for i, u in enumerate(us):      # :216-217: tf.layers.dense([user_stat, tar_sku_emb], d_model, name='dense_trans_concat_' + stag)
+            tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
+            out.append(ops.linear(torch.cat([u, raw], -1), self._lf(tp + "kernel"), self._lf(tp + "bias"), self._w(tp + "kernel")))
+        return out
 
     def decoder_query(self, tar):
         """The decoder's one-step query from the scaled target rows: + row 0 of the sinusoid (sin(0) on the even columns, cos(0) on the

@@ -69,8 +69,8 @@ def scaled_spec(spec: dict, rows: Dict[str, int]) -> dict:
 def mmoe_input_width(spec) -> int:
     w = spec["feature_dimension"] + sum(d for (_n, _r, d, _f, _s) in spec["embedding_list"])
     # interest state per sequence: user_stat [d_model], + the raw target-item embedding when is_trans_out_concat_item
-    # (mmoe_transformer_unbias.py:212-219; dmt.conf: false)
-    per_seq = spec["d_model"] * (2 if spec.get("is_trans_out_concat_item") else 1)
+    # (mmoe_transformer_unbias.py:212-219; dmt.conf: false), unless is_trans_out_by_mlp folds the pair back to d_model with a dense layer
+    per_seq = spec["d_model"] * (2 if (spec.get("is_trans_out_concat_item") and not spec.get("is_trans_out_by_mlp")) else 1)
     return w + len(spec["attention_embed_pairs"]) * per_seq
 
 

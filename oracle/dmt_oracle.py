@@ -120,7 +120,7 @@ def table_shapes(spec) -> Dict[str, tuple]:
 
 def mmoe_input_width(spec) -> int:
     w = spec["feature_dimension"] + sum(d for (_n, _r, d, _f, _s) in spec["embedding_list"])
-    per_seq = spec["d_model"] * (2 if spec.get("is_trans_out_concat_item") else 1)      # mmoe_transformer_unbias.py:212-219
+    per_seq = spec["d_model"] * (2 if (spec.get("is_trans_out_concat_item") and not spec.get("is_trans_out_by_mlp")) else 1)      # :212-219
     return w + len(spec["attention_embed_pairs"]) * per_seq
 
 
@@ -150,6 +150,11 @@ def param_shapes(spec) -> Dict[str, tuple]:
         shp[ff + "dense_1/bias"] = (d,)
         shp[ff + "ln/beta"] = (d,)
         shp[ff + "ln/gamma"] = (d,)
+        if spec.get("is_trans_out_concat_item") and spec.get("is_trans_out_by_mlp"):
+            # tf.layers.dense(final_state, d_model, name='dense_trans_concat_' + stag) inside variable_scope('trans_' + stag): :193, :216-217
+            tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
+            shp[tp + "kernel"] = (2 * d, d)
+            shp[tp + "bias"] = (d,)
         if not spec.get("tie_ffn", True):  # untied variant keeps a second copy for the decoder
             ffd = p + "num_blocks_0/positionwise_feedforward_dec/"
             for k in ("dense/kernel", "dense/bias", "dense_1/kernel", "dense_1/bias", "ln/beta", "ln/gamma"):
@@ -392,7 +397,7 @@ def generate_data(inputs, P, spec):
 
 def trans_core(seq_data, P, spec, step_seed=None):
     """mmoe_transformer_unbias.py:189-223; is_trans_out_concat_item (:212-215, dmt.conf: false): final_state = [user_stat, tar_sku_emb] with the
-    RAW target embedding (the decoder scales its own copy); is_trans_out_by_mlp (the dense on top of the pair) is not restated."""
+    RAW target embedding (the decoder scales its own copy); is_trans_out_by_mlp (:216-217): a dense layer folds the pair back to d_model."""
     states = []
     for i, (mask, lens, seq_emb, tar, _ts) in enumerate(seq_data):
         prefix = trans_prefix(i)
@@ -400,7 +405,13 @@ def trans_core(seq_data, P, spec, step_seed=None):
         q_lens = np.ones(seq_q.shape[0], dtype=np.int64)
         memory = encode(seq_emb, lens, P, prefix, spec, step_seed, i)
         dec = decode(seq_q, q_lens, memory, lens, P, prefix, spec, step_seed, i)
-        states.append(np.concatenate([dec[:, 0, :], tar], -1) if spec.get("is_trans_out_concat_item") else dec[:, 0, :])
+        final = dec[:, 0, :]
+        if spec.get("is_trans_out_concat_item"):
+            final = np.concatenate([final, tar], -1)
+            if spec.get("is_trans_out_by_mlp"):
+                tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
+                final = final @ P[tp + "kernel"] + P[tp + "bias"]
+        states.append(final)
     return np.concatenate(states, -1)
 
 

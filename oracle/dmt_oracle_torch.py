@@ -234,7 +234,13 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
             y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         y = _ff(y, P, blk + ffs, st)
-        states.append(torch.cat([y[:, 0, :], tar], -1) if spec.get("is_trans_out_concat_item") else y[:, 0, :])
+        fin = y[:, 0, :]
+        if spec.get("is_trans_out_concat_item"):
+            fin = torch.cat([fin, tar], -1)
+            if spec.get("is_trans_out_by_mlp"):
+                tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
+                fin = st.R(fin @ P[tp + "kernel"] + P[tp + "bias"])
+        states.append(fin)
         inter["seq_emb_%d" % i] = seq_emb
         inter["tar_emb"] = tar
         inter["memory_%d" % i] = mem

@@ -196,7 +196,7 @@ def test_edge_cases_single_example_and_all_ids_colliding(cuda, dtype):
     assert moved[7] and moved.sum() < 0.5 * len(moved)
 
 
-@pytest.mark.parametrize("dtype,dec_pos", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, "concat")])
+@pytest.mark.parametrize("dtype,dec_pos", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, "concat"), (torch.float32, "concat_mlp")])
 def test_position_sin_cos_matches_oracle(cuda, dtype, dec_pos):
     """position_encoding_method = position_sin_cos (TransformerModel.py:62-64, TransformerModel_util.py:238-279) at engine level: no position
     variable exists, the constant sinusoid is added in the gather (and, is_decoder_add_pos_emb, its row 0 to the decoder's one-step query);
@@ -206,8 +206,10 @@ def test_position_sin_cos_matches_oracle(cuda, dtype, dec_pos):
     so, sp = dict(so, position_encoding_method="position_sin_cos"), dict(sp, position_encoding_method="position_sin_cos")
     if dec_pos:       # is_decoder_add_pos_emb (TransformerModel.py:148-149): the sinusoid's row 0 on the scaled target item
         so, sp = dict(so, is_decoder_add_pos_emb=True), dict(sp, is_decoder_add_pos_emb=True)
-    if dec_pos == "concat":     # + is_trans_out_concat_item (mmoe_transformer_unbias.py:212-215): the raw target embedding beside every user_stat
+    if dec_pos in ("concat", "concat_mlp"):     # + is_trans_out_concat_item (mmoe_transformer_unbias.py:212-215): the raw target embedding beside every user_stat
         so, sp = dict(so, is_trans_out_concat_item=True), dict(sp, is_trans_out_concat_item=True)
+    if dec_pos == "concat_mlp":                 # + is_trans_out_by_mlp (:216-217): a dense layer folds the pair back to d_model
+        so, sp = dict(so, is_trans_out_by_mlp=True), dict(sp, is_trans_out_by_mlp=True)
     P = O.init_params(so, seed=13)
     assert not any("position_learn" in k for k in P)
     inputs, mask, label = make_batch(sp, 24, seed=8, lengths="ragged", weights="random")

@@ -105,8 +105,8 @@ def test_conf_transformer_options_the_engine_takes_and_refuses():
     assert sp["position_encoding_method"] == "position_sin_cos" and sp["is_decoder_add_pos_emb"] is True and sp["is_trans_out_concat_item"] is True
     assert S.mmoe_input_width(sp) == S.mmoe_input_width(dict(sp, is_trans_out_concat_item=False)) + 3 * sp["d_model"]
     conf.is_trans_out_by_mlp = True
-    with pytest.raises(NotImplementedError):
-        conf.to_spec()
+    sp2 = conf.to_spec()
+    assert sp2["is_trans_out_by_mlp"] is True and S.mmoe_input_width(sp2) == S.mmoe_input_width(dict(sp, is_trans_out_concat_item=False))
     conf.is_trans_out_by_mlp = False
     st = VariableStore(S.scaled_spec(sp, {"Sku": 500, "Brand": 50, "Shopid": 50, "Cid3": 20}), "cpu", torch.float32, seed=0)
     assert not any("position_learn" in k for k in st.state_dict())
