@@ -136,10 +136,9 @@ class Conf:
         """Plain-dict model spec for cikm2020_dmt_amd.engine (only the default DMT options are supported)."""
         if self.model_type not in ("mmoe_transformer_unbias", "mmoe_transformer"):
             raise NotImplementedError("model_type %s is outside the DMT hot path" % self.model_type)
-        if self.position_encoding_method not in ("position_learn", "position_sin_cos") or self.is_trans_input_by_mlp \
-                or self.num_blocks_encode != 1 or self.num_blocks_decode != 1:
+        if self.position_encoding_method not in ("position_learn", "position_sin_cos") or self.num_blocks_encode != 1 or self.num_blocks_decode != 1:
             raise NotImplementedError("Transformer options outside the engine: position_learn / position_sin_cos, is_decoder_add_pos_emb, "
-                                      "is_trans_out_concat_item (with or without is_trans_out_by_mlp), 1 + 1 blocks, no input MLP are implemented "
+                                      "is_trans_input_by_mlp, is_trans_out_concat_item (with or without is_trans_out_by_mlp), 1 + 1 blocks are implemented "
                                       "(dmt.conf ships position_learn, everything else off)")
         if self[MODEL][IS_BN] or self[MODEL][IS_DROPOUT]:
             raise NotImplementedError("is_bn / is_dropout are false in dmt.conf and not implemented")
@@ -164,4 +163,5 @@ class Conf:
             dropout_rate_bias=getattr(self, "dropout_rate_bias", [0.5, 0.5]), position_encoding_method=self.position_encoding_method,
             is_decoder_add_pos_emb=bool(self.is_decoder_add_pos_emb), is_trans_out_concat_item=bool(self.is_trans_out_concat_item),
             is_trans_out_by_mlp=bool(self.is_trans_out_concat_item and self.is_trans_out_by_mlp),
+            is_trans_input_by_mlp=bool(self.is_trans_input_by_mlp),
         )

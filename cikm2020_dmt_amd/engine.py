@@ -301,10 +301,13 @@ class GatherFn(torch.autograd.Function):
             f.pooled_off, f.seq_id, f.seq_off, f.group = it["pooled_off"], it["seq_id"], it["seq_off"], it["group"]
             f.inv_wsum = inv[i].data_ptr()
         desc.n_seq = n_seq
+        # is_trans_input_by_mlp (mmoe_transformer_unbias.py:196-198): the dense layers sit between the lookup and the scale / position /
+        # dropout prep, so the gather hands out the RAW rows (scale 1, no positions, no dropout) and the engine does the prep afterwards
+        raw = bool(spec.get("is_trans_input_by_mlp"))
         for s in range(n_seq):
             desc.seq_out[s] = X[s].data_ptr()
             desc.seq_T[s] = seq_T[s]
-            desc.pos[s] = pos_leaves[s].data_ptr()
+            desc.pos[s] = None if raw else pos_leaves[s].data_ptr()
             if packs[s] is not None:
                 desc.seq_row_off[s] = packs[s].row_off.data_ptr()
                 desc.seq_row_len[s] = engine.seq_lens(batch, s).data_ptr()
@@ -312,13 +315,13 @@ class GatherFn(torch.autograd.Function):
                 raise ValueError("sequence %d length %d exceeds the learned position table (%d rows)" % (s, seq_T[s], pos_leaves[s].shape[0]))
         desc.tar_out = tar.data_ptr()
         desc.d_model = d
-        desc.seq_scale = float(d) ** 0.5
+        desc.seq_scale = 1.0 if raw else float(d) ** 0.5
         desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
         desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
         desc.out_dtype = ops.dt_code(cdt)
         # block-input dropout of every sequence (TransformerModel.py:101) is applied by the gather itself; its gradient by the
         # consumers of dX (dmt_embgrad_reduce, dmt_colsum_drop) -- same counter mask as ops.dropout(x, rate, seed, 10*s)
-        seeds, keep = engine._input_dropout(n_seq)
+        seeds, keep = engine._input_dropout(n_seq) if not raw else ([0] * n_seq, 0.0)
         for s in range(n_seq):
             desc.seq_drop_seed[s] = seeds[s]
         desc.seq_drop_keep = keep
@@ -328,6 +331,7 @@ class GatherFn(torch.autograd.Function):
         ctx.engine, ctx.batch, ctx.inv, ctx.seq_T, ctx.packs = engine, batch, inv, seq_T, packs
         ctx.pos_shapes = [tuple(pl.shape) for pl in pos_leaves]
         ctx.pos_leaves = pos_leaves
+        ctx.raw = raw
         return (*X, tar, zbuf)
 
     @staticmethod
@@ -335,7 +339,7 @@ class GatherFn(torch.autograd.Function):
         engine, batch = ctx.engine, ctx.batch
         spec = engine.spec
         n_seq = len(spec["attention_embed_pairs"])
-        if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None or not pl.requires_grad
+        if engine.defer_sparse and all(g is not None for g in grads) and all(ops._grad_view(pl) is not None or not pl.requires_grad or ctx.raw
                                                                               for pl in ctx.pos_leaves):
             # Trainer.train_step finishes this node itself (finish_sparse_backward), on the index lane, beside the deferred weight gradients
             engine._pending_sparse = (ctx, grads)
@@ -360,7 +364,7 @@ class GatherFn(torch.autograd.Function):
         # learned positions: dP[t] = sum_b dX[b, t]   (lookup by range(T), TransformerModel_util.py:296-306)
         dpos = []
         for s in range(n_seq):
-            if not ctx.pos_leaves[s].requires_grad:      # position_sin_cos: a constant table, nothing to accumulate
+            if ctx.raw or not ctx.pos_leaves[s].requires_grad:      # position_sin_cos: a constant table; raw rows: the prep op has the gradient
                 dpos.append(None)
                 continue
             # accumulate straight into the position table's gradient arena when it is reachable (no zero-fill, no autograd add)
@@ -587,7 +591,7 @@ class DMTEngine:
               and self.use_mhsa and store.mhsa.get(blk + "self-attention/") is not None and ops.mhsa_supported(d, H, T, batch.B)
               and self.use_q1mem and store.q1mem.get(blk + "vanilla_attention/") is not None and ops.q1mem_supported(d, H, T)
               and self.use_chain and store.chain.get(blk + "positionwise_feedforward/") is not None
-              and T >= 8 and SeqPack.eligible(col.lens_host, T))
+              and T >= 8 and SeqPack.eligible(col.lens_host, T) and not spec.get("is_trans_input_by_mlp"))
         if ok:
             R = int(col.lens_host.astype(np.int64).sum())
             if R <= self.packed_rows_min_saving * batch.B * T:
@@ -734,17 +738,24 @@ class DMTEngine:
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         return self.ff(s, blk + ffs)
 
-    def interest_blocks(self, us, tar_scaled):
+    def interest_blocks(self, us, tars_scaled):
         """The d_model-wide blocks of interest_state: user_stat per sequence, each followed by the RAW target embedding when
         is_trans_out_concat_item (mmoe_transformer_unbias.py:212-219; the gather hands out the decoder's copy, scaled by sqrt(d_model):
         undone here with one rounding in the compute dtype)."""
         if not self.spec.get("is_trans_out_concat_item"):
             return us
-        raw = tar_scaled * (1.0 / float(self.spec["d_model"]) ** 0.5)
+        if not isinstance(tars_scaled, (list, tuple)):
+            tars_scaled = [tars_scaled] * len(us)
+        inv = 1.0 / float(self.spec["d_model"]) ** 0.5
+        raws, seen = [], {}
+        for t in tars_scaled:                      # (one division per distinct tensor: without the input MLP all sequences share it)
+            if id(t) not in seen:
+                seen[id(t)] = t * inv
+            raws.append(seen[id(t)])
         if not self.spec.get("is_trans_out_by_mlp"):
-            return [t for u in us for t in (u, raw)]
+            return [t for u, raw in zip(us, raws) for t in (u, raw)]
         out = []
-        for i, u in enumerate(us):      # :216-217: tf.layers.dense([user_stat, tar_sku_emb], d_model, name='dense_trans_concat_' + stag)
+        for i, (u, raw) in enumerate(zip(us, raws)):      # :216-217: tf.layers.dense([user_stat, tar_sku_emb], d_model, name='dense_trans_concat_' + stag)
             tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
             out.append(ops.linear(torch.cat([u, raw], -1), self._lf(tp + "kernel"), self._lf(tp + "bias"), self._w(tp + "kernel")))
         return out
@@ -763,15 +774,29 @@ class DMTEngine:
         X, tar, zbuf = self.gather(batch)
         packs = self._last_packs
         n_seq = len(self.spec["attention_embed_pairs"])
-        tar_scaled = tar
-        tar = self.decoder_query(tar)
+        tars_scaled = [tar] * n_seq
         # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
         # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
         # of one sequence's decoder fill the tails of another's big kernels.
         main = torch.cuda.current_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
         pairs_all = self.spec["attention_embed_pairs"]
         us, order = [None] * n_seq, list(range(n_seq))
-        tars = FanOutFn.apply(tar, n_seq) if (tar.requires_grad and n_seq > 1) else (tar,) * n_seq
+        tars = list(FanOutFn.apply(tar, n_seq) if (tar.requires_grad and n_seq > 1) else (tar,) * n_seq)
+        if self.spec.get("is_trans_input_by_mlp"):
+            # mmoe_transformer_unbias.py:196-198: seq_emb / tar_sku_emb through 'dense_trans_seq_<stag>' / 'dense_trans_sku_<stag>', then the
+            # prep the gather skipped (TransformerModel.py:96-101: * sqrt(d_model), + positions, dropout); the decoder scales its own copy
+            scale = float(self.spec["d_model"]) ** 0.5
+            rate = self.spec.get("dropout_rate", 0.0)
+            pos_tabs = self.position_tables()
+            for i in range(n_seq):
+                tp = "embedding_trans/trans_sequence_%d/" % i
+                ks, kt = tp + "dense_trans_seq_sequence_%d/" % i, tp + "dense_trans_sku_sequence_%d/" % i
+                xi = ops.linear(X[i], self._lf(ks + "kernel"), self._lf(ks + "bias"), self._w(ks + "kernel"))
+                xi = ops.ScaleAddPosFn.apply(xi, pos_tabs[i], scale)
+                X[i] = ops.dropout(xi, rate, self.dropout_step_seed, 10 * i + 0)
+                tars[i] = ops.linear(tars[i], self._lf(kt + "kernel"), self._lf(kt + "bias"), self._w(kt + "kernel")) * scale
+            tars_scaled = list(tars)
+        tars = [self.decoder_query(t) for t in tars]
         if main is not None:
             # Sequence 0 stays on the compute stream; the others start from ONE event (the gathered inputs), not behind sequence 0.
             # (Measured: issue order -- by length, either way -- moves the step by < 1 %; putting the compute stream's sequence
@@ -807,7 +832,7 @@ class DMTEngine:
             # (MMoE layer 0, experts, towers, loss and back) and most of the chip is idle -- Trainer._catch_up_early starts there
             self.junction_event = torch.cuda.Event()
             self.junction_event.record(main)
-        z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *self.interest_blocks(us, tar_scaled))
+        z = AssembleFn.apply(zbuf, self.plan.interest_off, self.spec["d_model"], *self.interest_blocks(us, tars_scaled))
         self.intermediates["zbuf"] = z
         return z
 
@@ -947,7 +972,7 @@ class DMTEngine:
         desc.entry_base[len(plan.items)] = ebase
         desc.total_rows = store.total_rows
         desc.d_model = spec["d_model"]
-        desc.seq_scale = float(spec["d_model"]) ** 0.5
+        desc.seq_scale = 1.0 if spec.get("is_trans_input_by_mlp") else float(spec["d_model"]) ** 0.5
         return desc, ebase
 
     def prepare(self, batch):

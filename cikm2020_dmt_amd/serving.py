@@ -41,6 +41,9 @@ class CandidateScorer:
         """optimizer: the TFAdam of a LIVE trainer sharing this engine's tables, or None for a frozen / restored model.  The exact lazy
         Adam leaves zero-gradient updates of untouched rows pending; scoring reads rows without replaying them, so with
         a live optimizer the tables are flushed before every request that follows a train step."""
+        if engine.spec.get("is_trans_input_by_mlp"):
+            raise NotImplementedError("CandidateScorer: is_trans_input_by_mlp (the encode-once request path gathers prepared rows); score such a "
+                                      "model through DMTEngine.inference(batch, is_predict=True) on the tiled request")
         self.engine = engine
         self.optimizer = optimizer
         self._flushed_at = -1

@@ -128,6 +128,12 @@ class VariableStore:
                     self._view(blk + "%s/%s/bias" % (att, dn), bq, (slice(j * d, (j + 1) * d),), "zeros", (d,))
                 self._simple(blk + att + "/ln/beta", (d,), "zeros")
                 self._simple(blk + att + "/ln/gamma", (d,), "ones")
+            if sp.get("is_trans_input_by_mlp"):
+                # tf.layers.dense(seq_emb / tar_sku_emb, d_model, name='dense_trans_seq_' / 'dense_trans_sku_' + stag) (mmoe_transformer_unbias.py:196-198)
+                for nm in ("seq", "sku"):
+                    tp = "embedding_trans/trans_sequence_%d/dense_trans_%s_sequence_%d/" % (i, nm, i)
+                    self._simple(tp + "kernel", (d, d), "xavier")
+                    self._simple(tp + "bias", (d,), "zeros")
             if sp.get("is_trans_out_concat_item") and sp.get("is_trans_out_by_mlp"):
                 # tf.layers.dense([user_stat, tar_sku_emb], d_model, name='dense_trans_concat_' + stag) (mmoe_transformer_unbias.py:216-217)
                 tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)

@@ -150,6 +150,12 @@ def param_shapes(spec) -> Dict[str, tuple]:
         shp[ff + "dense_1/bias"] = (d,)
         shp[ff + "ln/beta"] = (d,)
         shp[ff + "ln/gamma"] = (d,)
+        if spec.get("is_trans_input_by_mlp"):
+            # tf.layers.dense(seq_emb / tar_sku_emb, d_model, name='dense_trans_seq_' / 'dense_trans_sku_' + stag) inside 'trans_' + stag: :196-198
+            for nm in ("seq", "sku"):
+                tp = "embedding_trans/trans_sequence_%d/dense_trans_%s_sequence_%d/" % (i, nm, i)
+                shp[tp + "kernel"] = (d, d)
+                shp[tp + "bias"] = (d,)
         if spec.get("is_trans_out_concat_item") and spec.get("is_trans_out_by_mlp"):
             # tf.layers.dense(final_state, d_model, name='dense_trans_concat_' + stag) inside variable_scope('trans_' + stag): :193, :216-217
             tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
@@ -401,6 +407,10 @@ def trans_core(seq_data, P, spec, step_seed=None):
     states = []
     for i, (mask, lens, seq_emb, tar, _ts) in enumerate(seq_data):
         prefix = trans_prefix(i)
+        if spec.get("is_trans_input_by_mlp"):          # :196-198, before the Transformer's own scale / position / dropout prep
+            tp = "embedding_trans/trans_sequence_%d/" % i
+            seq_emb = seq_emb @ P[tp + "dense_trans_seq_sequence_%d/kernel" % i] + P[tp + "dense_trans_seq_sequence_%d/bias" % i]
+            tar = tar @ P[tp + "dense_trans_sku_sequence_%d/kernel" % i] + P[tp + "dense_trans_sku_sequence_%d/bias" % i]
         seq_q = tar[:, None, :]
         q_lens = np.ones(seq_q.shape[0], dtype=np.int64)
         memory = encode(seq_emb, lens, P, prefix, spec, step_seed, i)

@@ -208,6 +208,10 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
             tar_parts.append(_lookup_zero_pad(P["embedding_trans/%s/embedding" % table_of[itf]], tidx))
         seq_emb = torch.cat(seq_parts, -1)
         tar = torch.cat(tar_parts, -1)
+        if spec.get("is_trans_input_by_mlp"):          # mmoe_transformer_unbias.py:196-198
+            tp = "embedding_trans/trans_sequence_%d/" % i
+            seq_emb = st.R(seq_emb @ P[tp + "dense_trans_seq_sequence_%d/kernel" % i] + P[tp + "dense_trans_seq_sequence_%d/bias" % i])
+            tar = st.R(tar @ P[tp + "dense_trans_sku_sequence_%d/kernel" % i] + P[tp + "dense_trans_sku_sequence_%d/bias" % i])
         T = seq_emb.shape[1]
         rate = spec.get("dropout_rate", 0.0) if step_seed is not None else 0.0
         if spec.get("position_encoding_method", "position_learn") == "position_learn":

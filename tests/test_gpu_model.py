@@ -196,8 +196,9 @@ def test_edge_cases_single_example_and_all_ids_colliding(cuda, dtype):
     assert moved[7] and moved.sum() < 0.5 * len(moved)
 
 
-@pytest.mark.parametrize("dtype,dec_pos", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, "concat"), (torch.float32, "concat_mlp")])
-def test_position_sin_cos_matches_oracle(cuda, dtype, dec_pos):
+@pytest.mark.parametrize("dtype,dec_pos", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, "concat"), (torch.float32, "concat_mlp"),
+                                           (torch.float32, "in_mlp"), (torch.bfloat16, "in_mlp")])
+def test_transformer_options_match_oracle(cuda, dtype, dec_pos):
     """position_encoding_method = position_sin_cos (TransformerModel.py:62-64, TransformerModel_util.py:238-279) at engine level: no position
     variable exists, the constant sinusoid is added in the gather (and, is_decoder_add_pos_emb, its row 0 to the decoder's one-step query);
     forward, loss, every gradient and two train steps against the oracle
@@ -208,13 +209,23 @@ def test_position_sin_cos_matches_oracle(cuda, dtype, dec_pos):
         so, sp = dict(so, is_decoder_add_pos_emb=True), dict(sp, is_decoder_add_pos_emb=True)
     if dec_pos in ("concat", "concat_mlp"):     # + is_trans_out_concat_item (mmoe_transformer_unbias.py:212-215): the raw target embedding beside every user_stat
         so, sp = dict(so, is_trans_out_concat_item=True), dict(sp, is_trans_out_concat_item=True)
+    if dec_pos == "in_mlp":                     # is_trans_input_by_mlp (:196-198) with learned positions, dropout on, + the concat of the MLP's target
+        so, sp = small_specs()
+        opt = dict(is_trans_input_by_mlp=True, is_trans_out_concat_item=True)
+        so, sp = dict(so, **opt), dict(sp, **opt)
     if dec_pos == "concat_mlp":                 # + is_trans_out_by_mlp (:216-217): a dense layer folds the pair back to d_model
         so, sp = dict(so, is_trans_out_by_mlp=True), dict(sp, is_trans_out_by_mlp=True)
     P = O.init_params(so, seed=13)
-    assert not any("position_learn" in k for k in P)
+    learned = so.get("position_encoding_method", "position_learn") == "position_learn"
+    assert any("position_learn" in k for k in P) == learned
+    if dec_pos == "in_mlp":
+        rng = np.random.default_rng(1)
+        for k in P:                         # (tf.layers biases start at zero: make the new layers' biases count)
+            if "dense_trans_s" in k and k.endswith("/bias"):
+                P[k] = 0.05 * rng.standard_normal(P[k].shape)
     inputs, mask, label = make_batch(sp, 24, seed=8, lengths="ragged", weights="random")
     tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=False)
-    assert not any("position_learn" in k for k in tr.store.state_dict())
+    assert any("position_learn" in k for k in tr.store.state_dict()) == learned
     tr.store.load_state(P)
     (c_ref, o_ref), yb_ref = O.inference(inputs, P, so)
     loss_ref, (c_t, o_t, _yb_t), G = OT.loss_and_grads(P, inputs, mask, so)
@@ -237,6 +248,19 @@ def test_position_sin_cos_matches_oracle(cuda, dtype, dec_pos):
     l1 = float(tr.train_step(tr.make_batch(inputs, mask, label)))
     l2 = float(tr.train_step(tr.make_batch(inputs, mask, label)))
     assert abs(l1 - loss) <= 1e-3 * abs(loss) and l2 < l1
+    if dec_pos == "in_mlp" and dtype == torch.float32:
+        # the prep the gather skips for this variant (scale, positions, DROPOUT of the block input) runs as separate ops: same masks as the oracle's
+        sod = dict(so, dropout_rate=0.1, dropout_rate_bias=[0.5, 0.5])
+        trd = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=True, dropout_seed=123)
+        trd.store.load_state(P)
+        loss_d, (c_d, _o_d, _yb_d), Gd = OT.loss_and_grads(P, inputs, mask, sod, step_seed=123)
+        got_loss = float(trd.forward_backward(trd.make_batch(inputs, mask, label)))
+        assert np.abs(trd.last["out"][0][0].detach().cpu().numpy() - c_d).max() < t["logit"] and abs(got_loss - loss_d) <= 1e-4 * abs(loss_d)
+        gd = dict(trd.store.grad_dict())
+        gd.update(sparse_to_dense_tables(trd.store, trd.engine.sparse))
+        for name, g in gd.items():
+            err = np.linalg.norm(g - Gd[name]) / max(np.linalg.norm(Gd[name]), 1e-6 * gscale * np.sqrt(g.size))
+            assert err < t["grad"], (name, float(err))
 
 
 def test_padded_batch_equals_tight_batch(cuda):

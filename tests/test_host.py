@@ -110,7 +110,9 @@ def test_conf_transformer_options_the_engine_takes_and_refuses():
     conf.is_trans_out_by_mlp = False
     st = VariableStore(S.scaled_spec(sp, {"Sku": 500, "Brand": 50, "Shopid": 50, "Cid3": 20}), "cpu", torch.float32, seed=0)
     assert not any("position_learn" in k for k in st.state_dict())
-    for attr, val in (("position_encoding_method", "time_add"), ("is_trans_input_by_mlp", True), ("num_blocks_encode", 2)):
+    conf.is_trans_input_by_mlp = True
+    assert conf.to_spec()["is_trans_input_by_mlp"] is True
+    for attr, val in (("position_encoding_method", "time_add"), ("num_blocks_encode", 2), ("num_blocks_decode", 2)):
         c2 = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
         setattr(c2, attr, val)
         with pytest.raises(NotImplementedError):
