@@ -136,9 +136,9 @@ class Conf:
         """Plain-dict model spec for cikm2020_dmt_amd.engine (only the default DMT options are supported)."""
         if self.model_type not in ("mmoe_transformer_unbias", "mmoe_transformer"):
             raise NotImplementedError("model_type %s is outside the DMT hot path" % self.model_type)
-        if self.position_encoding_method not in ("position_learn", "position_sin_cos") or self.num_blocks_encode != 1 or self.num_blocks_decode != 1:
+        if self.position_encoding_method not in ("position_learn", "position_sin_cos") or self.num_blocks_encode < 1 or self.num_blocks_decode < 1:
             raise NotImplementedError("Transformer options outside the engine: position_learn / position_sin_cos, is_decoder_add_pos_emb, "
-                                      "is_trans_input_by_mlp, is_trans_out_concat_item (with or without is_trans_out_by_mlp), 1 + 1 blocks are implemented "
+                                      "is_trans_input_by_mlp, is_trans_out_concat_item (with or without is_trans_out_by_mlp), >= 1 blocks each way are implemented "
                                       "(dmt.conf ships position_learn, everything else off)")
         if self[MODEL][IS_BN] or self[MODEL][IS_DROPOUT]:
             raise NotImplementedError("is_bn / is_dropout are false in dmt.conf and not implemented")
@@ -155,7 +155,7 @@ class Conf:
             embedding_list=[tuple(e) for e in self.embedding_list], embedding_list_bias=[tuple(e) for e in self.embedding_list_bias],
             attention_embed_pairs=self.attention_embed_pairs, attention_embed_seq_ts=self.attention_embed_seq_ts,
             feature_dimension=m[FEAT_DIM], d_model=self.d_model, d_ff=self.d_ff, num_heads=self.num_heads, maxlen_k=self.maxlen_k,
-            num_blocks_encode=1, num_blocks_decode=1, hidden_units_bottom=m[hidden_units_bottom], hidden_units_task=m[hidden_units_task],
+            num_blocks_encode=int(self.num_blocks_encode), num_blocks_decode=int(self.num_blocks_decode), hidden_units_bottom=m[hidden_units_bottom], hidden_units_task=m[hidden_units_task],
             num_experts=m[num_experts], num_tasks=2, hidden_units_bias=m[HIDDEN_UNITS_BIAS] or [], output_units=m[OUTPUT_UNITS],
             weight_ctr=self.weight_ctr, weight_ecvr=self.weight_ecvr, loss_weight=self[PARAMETER][LOSS_WEIGHT],
             loss_unbias_method=getattr(self, "loss_unbias_method", "two_head_add"),

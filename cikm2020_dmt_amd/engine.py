@@ -711,32 +711,38 @@ class DMTEngine:
 
     def encode_prepared(self, x, lens, i, pack=None):
         """TransformerModel.encode after the input prep (x = sqrt(d)*seq_emb + P, fused into the gather)."""
-        blk = trans_prefix(i) + "num_blocks_0/"
         # TransformerModel.py:101 dropout(enc): already applied by the gather (GatherFn), stream id 10 * i + 0
-        x = self.mha_self(x, lens, blk, 10 * i + 2, pack=pack)
-        return self.ff(x, blk + "positionwise_feedforward/")
+        for j in range(int(self.spec.get("num_blocks_encode", 1))):          # TransformerModel.py:104-121 (dmt.conf: one block)
+            blk = trans_prefix(i) + "num_blocks_%d/" % j
+            x = self.mha_self(x, lens, blk, 10 * i + 2, pack=pack)
+            x = self.ff(x, blk + "positionwise_feedforward/")
+        return x
 
     def decode_prepared(self, y, mem, lens, i, pack=None):
         """TransformerModel.decode after the input prep (y = sqrt(d)*tar[:,None,:])."""
-        blk = trans_prefix(i) + "num_blocks_0/"
         y = ops.dropout(y, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 1)     # TransformerModel.py:151
-        y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3, pack=pack)
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
-        return self.ff(y, blk + ffs)
+        for j in range(int(self.spec.get("num_blocks_decode", 1))):          # TransformerModel.py:154-169 (dmt.conf: one block)
+            blk = trans_prefix(i) + "num_blocks_%d/" % j
+            y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3, pack=pack)
+            y = self.ff(y, blk + ffs)
+        return y
 
     def decode_shared(self, y, mem1, k_lens, i):
         """decode_prepared for B queries against ONE shared memory mem1 [1, T, d] (serving: every candidate row of a request has
         the same user): K | V are projected once and broadcast through a zero batch stride.  Inference only (no dropout)."""
-        blk = trans_prefix(i) + "num_blocks_0/"
         d, H = self.spec["d_model"], self.spec["num_heads"]
-        a = blk + "vanilla_attention/"
-        wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
-        q = ops.linear(y, wl[:, :d], bl[:d], self._wslice(w, 0, d))
-        kv = ops.linear(mem1, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d)).expand(y.shape[0], -1, -1)
-        s = ops.AttnFn.apply(q, kv, y, None, k_lens, H, d, False, 0, 1.0, self.kopts)
-        s = ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
-        return self.ff(s, blk + ffs)
+        for j in range(int(self.spec.get("num_blocks_decode", 1))):
+            blk = trans_prefix(i) + "num_blocks_%d/" % j
+            a = blk + "vanilla_attention/"
+            wl, bl, w = self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel")
+            q = ops.linear(y, wl[:, :d], bl[:d], self._wslice(w, 0, d))
+            kv = ops.linear(mem1, wl[:, d:], bl[d:], self._wslice(w, d, 3 * d)).expand(y.shape[0], -1, -1)
+            s = ops.AttnFn.apply(q, kv, y, None, k_lens, H, d, False, 0, 1.0, self.kopts)
+            s = ops.layer_norm(s, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))
+            y = self.ff(s, blk + ffs)
+        return y
 
     def interest_blocks(self, us, tars_scaled):
         """The d_model-wide blocks of interest_state: user_stat per sequence, each followed by the RAW target embedding when

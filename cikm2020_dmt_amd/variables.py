@@ -118,16 +118,29 @@ class VariableStore:
             pre = trans_prefix(i)
             if sp.get("position_encoding_method", "position_learn") == "position_learn":      # (position_sin_cos adds a constant: no variable)
                 self._simple(pre + "positional_encoding_k_position_learn/embedding_position_learn", (sp["maxlen_k"], d), "xavier")
-            blk = pre + "num_blocks_0/"
-            for att in ("self-attention", "vanilla_attention"):
-                wq, bq = blk + att + "/qkv_kernel", blk + att + "/qkv_bias"
-                self._leaf(wq, (d, 3 * d))
-                self._leaf(bq, (3 * d,))
-                for j, dn in enumerate(("dense", "dense_1", "dense_2")):
-                    self._view(blk + "%s/%s/kernel" % (att, dn), wq, (slice(None), slice(j * d, (j + 1) * d)), "xavier", (d, d))
-                    self._view(blk + "%s/%s/bias" % (att, dn), bq, (slice(j * d, (j + 1) * d),), "zeros", (d,))
-                self._simple(blk + att + "/ln/beta", (d,), "zeros")
-                self._simple(blk + att + "/ln/gamma", (d,), "ones")
+            ne, nd = int(sp.get("num_blocks_encode", 1)), int(sp.get("num_blocks_decode", 1))
+            for j in range(max(ne, nd)):
+                blk = pre + "num_blocks_%d/" % j
+                for att in (("self-attention",) if j < ne else ()) + (("vanilla_attention",) if j < nd else ()):
+                    wq, bq = blk + att + "/qkv_kernel", blk + att + "/qkv_bias"
+                    self._leaf(wq, (d, 3 * d))
+                    self._leaf(bq, (3 * d,))
+                    for c, dn in enumerate(("dense", "dense_1", "dense_2")):
+                        self._view(blk + "%s/%s/kernel" % (att, dn), wq, (slice(None), slice(c * d, (c + 1) * d)), "xavier", (d, d))
+                        self._view(blk + "%s/%s/bias" % (att, dn), bq, (slice(c * d, (c + 1) * d),), "zeros", (d,))
+                    self._simple(blk + att + "/ln/beta", (d,), "zeros")
+                    self._simple(blk + att + "/ln/gamma", (d,), "ones")
+                # (encoder block j and decoder block j open the same scope 'num_blocks_j' under AUTO_REUSE: one feed-forward, TransformerModel.py:104-123,154-171)
+                ffs = [blk + "positionwise_feedforward/"] if (j < ne or sp.get("tie_ffn", True)) else []
+                if not sp.get("tie_ffn", True) and j < nd:
+                    ffs.append(blk + "positionwise_feedforward_dec/")
+                for ff in ffs:
+                    self._simple(ff + "dense/kernel", (d, dff), "xavier")
+                    self._simple(ff + "dense/bias", (dff,), "zeros")
+                    self._simple(ff + "dense_1/kernel", (dff, d), "xavier")
+                    self._simple(ff + "dense_1/bias", (d,), "zeros")
+                    self._simple(ff + "ln/beta", (d,), "zeros")
+                    self._simple(ff + "ln/gamma", (d,), "ones")
             if sp.get("is_trans_input_by_mlp"):
                 # tf.layers.dense(seq_emb / tar_sku_emb, d_model, name='dense_trans_seq_' / 'dense_trans_sku_' + stag) (mmoe_transformer_unbias.py:196-198)
                 for nm in ("seq", "sku"):
@@ -139,16 +152,6 @@ class VariableStore:
                 tp = "embedding_trans/trans_sequence_%d/dense_trans_concat_sequence_%d/" % (i, i)
                 self._simple(tp + "kernel", (2 * d, d), "xavier")
                 self._simple(tp + "bias", (d,), "zeros")
-            ffs = [blk + "positionwise_feedforward/"]
-            if not sp.get("tie_ffn", True):
-                ffs.append(blk + "positionwise_feedforward_dec/")
-            for ff in ffs:
-                self._simple(ff + "dense/kernel", (d, dff), "xavier")
-                self._simple(ff + "dense/bias", (dff,), "zeros")
-                self._simple(ff + "dense_1/kernel", (dff, d), "xavier")
-                self._simple(ff + "dense_1/bias", (d,), "zeros")
-                self._simple(ff + "ln/beta", (d,), "zeros")
-                self._simple(ff + "ln/gamma", (d,), "ones")
         # MMoE: layer-0 of all experts and the gates share the input -> one fused [K, E*u0 + T*E] matrix
         K = mmoe_input_width(sp)
         E, T = sp["num_experts"], sp["num_tasks"]

@@ -137,19 +137,25 @@ def param_shapes(spec) -> Dict[str, tuple]:
         p = trans_prefix(i)
         if spec.get("position_encoding_method", "position_learn") == "position_learn":
             shp[p + "positional_encoding_k_position_learn/embedding_position_learn"] = (spec["maxlen_k"], d)
-        for att in ("self-attention", "vanilla_attention"):
-            for dn in ("dense", "dense_1", "dense_2"):
-                shp[p + "num_blocks_0/%s/%s/kernel" % (att, dn)] = (d, d)
-                shp[p + "num_blocks_0/%s/%s/bias" % (att, dn)] = (d,)
-            shp[p + "num_blocks_0/%s/ln/beta" % att] = (d,)
-            shp[p + "num_blocks_0/%s/ln/gamma" % att] = (d,)
-        ff = p + "num_blocks_0/positionwise_feedforward/"
-        shp[ff + "dense/kernel"] = (d, dff)
-        shp[ff + "dense/bias"] = (dff,)
-        shp[ff + "dense_1/kernel"] = (dff, d)
-        shp[ff + "dense_1/bias"] = (d,)
-        shp[ff + "ln/beta"] = (d,)
-        shp[ff + "ln/gamma"] = (d,)
+        # encoder block j (self-attention + ff) and decoder block j (vanilla_attention + ff) open the same scope 'num_blocks_j' under
+        # AUTO_REUSE (TransformerModel.py:104-121, 154-169): one feed-forward per j (tie_ffn); dmt.conf has one block of each
+        ne, nd = int(spec.get("num_blocks_encode", 1)), int(spec.get("num_blocks_decode", 1))
+        for j in range(max(ne, nd)):
+            blk = p + "num_blocks_%d/" % j
+            for att in (("self-attention",) if j < ne else ()) + (("vanilla_attention",) if j < nd else ()):
+                for dn in ("dense", "dense_1", "dense_2"):
+                    shp[blk + "%s/%s/kernel" % (att, dn)] = (d, d)
+                    shp[blk + "%s/%s/bias" % (att, dn)] = (d,)
+                shp[blk + "%s/ln/beta" % att] = (d,)
+                shp[blk + "%s/ln/gamma" % att] = (d,)
+            if j < ne or spec.get("tie_ffn", True):
+                ffj = blk + "positionwise_feedforward/"
+                shp[ffj + "dense/kernel"] = (d, dff)
+                shp[ffj + "dense/bias"] = (dff,)
+                shp[ffj + "dense_1/kernel"] = (dff, d)
+                shp[ffj + "dense_1/bias"] = (d,)
+                shp[ffj + "ln/beta"] = (d,)
+                shp[ffj + "ln/gamma"] = (d,)
         if spec.get("is_trans_input_by_mlp"):
             # tf.layers.dense(seq_emb / tar_sku_emb, d_model, name='dense_trans_seq_' / 'dense_trans_sku_' + stag) inside 'trans_' + stag: :196-198
             for nm in ("seq", "sku"):
@@ -162,9 +168,11 @@ def param_shapes(spec) -> Dict[str, tuple]:
             shp[tp + "kernel"] = (2 * d, d)
             shp[tp + "bias"] = (d,)
         if not spec.get("tie_ffn", True):  # untied variant keeps a second copy for the decoder
-            ffd = p + "num_blocks_0/positionwise_feedforward_dec/"
-            for k in ("dense/kernel", "dense/bias", "dense_1/kernel", "dense_1/bias", "ln/beta", "ln/gamma"):
-                shp[ffd + k] = shp[ff + k]
+            for j in range(nd):
+                ffd = p + "num_blocks_%d/positionwise_feedforward_dec/" % j
+                for k, shape in (("dense/kernel", (d, dff)), ("dense/bias", (dff,)), ("dense_1/kernel", (dff, d)), ("dense_1/bias", (d,)),
+                                 ("ln/beta", (d,)), ("ln/gamma", (d,))):
+                    shp[ffd + k] = shape
     k_in = mmoe_input_width(spec)
     for e in range(spec["num_experts"]):
         prev = k_in

@@ -223,21 +223,25 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
             pos_tab = torch.where((torch.arange(d) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang)).float().to(seq_emb.dtype)
         x = seq_emb * (d ** 0.5) + pos_tab[:T][None]
         x = st.R(_drop(x, rate, step_seed, 10 * i + 0))
-        blk = pre + "num_blocks_0/"
-        x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)
-        mem = _ff(x, P, blk + "positionwise_feedforward/", st)
+        for j in range(int(spec.get("num_blocks_encode", 1))):          # TransformerModel.py:104-121
+            blk = pre + "num_blocks_%d/" % j
+            x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)
+            x = _ff(x, P, blk + "positionwise_feedforward/", st)
+        mem = x
         y = tar * (d ** 0.5)
         if spec.get("is_decoder_add_pos_emb"):      # one-step query: sinusoid row 0 = (0, 1, 0, 1, ...)
             y = y + (torch.arange(d) % 2).to(y.dtype)
         y = st.R(y)[:, None, :]
         if rate and step_seed is not None:
             y = st.R(_drop(y, rate, step_seed, 10 * i + 1))
-        if st.on:
-            y = _mha_q1mem(y, mem, lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3, st)
-        else:
-            y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
-        y = _ff(y, P, blk + ffs, st)
+        for j in range(int(spec.get("num_blocks_decode", 1))):          # TransformerModel.py:154-169
+            blk = pre + "num_blocks_%d/" % j
+            if st.on:
+                y = _mha_q1mem(y, mem, lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3, st)
+            else:
+                y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
+            y = _ff(y, P, blk + ffs, st)
         fin = y[:, 0, :]
         if spec.get("is_trans_out_concat_item"):
             fin = torch.cat([fin, tar], -1)

@@ -147,6 +147,39 @@ def test_e64_bf16_forward_loss_and_every_gradient_match_oracle(cuda, monkeypatch
     _check_grads(tr, G, dtype, "E64 bf16 B=%d" % B)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_e64_bf16_two_encoder_and_two_decoder_blocks_match_oracle(cuda, monkeypatch, packed):
+    """num_blocks_encode = num_blocks_decode = 2 (TransformerModel.py:104-121, 154-169; dmt.conf has 1 + 1) through the E64 kernels: two
+    fused self-attention blocks and fused feed-forwards back to back per sequence (the second on the first's output, packed rows or dense),
+    two raw-memory decoder blocks; forward, loss and every gradient against the oracle, every fused route taken twice as often."""
+    monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 256)
+    dtype = torch.bfloat16
+    so, sp = e64_specs()
+    so = sp = dict(sp, num_blocks_encode=2, num_blocks_decode=2)
+    P = _params(so)
+    inputs, mask, label = make_batch(sp, 24, seed=6, lengths="ragged", weights="random")
+    tr = Trainer(sp, device=cuda, compute_dtype=dtype, init=False, dropout=False, packed_rows=packed)
+    tr.store.load_state(P)
+    loss_ref, (c_ref, o_ref, yb_ref), G = OT.loss_and_grads(P, inputs, mask, so)
+    with L.route_trace() as rt:
+        loss = tr.forward_backward(tr.make_batch(inputs, mask, label))
+        torch.cuda.synchronize()
+    key = "dmt_mhsa_block_fwd(packed)" if packed else "dmt_mhsa_block_fwd"
+    assert rt.counts.get(key, 0) == 6 and rt.counts.get("dmt_q1mem_fwd", 0) == 6 and rt.counts.get("dmt_chain2", 0) == 24, sorted(rt.counts.items())
+    (c, o), yb = tr.last["out"]
+    t = TOL[dtype]
+    errs = [np.abs(x.detach().float().cpu().numpy() - r).max() for x, r in ((c, c_ref), (o, o_ref), (yb, yb_ref))]
+    print("E64 bf16 2+2 blocks (packed %s): max |dlogit|" % packed, errs)
+    assert max(errs) < 1.5 * t["logit"] and abs(float(loss) - loss_ref) / abs(loss_ref) < t["loss"]      # (two blocks deep: 1.5x the one-block bound)
+    got = dict(tr.store.grad_dict())
+    got.update(sparse_to_dense_tables(tr.store, tr.engine.sparse))
+    assert set(got) == set(G)
+    gscale = max(np.abs(G[n]).max() for n in got)
+    worst = sorted(((float(np.linalg.norm(g - G[n]) / max(np.linalg.norm(G[n]), t["floor"] * gscale * np.sqrt(g.size))), n) for n, g in got.items()), reverse=True)
+    print("worst gradient distances:", worst[:3])
+    assert worst[0][0] < 0.3, worst[:5]
+
+
 def test_e64_fp32_mode_matches_oracle(cuda):
     """The same dims in fp32 mode (generic GEMM, scalar attention kernels at d_h = 80): tight tolerances."""
     dtype = torch.float32

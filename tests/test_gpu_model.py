@@ -197,7 +197,8 @@ def test_edge_cases_single_example_and_all_ids_colliding(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype,dec_pos", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, "concat"), (torch.float32, "concat_mlp"),
-                                           (torch.float32, "in_mlp"), (torch.bfloat16, "in_mlp")])
+                                           (torch.float32, "in_mlp"), (torch.bfloat16, "in_mlp"),
+                                           (torch.float32, "blocks_2_1"), (torch.bfloat16, "blocks_2_1"), (torch.float32, "blocks_1_3")])
 def test_transformer_options_match_oracle(cuda, dtype, dec_pos):
     """position_encoding_method = position_sin_cos (TransformerModel.py:62-64, TransformerModel_util.py:238-279) at engine level: no position
     variable exists, the constant sinusoid is added in the gather (and, is_decoder_add_pos_emb, its row 0 to the decoder's one-step query);
@@ -213,6 +214,10 @@ def test_transformer_options_match_oracle(cuda, dtype, dec_pos):
         so, sp = small_specs()
         opt = dict(is_trans_input_by_mlp=True, is_trans_out_concat_item=True)
         so, sp = dict(so, **opt), dict(sp, **opt)
+    if isinstance(dec_pos, str) and dec_pos.startswith("blocks"):     # num_blocks_encode / num_blocks_decode (TransformerModel.py:104-121, 154-169)
+        so, sp = small_specs()
+        ne, nd = int(dec_pos.split("_")[1]), int(dec_pos.split("_")[2])
+        so, sp = dict(so, num_blocks_encode=ne, num_blocks_decode=nd), dict(sp, num_blocks_encode=ne, num_blocks_decode=nd)
     if dec_pos == "concat_mlp":                 # + is_trans_out_by_mlp (:216-217): a dense layer folds the pair back to d_model
         so, sp = dict(so, is_trans_out_by_mlp=True), dict(sp, is_trans_out_by_mlp=True)
     P = O.init_params(so, seed=13)

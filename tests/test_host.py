@@ -112,7 +112,10 @@ def test_conf_transformer_options_the_engine_takes_and_refuses():
     assert not any("position_learn" in k for k in st.state_dict())
     conf.is_trans_input_by_mlp = True
     assert conf.to_spec()["is_trans_input_by_mlp"] is True
-    for attr, val in (("position_encoding_method", "time_add"), ("num_blocks_encode", 2), ("num_blocks_decode", 2)):
+    conf.num_blocks_encode, conf.num_blocks_decode = 2, 3
+    sp3 = conf.to_spec()
+    assert (sp3["num_blocks_encode"], sp3["num_blocks_decode"]) == (2, 3)
+    for attr, val in (("position_encoding_method", "time_add"), ("position_encoding_method", "time_concat"), ("num_blocks_encode", 0)):
         c2 = Conf(os.path.join(ROOT, "cikm2020_dmt_amd/conf/settings/"), "dmt.conf")
         setattr(c2, attr, val)
         with pytest.raises(NotImplementedError):
