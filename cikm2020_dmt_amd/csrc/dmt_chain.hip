@@ -366,21 +366,31 @@ __global__ __launch_bounds__(CH_NT, 2) void chain2_kernel(const ChainArgs g) {
         if constexpr (TRACE) tr_mark(2);                                                  // 2: fragment reads + MFMA issue
         // ---- mid op on the accumulator: lane (m, hi) holds j = 32 u + 8 q + 4 hi + i in register 4 q + i
         f32x16_t H = Ha;
+        unsigned hb[8], ho[8];
         if constexpr (MODE == DMT_CHAIN_FFN_LN) {
-          bits = 0;
+          // relu and its mask on the PACKED pairs: bf16 keeps the sign bit, so max(int16, 0) is the relu of either half, and a half that is
+          // not zero afterwards was positive (a positive fp32 below bf16's smallest denormal rounds to +0: its relu output is 0 either way).
+          // 8 conversions + 8 packed max + 2 per pair for the bits, where the fp32 form took a compare, two selects and an or per element.
+          typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+          typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+          unsigned acc = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool pos = H[r] > 0.f;
-            bits |= pos ? (1u << r) : 0u;
-            H[r] = pos ? H[r] : 0.f;
+          for (int p = 0; p < 8; ++p) {
+            const s16x2_t v = __builtin_bit_cast(s16x2_t, dmt_pack_bf16(H[2 * p], H[2 * p + 1]));
+            const s16x2_t zero = {0, 0};
+            const s16x2_t rl = __builtin_elementwise_max(v, zero);
+            hb[p] = __builtin_bit_cast(unsigned, rl);
+            const u16x2_t one = {1, 1};
+            const unsigned nz = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, rl), one));   // bit 0 / bit 16
+            acc |= nz << (2 * p);
           }
+          bits = (acc & 0xFFFFu) | (acc >> 15);        // element 2p -> bit 2p, element 2p + 1 -> bit 2p + 1
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) H[r] = ((bits >> r) & 1u) ? H[r] : 0.f;
-        }
-        unsigned hb[8], ho[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) hb[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
+          for (int p = 0; p < 8; ++p) hb[p] = dmt_pack_bf16(H[2 * p], H[2 * p + 1]);
+        }
         if constexpr (TRACE) { ch_keepu(hb[0]); ch_keepu(hb[7]); tr_mark(3); }   // 3: MFMA drain + mid op + pack
         // hand the tile to the consumer: two B fragments, slot u & 1
         ch_write128(hand_lane + (u & 1) * 2048, u32x4_t{hb[0], hb[1], hb[2], hb[3]});
