@@ -309,11 +309,14 @@ class TFSlotOptimizer:
         self.store.refresh_shadows()
 
     def flush_tables(self):
-        """Every row's slots brought to the last completed step (FTRL: never-updated rows zeroed), before a checkpoint / export."""
+        """Every row's slots brought to the last completed step (FTRL: var recomputed from the slots, never-updated rows zeroed), before a
+        checkpoint / export.  Nothing to do before the first step since the slots were (re)initialised: TF's variables only change in
+        apply_gradients (and an FTRL sweep over fresh slots would zero every table)."""
+        if self._last_lr is None:
+            return
         s = self.store
         L.call("dmt_opt_flush_rows", self.code, C.byref(self.tm), ops.p(s.tab_p), ops.p(s.tab_m), ops.p(s.tab_v), ops.p(s.last_step),
-               self.global_step - self._step_base, float(self._last_lr if self._last_lr is not None else self.current_lr()), *self.hp,
-               ops.stream_ptr())
+               self.global_step - self._step_base, float(self._last_lr), *self.hp, ops.stream_ptr())
 
     def reset_slots(self, global_step: int = 0):
         """As TFAdam.reset_slots: the reference's Saver keeps no slots (run_dnn.py:258-261); global_step keeps driving the schedule."""

@@ -174,6 +174,21 @@ def test_train_steps_with_each_optimizer_match_oracle_fp32(cuda, kind):
         assert zero_ref.any() and (np.abs(got[name][zero_ref]).max() == 0)
 
 
+def test_flush_before_the_first_step_changes_nothing(cuda):
+    """A checkpoint written before any step flushes the lazy rows first: with fresh slots that must be a no-op for every kind (an FTRL
+    sweep over linear == 0 would zero the tables)."""
+    _so, sp = small_specs()
+    for kind in KINDS:
+        st = VariableStore(sp, cuda, torch.float32, seed=4)
+        before = st.tab_p.clone()
+        opt = make_optimizer(kind, st)
+        opt.flush_tables()
+        opt.reset_slots(1000)
+        opt.flush_tables()
+        torch.cuda.synchronize()
+        assert torch.equal(st.tab_p, before), kind
+
+
 def test_get_optimizer_returns_every_reference_branch(cuda):
     _so, sp = small_specs()
     inf = Inference(None, device=cuda, compute_dtype=torch.float32, seed=4, spec=sp)
