@@ -554,6 +554,8 @@ class DMTEngine:
 
     # ---- stages
     def gather(self, batch: DeviceBatch):
+        if self.spec.get("is_trans_input_by_mlp") and self.store.shard is not None:
+            raise NotImplementedError("is_trans_input_by_mlp with row-sharded tables (the raw-row gather has no fetched-row form)")
         pos = self.position_tables()
         packs = [self.seq_pack(batch, s) for s in range(len(pos))]
         self._last_packs = packs
