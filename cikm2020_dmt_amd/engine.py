@@ -657,7 +657,7 @@ class DMTEngine:
             f.seq_id, f.seq_off = (it["seq_id"], it["seq_off"]) if is_target else (-1, 0)
             f.inv_wsum = inv[i].data_ptr()
         desc.n_seq = 0
-        desc.tar_out, desc.d_model, desc.seq_scale = tar.data_ptr(), d, float(d) ** 0.5
+        desc.tar_out, desc.d_model, desc.seq_scale = tar.data_ptr(), d, (1.0 if spec.get("is_trans_input_by_mlp") else float(d) ** 0.5)
         desc.pooled, desc.ld_pooled = zbuf.data_ptr(), plan.ldz
         desc.dense, desc.n_dense = batch.dense.data_ptr(), spec["feature_dimension"]
         desc.out_dtype = ops.dt_code(cdt)
@@ -768,6 +768,19 @@ class DMTEngine:
             out.append(ops.linear(torch.cat([u, raw], -1), self._lf(tp + "kernel"), self._lf(tp + "bias"), self._w(tp + "kernel")))
         return out
 
+    def input_mlp(self, i, x_raw, tar_raw):
+        """is_trans_input_by_mlp (mmoe_transformer_unbias.py:196-198): the RAW rows of sequence i and the raw target rows through
+        'dense_trans_seq_<stag>' / 'dense_trans_sku_<stag>', then the prep the gather skipped for this variant (TransformerModel.py:96-101:
+        * sqrt(d_model), + positions, dropout of the block input; the decoder's query is scaled the same way) -> (x, scaled target)."""
+        scale = float(self.spec["d_model"]) ** 0.5
+        tp = "embedding_trans/trans_sequence_%d/" % i
+        ks, kt = tp + "dense_trans_seq_sequence_%d/" % i, tp + "dense_trans_sku_sequence_%d/" % i
+        x = ops.linear(x_raw, self._lf(ks + "kernel"), self._lf(ks + "bias"), self._w(ks + "kernel"))
+        x = ops.ScaleAddPosFn.apply(x, self.position_tables()[i], scale)
+        x = ops.dropout(x, self.spec.get("dropout_rate", 0.0), self.dropout_step_seed, 10 * i + 0)
+        tar = ops.linear(tar_raw, self._lf(kt + "kernel"), self._lf(kt + "bias"), self._w(kt + "kernel")) * scale
+        return x, tar
+
     def decoder_query(self, tar):
         """The decoder's one-step query from the scaled target rows: + row 0 of the sinusoid (sin(0) on the even columns, cos(0) on the
         odd ones) when is_decoder_add_pos_emb (TransformerModel.py:148-149: dec += positional_encoding(dec, maxlen_q); dmt.conf: false)."""
@@ -791,18 +804,8 @@ class DMTEngine:
         us, order = [None] * n_seq, list(range(n_seq))
         tars = list(FanOutFn.apply(tar, n_seq) if (tar.requires_grad and n_seq > 1) else (tar,) * n_seq)
         if self.spec.get("is_trans_input_by_mlp"):
-            # mmoe_transformer_unbias.py:196-198: seq_emb / tar_sku_emb through 'dense_trans_seq_<stag>' / 'dense_trans_sku_<stag>', then the
-            # prep the gather skipped (TransformerModel.py:96-101: * sqrt(d_model), + positions, dropout); the decoder scales its own copy
-            scale = float(self.spec["d_model"]) ** 0.5
-            rate = self.spec.get("dropout_rate", 0.0)
-            pos_tabs = self.position_tables()
             for i in range(n_seq):
-                tp = "embedding_trans/trans_sequence_%d/" % i
-                ks, kt = tp + "dense_trans_seq_sequence_%d/" % i, tp + "dense_trans_sku_sequence_%d/" % i
-                xi = ops.linear(X[i], self._lf(ks + "kernel"), self._lf(ks + "bias"), self._w(ks + "kernel"))
-                xi = ops.ScaleAddPosFn.apply(xi, pos_tabs[i], scale)
-                X[i] = ops.dropout(xi, rate, self.dropout_step_seed, 10 * i + 0)
-                tars[i] = ops.linear(tars[i], self._lf(kt + "kernel"), self._lf(kt + "bias"), self._w(kt + "kernel")) * scale
+                X[i], tars[i] = self.input_mlp(i, X[i], tars[i])
             tars_scaled = list(tars)
         tars = [self.decoder_query(t) for t in tars]
         if main is not None:

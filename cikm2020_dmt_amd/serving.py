@@ -41,9 +41,6 @@ class CandidateScorer:
         """optimizer: the TFAdam of a LIVE trainer sharing this engine's tables, or None for a frozen / restored model.  The exact lazy
         Adam leaves zero-gradient updates of untouched rows pending; scoring reads rows without replaying them, so with
         a live optimizer the tables are flushed before every request that follows a train step."""
-        if engine.spec.get("is_trans_input_by_mlp"):
-            raise NotImplementedError("CandidateScorer: is_trans_input_by_mlp (the encode-once request path gathers prepared rows); score such a "
-                                      "model through DMTEngine.inference(batch, is_predict=True) on the tiled request")
         self.engine = engine
         self.optimizer = optimizer
         self._flushed_at = -1
@@ -102,15 +99,17 @@ class CandidateScorer:
         try:
             b1 = self._row0(batch)
             X1, _tar1, _z1 = eng.gather(b1)
-            tar_scaled, zbuf = eng.gather_pooled(batch)
-            tar = eng.decoder_query(tar_scaled)
-            us = []
+            tar_g, zbuf = eng.gather_pooled(batch)
+            in_mlp = bool(spec.get("is_trans_input_by_mlp"))      # (then both gathers hand out raw rows and every sequence has its own target)
+            us, tars_scaled = [], []
             for i, pairs in enumerate(spec["attention_embed_pairs"]):
                 lens1 = b1.feats[pairs[-1][0]].lens
-                mem1 = eng.encode_prepared(X1[i], lens1, i)                    # [1, T, d], once per request
+                x1, tar_i = eng.input_mlp(i, X1[i], tar_g) if in_mlp else (X1[i], tar_g)
+                tars_scaled.append(tar_i)
+                mem1 = eng.encode_prepared(x1, lens1, i)                       # [1, T, d], once per request
                 k_lens = lens1.expand(batch.B).contiguous()
-                us.append(eng.decode_shared(tar.unsqueeze(1), mem1, k_lens, i).squeeze(1))
-            z = AssembleFn.apply(zbuf, eng.plan.interest_off, spec["d_model"], *eng.interest_blocks(us, tar_scaled))
+                us.append(eng.decode_shared(eng.decoder_query(tar_i).unsqueeze(1), mem1, k_lens, i).squeeze(1))
+            z = AssembleFn.apply(zbuf, eng.plan.interest_off, spec["d_model"], *eng.interest_blocks(us, tars_scaled))
             tasks = eng.expert_gate(z, z_is_engine_buffer=True)          # (z is gather_pooled's zero-initialised zbuf)
             return tuple(eng.build_tower(m, nm) for m, nm in zip(tasks, ("click", "order")))
         finally:

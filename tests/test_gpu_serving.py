@@ -33,11 +33,14 @@ def _tile_user_side(sp, inputs):
     return out
 
 
-@pytest.mark.parametrize("dtype,tol,variant", [(torch.float32, 2e-5, None), (torch.bfloat16, 4e-2, None), (torch.float32, 2e-5, "sin_cos")])
+@pytest.mark.parametrize("dtype,tol,variant", [(torch.float32, 2e-5, None), (torch.bfloat16, 4e-2, None), (torch.float32, 2e-5, "sin_cos"), (torch.float32, 2e-5, "in_mlp")])
 def test_encode_once_equals_tiled_predict_graph_and_oracle(cuda, dtype, tol, variant):
     so, sp = small_specs()
     if variant == "sin_cos":      # position_sin_cos + is_decoder_add_pos_emb + is_trans_out_concat_item: the request path adds the same constants as the train graph
         opt = dict(position_encoding_method="position_sin_cos", is_decoder_add_pos_emb=True, is_trans_out_concat_item=True)
+        so, sp = dict(so, **opt), dict(sp, **opt)
+    if variant == "in_mlp":       # is_trans_input_by_mlp + two encoder blocks: the request path runs the same input layers and prep, once per request
+        opt = dict(is_trans_input_by_mlp=True, num_blocks_encode=2, num_blocks_decode=2, is_trans_out_concat_item=True)
         so, sp = dict(so, **opt), dict(sp, **opt)
     P = O.init_params(so, seed=21)
     inputs, mask, label = make_batch(sp, 37, seed=8, lengths="ragged", weights="random")
