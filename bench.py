@@ -76,10 +76,23 @@ def main():
                          "each around chain2, 0.2 ms per step if every step is timed)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the line the driver uses) and
+    # hand this process over to the launcher.  A --gpus N request never runs -- or prints -- as fewer than N ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        port = os.environ.get("MASTER_PORT")
+        if not port:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = str(s.getsockname()[1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); the HIP path has no CPU fallback")

@@ -1366,6 +1366,19 @@ extern "C" int dmt_gemm(const dmt_gemm_desc* d, void* stream) {
 extern "C" int dmt_gemm_dw_batched(const dmt_gemm_desc* descs, int32_t n, void* stream) {
   DMT_CHECK_ARG(descs != nullptr && n > 0, "dmt_gemm_dw_batched: no jobs");
   hipStream_t st = (hipStream_t)stream;
+  // pass 1: every descriptor is checked before the first launch (all or nothing also when n spans several launches)
+  for (int j = 0; j < n; ++j) {
+    GemmArgs probe;
+    int route = GR_GENERIC;
+    long long nblk = 0;
+    const int prc = gemm_prepare(&descs[j], probe, route, nblk);
+    if (prc != DMT_OK) return prc;
+    const long long kps = (long long)descs[j].K / (probe.split_k > 1 ? probe.split_k : 1);
+    if (route != GR_DW_GLDS || kps > 4096) {
+      dmt_set_error("dmt_gemm_dw_batched: job %d (M %d, N %d, K %d) is not of the B-row weight-gradient class", j, descs[j].M, descs[j].N, descs[j].K);
+      return DMT_ERR_UNSUPPORTED;
+    }
+  }
   for (int j0 = 0; j0 < n; j0 += DW_MAX_JOBS) {
     DwJobs p;
     p.n = (n - j0) < DW_MAX_JOBS ? (n - j0) : DW_MAX_JOBS;
@@ -1375,11 +1388,6 @@ extern "C" int dmt_gemm_dw_batched(const dmt_gemm_desc* descs, int32_t n, void* 
       long long nblk = 0;
       const int prc = gemm_prepare(&descs[j0 + j], p.job[j], route, nblk);
       if (prc != DMT_OK) return prc;
-      const long long kps = (long long)descs[j0 + j].K / (p.job[j].split_k > 1 ? p.job[j].split_k : 1);
-      if (route != GR_DW_GLDS || kps > 4096) {
-        dmt_set_error("dmt_gemm_dw_batched: job %d (M %d, N %d, K %d) is not of the B-row weight-gradient class", j0 + j, descs[j0 + j].M, descs[j0 + j].N, descs[j0 + j].K);
-        return DMT_ERR_UNSUPPORTED;
-      }
       const int nb = (int)(nblk < GL_GRID ? nblk : GL_GRID);
       p.start[j] = at;
       at += nb;
@@ -1391,4 +1399,3 @@ extern "C" int dmt_gemm_dw_batched(const dmt_gemm_desc* descs, int32_t n, void* 
   }
   return DMT_OK;
 }
-

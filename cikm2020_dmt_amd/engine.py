@@ -560,6 +560,7 @@ class DMTEngine:
         packs = [self.seq_pack(batch, s) for s in range(len(pos))]
         self._last_packs = packs
         self._l2_coef = None         # (a new forward pass: an l2 row term nobody asked the rows for belongs to the previous one)
+        self._sparse = None          # ... and so do the previous backward's rows: the `sparse` getter must never add this pass's l2 term to them
         if not any(pl.requires_grad for pl in pos):
             # position_sin_cos: no input of the node requires a gradient, and autograd would not run its backward (the embedding gradient):
             # one more input, any leaf, ties it into the graph (its gradient is None)
@@ -716,7 +717,7 @@ class DMTEngine:
         # TransformerModel.py:101 dropout(enc): already applied by the gather (GatherFn), stream id 10 * i + 0
         for j in range(int(self.spec.get("num_blocks_encode", 1))):          # TransformerModel.py:104-121 (dmt.conf: one block)
             blk = trans_prefix(i) + "num_blocks_%d/" % j
-            x = self.mha_self(x, lens, blk, 10 * i + 2, pack=pack)
+            x = self.mha_self(x, lens, blk, 10 * i + 2 + 1000 * j, pack=pack)        # (an independent attention-dropout mask per block)
             x = self.ff(x, blk + "positionwise_feedforward/")
         return x
 
@@ -726,7 +727,7 @@ class DMTEngine:
         ffs = "positionwise_feedforward/" if self.spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         for j in range(int(self.spec.get("num_blocks_decode", 1))):          # TransformerModel.py:154-169 (dmt.conf: one block)
             blk = trans_prefix(i) + "num_blocks_%d/" % j
-            y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3, pack=pack)
+            y = self.mha_cross(y, mem, None, lens, blk, 10 * i + 3 + 1000 * j, pack=pack)
             y = self.ff(y, blk + ffs)
         return y
 

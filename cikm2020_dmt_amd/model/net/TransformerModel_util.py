@@ -37,6 +37,13 @@ def _seq_index() -> int:
     return int(m.group(1)) if m else 0
 
 
+def _block_index() -> int:
+    """j of the enclosing `num_blocks_j` scope (TransformerModel.py:104,154): every block draws its own attention-dropout mask."""
+    import re
+    m = re.search(r"num_blocks_(\d+)", R.current_scope())
+    return int(m.group(1)) if m else 0
+
+
 def _attn_dropout(rate, training, offset):
     """(site seed, keep probability) of the attention-weight dropout, or (0, 1.0) when it is off."""
     eng = R.get_default().engine
@@ -44,7 +51,7 @@ def _attn_dropout(rate, training, offset):
         return 0, 1.0
     if eng.dropout_step_seed is None:
         raise RuntimeError("training=True with dropout_rate > 0 needs engine.dropout_step_seed (Inference.inference(is_train=True) sets it)")
-    return ops.site_seed(eng.dropout_step_seed, 10 * _seq_index() + offset), 1.0 - float(rate)
+    return ops.site_seed(eng.dropout_step_seed, 10 * _seq_index() + offset + 1000 * _block_index()), 1.0 - float(rate)
 
 
 def ln(inputs, epsilon=1e-8, scope="ln"):

@@ -319,7 +319,15 @@ class TFSlotOptimizer:
                self.global_step - self._step_base, float(self._last_lr), *self.hp, ops.stream_ptr())
 
     def reset_slots(self, global_step: int = 0):
-        """As TFAdam.reset_slots: the reference's Saver keeps no slots (run_dnn.py:258-261); global_step keeps driving the schedule."""
+        """As TFAdam.reset_slots: the reference's Saver keeps no slots (run_dnn.py:258-261); global_step keeps driving the schedule.
+        FTRL after a restore (global_step > 0): the first step's sweep recomputes EVERY variable from (accum 0.1, linear 0) -- TF 1.12's
+        dense ApplyFtrl does the same after a slot-less restore -- so every restored embedding row that step does not touch becomes 0.
+        That is the reference's behaviour, and it throws the restored model away: said aloud here."""
+        if self.kind == "ftrl" and int(global_step) > 0:
+            import warnings
+            warnings.warn("ftrl: slots reset at global_step %d (the reference's checkpoints hold no slots); the next step's dense sweep "
+                          "recomputes every variable from fresh (accum, linear) slots, which ZEROES all restored embedding rows the step does "
+                          "not touch -- TF 1.12 semantics, not a way to continue training a restored model" % int(global_step))
         self._init_slots()
         self._last_lr = None
         self.global_step = int(global_step)

@@ -39,9 +39,11 @@ def index_group():
     collectives of different communicators are launched in the same order on every rank or can co-reside on the device.  Here each
     rank issues, per step, the index plane of batch i + 1 (this communicator) and the gradient collectives of step i (the default one)
     from different host points, so the device-side order can differ between ranks; both kinds of kernels are small (a few workgroups) and
-    co-reside on a 256-CU device, which is what makes this work -- it has not been soak-tested on 8 GPUs.  DMT_INDEX_GROUP=0 puts
-    everything on the default communicator (one stream, one order: the id exchange then queues behind the gradient collectives)."""
-    mode = os.environ.get("DMT_INDEX_GROUP", "1")
+    co-reside on a 256-CU device, which is what makes this work -- it has not been soak-tested on 8 GPUs.
+    DEFAULT SINCE ROUND 6: DMT_INDEX_GROUP=0 -- everything on the default communicator (one stream, one order on every rank: the id
+    exchange queues behind the gradient collectives of the step before; progress then rests on nothing but NCCL's own in-order rule).
+    DMT_INDEX_GROUP=1 opts into the second communicator once an 8-rank soak on hardware has shown it safe."""
+    mode = os.environ.get("DMT_INDEX_GROUP", "0")
     if not (dist.is_available() and dist.is_initialized()) or mode not in ("1", "force") or (dist.get_backend() != "nccl" and mode != "force"):
         return None          # (DMT_INDEX_GROUP=0: everything on the default communicator -- the id exchange then queues behind gradient collectives)
     # ("force": a second group on ANY backend -- the soak test of tests/test_gpu_dp.py runs the two-communicator schedule over gloo)
@@ -242,6 +244,17 @@ def _parse_cpulist(text: str):
     return out
 
 
+def device_bdf(props) -> str:
+    """sysfs name ('dddd:bb:dd.f') of a device from torch's properties: `pci_bus_id` is the BUS NUMBER (an int) in torch 2.10+rocm, a BDF
+    string in some other builds."""
+    bus = getattr(props, "pci_bus_id", None)
+    if isinstance(bus, str):
+        return bus.lower()
+    if bus is None:
+        return ""
+    return "%04x:%02x:%02x.0" % (int(getattr(props, "pci_domain_id", 0)), int(bus), int(getattr(props, "pci_device_id", 0)))
+
+
 def pin_rank_to_cores(local_rank: int, local_world: int, device_index: int = None):
     """CPU plan of one rank of a one-process-per-GPU job: this process -- its Python launcher thread, the autograd thread and the native
     input stage's parser pool (threads inherit the mask) -- is confined to an equal share of the host's cores, taken from the NUMA node
@@ -253,18 +266,20 @@ def pin_rank_to_cores(local_rank: int, local_world: int, device_index: int = Non
         return {}
     allowed = sorted(os.sched_getaffinity(0))
     node, node_cores = None, None
-    try:
-        if device_index is not None and torch.cuda.is_available():
-            bdf = torch.cuda.get_device_properties(device_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else None
-            if bdf:
-                path = "/sys/bus/pci/devices/%s/numa_node" % bdf.lower()
-                if os.path.exists(path):
-                    n = int(open(path).read().strip())
-                    if n >= 0:
-                        cl = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read())
-                        node, node_cores = n, [c for c in cl if c in set(allowed)]
-    except Exception:
-        node, node_cores = None, None
+    if device_index is not None and torch.cuda.is_available():
+        try:
+            bdf = device_bdf(torch.cuda.get_device_properties(device_index))
+            path = "/sys/bus/pci/devices/%s/numa_node" % bdf
+            if bdf and os.path.exists(path):
+                n = int(open(path).read().strip())
+                if n >= 0:
+                    cl = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read())
+                    node, node_cores = n, [c for c in cl if c in set(allowed)]
+        except (OSError, ValueError, AttributeError) as e:
+            import warnings
+            warnings.warn("pin_rank_to_cores: NUMA node of device %s not found (%s: %s); the rank keeps a plain slice of the host's cores"
+                          % (device_index, type(e).__name__, e))
+            node, node_cores = None, None
     share = max(1, len(allowed) // local_world)
     if node_cores and len(node_cores) >= share:
         # the ranks whose GPUs share this node split ITS cores: position of this rank among them = its index modulo ranks per node

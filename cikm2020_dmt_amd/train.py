@@ -631,7 +631,9 @@ class Trainer:
         plan_dp = dp and self.dp_exchange == "owner" and self.overlap_wgrads
         loss = self.forward_backward(batch, join=dp, prefetch=prefetch, defer_wgrads=plan_dp, open_step=True)
         self._inflight = None
-        sparse = self.engine.sparse
+        # (with the sparse tail of backward deferred the rows do not exist yet: reading `engine.sparse` here would hand the l2_norm row
+        #  term to a stale buffer that finish_sparse_backward then zeroes)
+        sparse = self.engine.sparse if self.engine._pending_sparse is None else None
         if not dp:
             lane = self._index_stream() if self.engine._pending_sparse is not None else None
             if lane is not None:

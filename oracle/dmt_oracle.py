@@ -235,7 +235,7 @@ def _mix32(h):
 
 def site_seed(step_seed: int, stream: int) -> int:
     """32-bit seed of one dropout site (stream) at one step; streams: 10*i+0 encoder input, 10*i+1 decoder input,
-    10*i+2 self-attention weights, 10*i+3 cross-attention weights of sequence i; 100+l bias-tower layer l."""
+    10*i+2 (+1000*j) self-attention weights, 10*i+3 (+1000*j) cross-attention weights of block j of sequence i; 100+l bias-tower layer l."""
     return int(_mix32((step_seed * 0x9E3779B1 + stream * 0x85EBCA6B + 1) & 0xFFFFFFFF))
 
 
@@ -346,7 +346,7 @@ def encode(seq_emb, seqlens, P, prefix, spec, step_seed=None, seq_index=0):
     for i in range(spec["num_blocks_encode"]):
         blk = prefix + "num_blocks_%d/" % i
         enc = multihead_attention(enc, enc, enc, seqlens, seqlens, spec["num_heads"], P, blk + "self-attention/", rate, step_seed,
-                                  10 * seq_index + 2)
+                                  10 * seq_index + 2 + 1000 * i)      # one independent tf.layers.dropout mask per block
         enc = ff(enc, P, blk + "positionwise_feedforward/")
     return enc
 
@@ -365,7 +365,7 @@ def decode(query_emb, query_length, key_emb, key_length, P, prefix, spec, step_s
     for i in range(spec["num_blocks_decode"]):
         blk = prefix + "num_blocks_%d/" % i
         dec = multihead_attention(dec, key_emb, key_emb, query_length, key_length, spec["num_heads"], P,
-                                  blk + "vanilla_attention/", rate, step_seed, 10 * seq_index + 3)
+                                  blk + "vanilla_attention/", rate, step_seed, 10 * seq_index + 3 + 1000 * i)
         ffs = "positionwise_feedforward/" if spec.get("tie_ffn", True) else "positionwise_feedforward_dec/"
         dec = ff(dec, P, blk + ffs)                                    # same scope => tied weights
     return dec

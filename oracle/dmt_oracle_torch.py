@@ -225,7 +225,7 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         x = st.R(_drop(x, rate, step_seed, 10 * i + 0))
         for j in range(int(spec.get("num_blocks_encode", 1))):          # TransformerModel.py:104-121
             blk = pre + "num_blocks_%d/" % j
-            x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2, st)
+            x = _mha(x, x, lens, lens, H, P, blk + "self-attention/", rate, step_seed, 10 * i + 2 + 1000 * j, st)
             x = _ff(x, P, blk + "positionwise_feedforward/", st)
         mem = x
         y = tar * (d ** 0.5)
@@ -238,9 +238,9 @@ def forward(P: Dict[str, torch.Tensor], inputs, spec, is_predict=False, return_i
         for j in range(int(spec.get("num_blocks_decode", 1))):          # TransformerModel.py:154-169
             blk = pre + "num_blocks_%d/" % j
             if st.on:
-                y = _mha_q1mem(y, mem, lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3, st)
+                y = _mha_q1mem(y, mem, lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3 + 1000 * j, st)
             else:
-                y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3)
+                y = _mha(y, mem, torch.ones(B, dtype=torch.long), lens, H, P, blk + "vanilla_attention/", rate, step_seed, 10 * i + 3 + 1000 * j)
             y = _ff(y, P, blk + ffs, st)
         fin = y[:, 0, :]
         if spec.get("is_trans_out_concat_item"):

@@ -399,6 +399,26 @@ def test_bench_two_ranks_torchrun_on_one_device(cuda):
     assert "row-sharded" in j2["config"]["parallelism"] and np.isfinite(j2["final_loss"])
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2` with no launcher in front (no WORLD_SIZE in the environment): bench.py starts the two ranks itself
+    (run_dnn.py:148-207's towers = ranks here) and the line says n_gpus 2 -- never a one-rank number under a --gpus 2 request."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMT_BENCH_ONE_DEVICE="1", DMT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 512 and np.isfinite(j["final_loss"])
+
+
 def _soak_worker(rank, world, port, q, steps):
     import torch.distributed as dist
     from cikm2020_dmt_amd import parallel

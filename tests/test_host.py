@@ -270,3 +270,24 @@ def test_tf_checkpoint_bundle_container_round_trip_and_format_invariants(tmp_pat
         TB.read_bundle(prefix)
     with pytest.raises(ValueError):
         TB.write_table(str(tmp_path / "t"), [(b"b", b""), (b"a", b"")])
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with two ranks
+    (here, without a GPU, both then refuse to run: the message must come from the ranks, and a one-rank run must never happen), and a
+    launcher whose WORLD_SIZE disagrees with --gpus is refused -- also for --gpus N under WORLD_SIZE=1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE")}
+    if torch.cuda.is_available():
+        env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "local_rank: 0" in out.stderr or "local_rank: 1" in out.stderr, out.stderr[-2000:]        # torchrun's failure report: ranks existed
+    assert out.stderr.count("bench.py needs an MI355X") >= 1
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1 but --gpus 8" in out.stderr
