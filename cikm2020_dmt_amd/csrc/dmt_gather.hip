@@ -3,9 +3,6 @@
 // the sequence rows; no GEMM reshaping.
 #include "dmt_common.h"
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/functional.hpp>
 #include <utility>
 #include <stdlib.h>
 
@@ -335,7 +332,7 @@ __global__ __launch_bounds__(256) void embgrad_keys_kernel(const dmt_embgrad_des
       key = (uint32_t)(s_rb[f] + id - 1);
   }
   keys[e] = key;
-  vals[e] = (uint32_t)e;
+  if (vals != nullptr) vals[e] = (uint32_t)e;        // (null: the sort numbers the entries itself, dmt_sort_pairs(vals_in = nullptr))
 }
 
 // Row-cache slots of every entry (row-sharded tables): sorted entry j (row keys_s[j], entry vals_s[j], distinct-row number seg[j])
@@ -361,24 +358,6 @@ __global__ __launch_bounds__(256) void entry_slots_kernel(const dmt_embgrad_desc
     out = (pos ? pos[u] : u) + kind;
   }
   slots[e] = out;
-}
-
-__global__ __launch_bounds__(256) void head_flags_kernel(const uint32_t* __restrict__ k, long long n, int* __restrict__ flag) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  flag[e] = (e == 0 || k[e] != k[e - 1]) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void finish_heads_kernel(const uint32_t* __restrict__ k, long long n, uint32_t invalid,
-                                                           int* __restrict__ seg, uint32_t* __restrict__ uniq,
-                                                           int* __restrict__ n_uniq) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  const int s = seg[e] - 1;     // inclusive scan of flags is 1-based
-  seg[e] = s;
-  const bool head = (e == 0 || k[e] != k[e - 1]);
-  if (head) uniq[s] = k[e];
-  if (e == n - 1) n_uniq[0] = (k[e] >= invalid) ? s : s + 1;
 }
 
 // One wavefront per chunk of 64 sorted entries.
@@ -782,54 +761,12 @@ extern "C" int dmt_gather_fwd(const dmt_gather_desc* d, void* stream) {
 }
 
 extern "C" int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, void* stream) {
-  DMT_CHECK_ARG(d && keys && vals, "dmt_embgrad_keys: null argument");
+  DMT_CHECK_ARG(d && keys, "dmt_embgrad_keys: null argument");
   DMT_CHECK_ARG(d->n_features > 0 && d->n_features <= DMT_MAX_FEATURES, "dmt_embgrad_keys: bad n_features");
   const long long n = d->entry_base[d->n_features];
   if (n == 0) return DMT_OK;
   hipLaunchKernelGGL(embgrad_keys_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, *d, keys, vals, n);
   DMT_CHECK_LAUNCH("dmt_embgrad_keys");
-  return DMT_OK;
-}
-
-extern "C" int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                              int64_t n, int32_t end_bit, void* ws, uint64_t* ws_bytes, void* stream) {
-  DMT_CHECK_ARG(ws_bytes != nullptr, "dmt_sort_pairs: ws_bytes is null");
-  DMT_CHECK_ARG(end_bit > 0 && end_bit <= 32, "dmt_sort_pairs: bad end_bit");
-  size_t need = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                           (unsigned)end_bit, (hipStream_t)stream);
-  if (e != hipSuccess) { dmt_set_error("dmt_sort_pairs: size query failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
-  if (ws == nullptr) { *ws_bytes = need; return DMT_OK; }
-  DMT_CHECK_ARG(*ws_bytes >= need, "dmt_sort_pairs: workspace too small (%llu < %llu)", (unsigned long long)*ws_bytes,
-                (unsigned long long)need);
-  size_t have = (size_t)*ws_bytes;
-  e = rocprim::radix_sort_pairs(ws, have, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, (unsigned)end_bit,
-                                (hipStream_t)stream);
-  if (e != hipSuccess) { dmt_set_error("dmt_sort_pairs: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
-  return DMT_OK;
-}
-
-extern "C" int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_key, int32_t* seg_id,
-                                 uint32_t* uniq_keys, int32_t* n_uniq, void* ws, uint64_t* ws_bytes, void* stream) {
-  DMT_CHECK_ARG(ws_bytes != nullptr, "dmt_segment_heads: ws_bytes is null");
-  size_t scan_need = 0;
-  hipError_t e = rocprim::inclusive_scan(nullptr, scan_need, (int*)nullptr, (int*)nullptr, (size_t)n, rocprim::plus<int>(),
-                                         (hipStream_t)stream);
-  if (e != hipSuccess) { dmt_set_error("dmt_segment_heads: size query failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
-  const size_t flags_bytes = (((size_t)n * sizeof(int)) + 255) & ~(size_t)255;
-  const size_t need = flags_bytes + scan_need + 256;
-  if (ws == nullptr) { *ws_bytes = need; return DMT_OK; }
-  DMT_CHECK_ARG(*ws_bytes >= need, "dmt_segment_heads: workspace too small");
-  DMT_CHECK_ARG(sorted_keys && seg_id && uniq_keys && n_uniq && n > 0, "dmt_segment_heads: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  int* flags = reinterpret_cast<int*>(ws);
-  void* scan_ws = reinterpret_cast<unsigned char*>(ws) + flags_bytes;
-  const unsigned nb = (unsigned)cdiv64(n, 256);
-  hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, sorted_keys, (long long)n, flags);
-  e = rocprim::inclusive_scan(scan_ws, scan_need, flags, seg_id, (size_t)n, rocprim::plus<int>(), st);
-  if (e != hipSuccess) { dmt_set_error("dmt_segment_heads: scan failed: %s", hipGetErrorString(e)); return DMT_ERR_LAUNCH; }
-  hipLaunchKernelGGL(finish_heads_kernel, dim3(nb), dim3(256), 0, st, sorted_keys, (long long)n, invalid_key, seg_id, uniq_keys, n_uniq);
-  DMT_CHECK_LAUNCH("dmt_segment_heads");
   return DMT_OK;
 }
 

@@ -998,11 +998,10 @@ class DMTEngine:
         st = ops.stream_ptr()
         dev = self.store.device
         keys = self._buf("keys", (n,), torch.int32)
-        vals = self._buf("vals", (n,), torch.int32)
         keys_s = torch.empty((n,), dtype=torch.int32, device=dev)
         vals_s = torch.empty((n,), dtype=torch.int32, device=dev)
-        L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), ops.p(vals), st)
-        uniq, n_uniq, seg = self.sort_segments(keys, vals, keys_s, vals_s, n, own=True)      # (kept by the batch: no copies)
+        L.call("dmt_embgrad_keys", C.byref(desc), ops.p(keys), None, st)             # (values = entry numbers: the sort writes them itself)
+        uniq, n_uniq, seg = self.sort_segments(keys, None, keys_s, vals_s, n, own=True)      # (kept by the batch: no copies)
         cap = min(n, self.store.total_rows)
         prep = dict(desc=desc, n=n, keys_s=keys_s, vals_s=vals_s, seg=seg, uniq=uniq[:cap], n_uniq=n_uniq, cap=cap)
         batch._prep = prep

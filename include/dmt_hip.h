@@ -161,7 +161,8 @@ typedef struct {
   const int32_t* seq_row_len[DMT_MAX_SEQS];
 } dmt_embgrad_desc;
 
-/* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e.            */
+/* keys[e] (uint32 global row or total_rows if the entry carries no gradient), vals[e] = e (vals may be NULL: dmt_sort_pairs numbers
+ * the entries itself when its vals_in is NULL).                                                                                     */
 int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, void* stream);
 
 /* out[i, :] = in[perm[i], :] for fp32 rows of `dim` floats (dim % 4 == 0), written as fp32 or rounded to bf16: groups a
@@ -169,13 +170,17 @@ int dmt_embgrad_keys(const dmt_embgrad_desc* d, uint32_t* keys, uint32_t* vals, 
 int dmt_rows_permute(const float* in_rows, const int64_t* perm, int64_t n, int32_t dim, int32_t out_dtype, void* out_rows,
                      void* stream);
 
-/* Stable LSD radix sort of (key, value) pairs on bits [0, end_bit).  ws_bytes: in/out workspace size;
- * call with ws == NULL to query.                                                                     */
+/* Stable LSD radix sort of (key, value) pairs on bits [0, end_bit): the library's own kernels (csrc/dmt_sort.hip: 8-bit digits, per pass a
+ * tile histogram, a one-workgroup scan and a ranked scatter through LDS), no vendor sort.  Equal keys keep their input order -- the order
+ * in which the reference's IndexedSlices of one variable are summed is the entry order (run_dnn.py:203-207 densifies them per variable).
+ * vals_in == NULL: values are the entry numbers 0 .. n-1.  Inputs are left untouched; outputs must not alias them.
+ * ws_bytes: in/out workspace size; call with ws == NULL to query (16-byte aligned workspace; n < 2^31 - 4096).                          */
 int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                    int64_t n, int32_t end_bit, void* ws, uint64_t* ws_bytes, void* stream);
 
 /* From sorted keys: seg_id[e] = rank of key[e] among distinct keys (inclusive scan of head flags - 1);
- * uniq_keys[seg] = key; n_uniq[0] = number of distinct keys < invalid_key.                            */
+ * uniq_keys[seg] = key; n_uniq[0] = number of distinct keys < invalid_key.  sorted_keys, seg_id and ws 16-byte aligned.
+ * Three launches of the library's own (count run heads per 4096-entry tile, scan the tile counts, write).                */
 int dmt_segment_heads(const uint32_t* sorted_keys, int64_t n, uint32_t invalid_key, int32_t* seg_id,
                       uint32_t* uniq_keys, int32_t* n_uniq, void* ws, uint64_t* ws_bytes, void* stream);
 
