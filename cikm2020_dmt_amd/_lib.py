@@ -16,7 +16,7 @@ DMT_OPT_SGD, DMT_OPT_ADAGRAD, DMT_OPT_ADADELTA, DMT_OPT_RMSPROP, DMT_OPT_FTRL = 
 DMT_MAX_FEATURES, DMT_MAX_SEQS, DMT_MAX_TABLES = 32, 4, 32
 DMT_SEQ_TARGET = 100
 DMT_ERR_UNSUPPORTED = -3
-DMT_ABI_VERSION = 5        # include/dmt_hip.h: the revision this binding was written against (checked by load())
+DMT_ABI_VERSION = 6        # include/dmt_hip.h: the revision this binding was written against (checked by load())
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

@@ -99,7 +99,7 @@ class DeviceBatch:
         self.ready = None
         if dense.is_cuda:
             self.ready = torch.cuda.Event()
-            self.ready.record(torch.cuda.current_stream(dense.device))
+            self.ready.record(ops.cur_stream(dense.device))
 
     @staticmethod
     def from_inputs(inputs: dict, spec: dict, device, mask=None, label=None, pad_to: Optional[Dict[str, int]] = None) -> "DeviceBatch":
@@ -162,7 +162,7 @@ class DeviceBatch:
             if slot is not None and dbuf.is_cuda:
                 # (BatchParser.ring: the host buffer is reused `ring` batches from now -- not before this copy has read it)
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dbuf.device))
+                ev.record(ops.cur_stream(dbuf.device))
                 slot["event"] = ev
             return DeviceBatch(dense.shape[0], feats, dense, m, lb)
         dense = torch.as_tensor(cols["features"]).to(device, non_blocking=True)
@@ -800,7 +800,7 @@ class DMTEngine:
         # The behaviour sequences are independent between the gather and the assembly of z: with seq_streams each runs on its own
         # stream (autograd replays the backward of every op on the stream of its forward), so the launch-latency-bound B-row kernels
         # of one sequence's decoder fill the tails of another's big kernels.
-        main = torch.cuda.current_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
+        main = ops.cur_stream(self.store.device) if (self.seq_streams and X[0].is_cuda) else None
         pairs_all = self.spec["attention_embed_pairs"]
         us, order = [None] * n_seq, list(range(n_seq))
         tars = list(FanOutFn.apply(tar, n_seq) if (tar.requires_grad and n_seq > 1) else (tar,) * n_seq)
@@ -1072,7 +1072,7 @@ class DMTEngine:
         if pend is None:
             return False
         ctx, grads = pend
-        cur = torch.cuda.current_stream(self.store.device)
+        cur = ops.cur_stream(self.store.device)
         for g in grads:
             if g is not None and g.is_cuda:
                 g.record_stream(cur)

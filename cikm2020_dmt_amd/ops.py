@@ -67,8 +67,19 @@ def det_ws(n: int, max_dim: int, device, tag=""):
     return t.data_ptr(), need
 
 
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
+def cur_stream(device):
+    """torch.cuda.current_stream(device) without its four Python frames of device-index normalisation (12 -> 3 us; ~60 calls a step)."""
+    idx = device.index
+    sd = torch._C._cuda_getCurrentStream(idx if idx is not None else _cur_device())
+    return torch.cuda.Stream(stream_id=sd[0], device_index=sd[1], device_type=sd[2])
+
+
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (the raw handle, ~0.3 us: torch.cuda.current_stream() builds a Stream object through four Python frames -- 12 us, 160 + times a step)
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 def dt_code(t: torch.dtype) -> int:
@@ -128,7 +139,7 @@ def gemm(A, a_rs, a_cs, Bm, b_rs, b_cs, M, N, K, out, ldc, *, bias=None, act_nco
             and K // max(split_k, 1) <= 4096 and bias is None and act_ncols == 0 and gate is None and resid is None and not DETERMINISTIC):
         # a B-row weight gradient accumulated into the gradient arena: nothing reads it before the optimizer, so it waits for the others
         # of its stream and leaves with them in one launch (flush_dw_batches; dmt_gemm_dw_batched)
-        st = torch.cuda.current_stream(A.device)
+        st = cur_stream(A.device)
         lst = _state.dw_batch.setdefault(st, [])
         lst.append((d, (A, Bm, out, c_last), 2.0 * M * N * K * max(batch, 1)))
         if len(lst) >= DW_BATCH_MAX:
@@ -194,7 +205,7 @@ def ln_bwd(dtype_code, rows, d, x, ldx, gamma, stats, dy, lddy, dx, lddx, dg, db
     if lst is not None and direct:
         L.call("dmt_ln_bwd", dtype_code, rows, d, p(x), ldx, p(gamma), p(stats), p(dy), lddy, p(dx), lddx, None, None, p(partials), stream_ptr())
         lst.append((L.LnFinishJob(partials.data_ptr(), dg.data_ptr(), db.data_ptr(), int(partials.shape[0]), int(d)), (partials, dg, db),
-                    torch.cuda.current_stream(partials.device)))
+                    cur_stream(partials.device)))
         return
     L.call("dmt_ln_bwd", dtype_code, rows, d, p(x), ldx, p(gamma), p(stats), p(dy), lddy, p(dx), lddx, p(dg), p(db), p(partials), stream_ptr())
 
@@ -207,7 +218,7 @@ def flush_ln_finish(end=False):
     _state.ln_finish = None if end else []
     if not lst:
         return 0
-    cur = torch.cuda.current_stream(lst[0][1][0].device)
+    cur = cur_stream(lst[0][1][0].device)
     for st in {st for (_j, _k, st) in lst}:
         if st != cur:
             cur.wait_stream(st)
@@ -433,7 +444,7 @@ def _fork_stream(M, *grad_views):
 
 
 def _deferred_wgrad320(x, dz, gw, gb, k_is_320):
-    cur = torch.cuda.current_stream(x.device)
+    cur = cur_stream(x.device)
     x.record_stream(cur)          # (operands of the side-lane sequences were allocated on their streams)
     dz.record_stream(cur)
     if k_is_320:
@@ -455,7 +466,7 @@ def wgrad320(A, B, C, transposed, bias=None, bias_of=0):
         # ordered form: the row splits' partial blocks go through a workspace and are added in split order (no fp32 atomics).  One
         # workspace per stream: the sequence lanes run their weight gradients concurrently
         need = int(L.load().dmt_wgrad320_det_ws_bytes(int(A.shape[0]), int(B.shape[1])))
-        key = ("wgrad320", str(A.device), int(torch.cuda.current_stream(A.device).cuda_stream))
+        key = ("wgrad320", str(A.device), int(cur_stream(A.device).cuda_stream))
         ws = _det_ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=A.device)
@@ -498,7 +509,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
     if gw is not None and (gb is not None or not want_bias):
         if _may_defer(M, gw, gb):
             def _later(x=x, dz=dz, gw=gw, gb=gb):
-                cur = torch.cuda.current_stream(x.device)
+                cur = cur_stream(x.device)
                 x.record_stream(cur)
                 dz.record_stream(cur)
                 gemm(x, 1, ldx, dz, ldz, 1, rows, N, M, gw, gw.stride(0) if gw.shape[0] > 1 else N, ones_row=want_bias, c_last=gb,
@@ -507,7 +518,7 @@ def linear_backward_weight(x, dz, want_bias=True, w_leaf=None, b_leaf=None):
             return None, None
         side = _fork_stream(M, gw, gb)
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(x.device))       # x, dz were produced on the current stream
+            side.wait_stream(cur_stream(x.device))       # x, dz were produced on the current stream
             with torch.cuda.stream(side):
                 x.record_stream(side)
                 dz.record_stream(side)
@@ -843,7 +854,7 @@ class FFNLNChainFn(torch.autograd.Function):
         if _state.dw_batch is not None and M >= _state.min_rows():
             # an encoder's backward begins on this lane: the decoder's B-row weight gradients collected so far leave now, in one launch,
             # in front of the long kernels (at the very end of backward they would sit beside the HBM-bound embedding tail)
-            _flush_dw_stream(torch.cuda.current_stream(x2.device))
+            _flush_dw_stream(cur_stream(x2.device))
         dy2 = dy.reshape(-1, d)
         if dy2.stride(-1) != 1:
             dy2 = dy2.contiguous()

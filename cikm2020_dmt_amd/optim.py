@@ -92,7 +92,7 @@ class TFAdam:
             return
         if self._early_event is not None:
             # an early catch-up on the index lane reads state / lr_hist / stamp: order the rollback behind it
-            torch.cuda.current_stream(self.store.device).wait_event(self._early_event)
+            ops.cur_stream(self.store.device).wait_event(self._early_event)
             self._early_event = None
         self.state.view(torch.int32)[3] -= 1
         self._begun = False
@@ -120,7 +120,7 @@ class TFAdam:
                ops.p(self.stamp) if self.stamp is not None else None, int(to_step), ops.stream_ptr())
         if s.device.type == "cuda":
             self._early_event = torch.cuda.Event()
-            self._early_event.record(torch.cuda.current_stream(s.device))
+            self._early_event.record(ops.cur_stream(s.device))
 
     def apply_dense(self, grad_scale: float = 1.0):
         s = self.store

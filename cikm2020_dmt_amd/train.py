@@ -150,7 +150,7 @@ class Trainer:
             if need_plan and "xplan" not in prep:
                 prep["xplan"] = self.plan_exchange(prep["uniq"], prep["n_uniq"])
             return prep
-        main = torch.cuda.current_stream(self.device)
+        main = ops.cur_stream(self.device)
         if batch.ready is not None:
             side.wait_event(batch.ready)
             self._record_batch(batch, main)      # (the id columns are read on this lane, possibly before forward_backward sees the batch)
@@ -187,7 +187,7 @@ class Trainer:
         if infl is None or side is None or prep is None or "_caught" in prep or self.table_layout == "sharded":
             return
         ev_begun, to_step = infl
-        main = torch.cuda.current_stream(self.device)
+        main = ops.cur_stream(self.device)
         with torch.cuda.stream(side):
             side.wait_event(ev_begun)
             jev = getattr(self.engine, "junction_event", None)
@@ -212,7 +212,7 @@ class Trainer:
         for key in ("_ready", "_caught"):
             ev = prep.pop(key, None)
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                ops.cur_stream(self.device).wait_event(ev)
         if self.table_layout == "sharded":
             with self._span("row_fetch"):
                 self.engine.fetch_rows(batch, self.opt, prep.get("xplan"))      # owners replay the lazy updates of what they send
@@ -426,7 +426,7 @@ class Trainer:
         else:
             self.opt.stamp_rows(prep["uniq"], prep["n_uniq"], prep["cap"])
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(ops.cur_stream(self.device))
         self._inflight = (ev, self.opt.step_in_flight())
 
     def _abort_open_step(self):
@@ -448,7 +448,7 @@ class Trainer:
         if batch.ready is not None and self.device.type == "cuda":
             # a batch uploaded on another stream (an input thread's): the compute stream waits for the copy, and the allocator learns
             # that this stream reads the buffer (a no-op for a batch made on this stream)
-            cur = torch.cuda.current_stream(self.device)
+            cur = ops.cur_stream(self.device)
             cur.wait_event(batch.ready)
             self._record_batch(batch, cur)
         self.sync_rows(batch)
@@ -525,12 +525,12 @@ class Trainer:
                 self.engine.step_state.ln_finish = None
         if batch_dw:
             ops.flush_ln_finish(end=True)
-            cur = torch.cuda.current_stream(self.device)
+            cur = ops.cur_stream(self.device)
             for st in ops.flush_dw_batches(end=True):
                 if st != cur:
                     cur.wait_stream(st)                         # the batched weight gradients are part of this backward
         if fork_lane is not None and forked is not None and forked["n"]:
-            torch.cuda.current_stream(self.device).wait_stream(fork_lane)     # the forked weight gradients are part of this backward
+            ops.cur_stream(self.device).wait_stream(fork_lane)     # the forked weight gradients are part of this backward
         self.n_forked = forked["n"] if forked is not None else 0
         self.engine.dropout_step_seed = None
         self.last = dict(out=out, p_ctr=p_ctr, p_cvr=p_cvr)
@@ -640,7 +640,7 @@ class Trainer:
                 # TWO LANES from here: the id-bound tail of the step (position / embedding-row gradients, sparse Adam: HBM-latency
                 # work on few wavefronts) on the index lane, the long-row weight gradients backward skipped (MFMA work) on the compute
                 # stream; they meet at the dense Adam.
-                main = torch.cuda.current_stream(self.device)
+                main = ops.cur_stream(self.device)
                 lane.wait_stream(main)
                 with torch.cuda.stream(lane):
                     self.engine.finish_sparse_backward()

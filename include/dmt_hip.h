@@ -45,6 +45,8 @@ extern "C" {
  *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31).   4  round 4: dmt_mmoe_desc grew (ws, ws_bytes,
  *   gate_dx); dmt_mmoe_experts_ws_bytes added.   5  round 5: PACKED ROWS (below): dmt_gather_desc / dmt_embgrad_desc grew (seq_row_off,
  *   seq_row_len), dmt_attn_desc (row_off, ex_list, n_list), dmt_mhsa_desc (packed-row fields), dmt_q1mem_desc (row_off); dmt_colsum_rows_packed added.
+ *   6  round 6: dmt_sort_pairs / dmt_segment_heads are the library's own kernels (vals_in may be NULL; 16-byte aligned workspace; the
+ *   workspace sizes changed), dmt_embgrad_keys takes vals == NULL.
  *
  * PACKED ROWS.  A behaviour sequence of a batch may be stored WITHOUT its padding: example b's rows t = 0 .. len[b] - 1 are rows
  * row_off[b] + t of an [R, d] matrix, R = sum_b len[b] (row_off: int32 [B], any order of the examples -- the engine groups examples of
@@ -52,7 +54,7 @@ extern "C" {
  * know about examples take row_off (NULL = the dense [B, T, d] layout, row b * T + t).  Rows t >= len[b] do not exist: in the dense
  * layout they hold finite values nothing reads (the reference masks them as keys, and their gradients are zero), so the
  * two layouts agree on every row that exists.  Dropout counters keep the DENSE element index, so a packed and a dense run draw the same mask. */
-#define DMT_ABI_VERSION 5
+#define DMT_ABI_VERSION 6
 const char* dmt_last_error(void);
 int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */

@@ -171,20 +171,38 @@ def _auc_pair(y, p, cuda):
     return O.exact_auc(y, p), s.result()
 
 
+def _spread_and_label(x_ref, xs, rng, sharp=3.0):
+    """Random-init logits are small and bunched: ONE affine map (fitted on the reference logits) spreads every run's logits over the score
+    range -- monotone and shared, so the rank AUC is untouched and the 200 bins of the estimator are actually used.  Labels are Bernoulli
+    draws from the REFERENCE scorer's sharpened scores (AUC ~0.8-0.9, both classes in the thousands)."""
+    med, sd = np.median(x_ref), x_ref.std() + 1e-12
+    ps = [1.0 / (1.0 + np.exp(-2.0 * (x - med) / sd)) for x in xs]
+    y = (rng.random(len(x_ref)) < 1.0 / (1.0 + np.exp(-sharp * (x_ref - med) / sd))).astype(np.float64)
+    return ps, y, sd
+
+
+AUC_BAR = 1e-4          # north_star: per-task AUC within 1e-4, for EVERY configuration
+AUC_LABEL_SEEDS = (5, 6, 7)
+
+
+@pytest.mark.parametrize("pseed", [21, 22, 23])
 @pytest.mark.parametrize("cfg", ["configs1_L50_bf16", "configs4_L200_bf16", "configs4_L200_fp8"])
-def test_auc_of_bf16_and_fp8_scores_against_fp32_on_a_large_evaluation_set(cuda, cfg):
-    """north_star: per-task AUC within 1e-4.  The 474 demo records cannot resolve that (18 order positives).  Here the SAME weights
-    score an evaluation set of 102 400 synthetic examples in fp32 mode and in the low-precision mode; the
-    labels are drawn from the fp32 model's own sharpened scores (so the AUC is ~0.8, not 0.5, and both tasks have >= 10 K positives).
-    Reported and asserted: |AUC(low precision) - AUC(fp32)| for the exact rank AUC and for the 200-bin estimator, per task."""
+def test_auc_of_bf16_and_fp8_scores_against_fp32_on_a_large_evaluation_set(cuda, cfg, pseed):
+    """north_star: per-task AUC within 1e-4.  The 474 demo records cannot resolve that (18 order positives).  Here the SAME weights score
+    an evaluation set of 102 400 synthetic examples in fp32 mode and in the low-precision mode; labels are drawn from the fp32 model's
+    own sharpened scores.  Three weight draws (pseed) x three label draws x both estimators (exact rank AUC, the 200-bin tf.metrics.auc)
+    x both tasks: the WORST |AUC(low precision) - AUC(fp32)| of a weight draw is what is asserted -- one draw at 1.5x margin (round 5)
+    was not a claim.  This is HIP against HIP (fp32 engine as the reference scorer); the oracle-labelled form is the next test.
+    A configuration that does not meet the bar is reported as an expected failure (XFAIL) under a regression guard, never passed under a
+    relaxed bound; the benchmarked configuration (L = 50 bf16) must meet it outright.
+    (fp8: the e4m3 MFMA path covers the attention FORWARD only -- backward stays bf16 -- and as a kernel it is slower than the bf16 one:
+    BASELINE.md section 5.  The labels here follow the scores far more sharply -- AUC ~0.9 -- than the reference's data does -- 0.69 --,
+    so a given score perturbation moves these AUCs more than it would there.)"""
     long = "L200" in cfg
     so, sp = _long_spec(200) if long else (dict(S.scaled_spec(S.e64_spec(), E64_ROWS)),) * 2
-    P = _params(so, seed=21)
-    rng = np.random.default_rng(5)
-    # the SAME evaluation-set size for every configuration (>= 100 K examples, as the module docstring states): the rank AUC of two
-    # scorers that differ by per-example noise differs by ~ 1 / sqrt(n) of that noise -- rounds 2-4 scored the long configurations on
-    # 40 960 examples and compared the result with the bar the 102 400-example configuration met (1.0e-4 vs 4e-5 at a SMALLER logit
-    # distance, 0.068 vs 0.11 of the logit spread)
+    P = _params(so, seed=pseed)
+    # the SAME evaluation-set size for every configuration (>= 100 K examples): the rank AUC of two scorers that differ by per-example
+    # noise differs by ~ 1 / sqrt(n) of that noise
     nb, B = 25, 4096
     seq_lens = {grp[0][0]: 200 for grp in sp["attention_embed_pairs"][:2]} if long else None
     batches = []
@@ -194,36 +212,85 @@ def test_auc_of_bf16_and_fp8_scores_against_fp32_on_a_large_evaluation_set(cuda,
     pc32, pv32 = _eval_scores(cuda, sp, P, torch.float32, None, batches)
     ad = "fp8" if cfg.endswith("fp8") else ("bf16" if long else None)
     pcl, pvl = _eval_scores(cuda, sp, P, torch.bfloat16, ad, batches)
-    out = []
-    for name, x32, xl in (("ctr", pc32, pcl), ("ctvr", pv32, pvl)):
-        # random-init logits are small and bunched: ONE affine map (from the fp32 logits) spreads both runs' logits over the score
-        # range -- monotone and shared, so the rank AUC is untouched and the 200 bins of the estimator are actually used
-        med, sd = np.median(x32), x32.std() + 1e-12
-        p32, pl = (1.0 / (1.0 + np.exp(-2.0 * (x - med) / sd)) for x in (x32, xl))
-        y = (rng.random(len(p32)) < 1.0 / (1.0 + np.exp(-3.0 * (x32 - med) / sd))).astype(np.float64)
-        assert 1000 <= y.sum() <= len(y) - 1000
-        e32, b32 = _auc_pair(y, p32.astype(np.float32), cuda)
-        el, bl = _auc_pair(y, pl.astype(np.float32), cuda)
-        out.append((name, e32, el, abs(el - e32), b32, bl, abs(bl - b32), float(np.abs(xl - x32).max() / sd)))
-    print("AUC %s (n = %d): task, exact fp32, exact low, |d|, 200-bin fp32, 200-bin low, |d|, max |dlogit| / std:" % (cfg, nb * B), out)
-    # north_star's bar is |d AUC| <= 1e-4 per task, for EVERY configuration: no configuration gets a bar of its own.  Measured on
-    # MI355X (this test prints them): L = 50 bf16 (the benchmarked mode) 3e-5 / 2e-5 exact, 4e-5 / 2e-5 200-bin: inside; L = 200 bf16
-    # 1e-5 / 1.0e-4: AT the bar; L = 200 with the e4m3 attention forward 1.1e-4 / 1.8e-4: OUTSIDE -- configs[4]'s fp8 path does not
-    # meet north_star and this test reports it as an expected failure (XFAIL) instead of
-    # passing under a relaxed bound.  The `guard` numbers below are regression guards for the kernels (a broken kernel moves the AUC by
-    # 1e-2), not parity claims.  (The labels here follow the scores far more sharply -- AUC 0.92 -- than the reference's data does --
-    # AUC 0.69 --, so a given score perturbation moves these AUCs more than it would there.)
-    BAR = 1e-4
-    guard = {"configs1_L50_bf16": 1e-4, "configs4_L200_bf16": 3e-4, "configs4_L200_fp8": 6e-4}[cfg]
-    worst = 0.0
-    for (name, e32, el, de, b32, bl, db, _ds) in out:
-        assert e32 > 0.7
-        assert de < guard, (cfg, name, "exact AUC (regression guard)", de)
-        assert db < guard, (cfg, name, "200-bin AUC (regression guard)", db)
-        worst = max(worst, de, db)
-    if worst >= BAR:
+    out, worst = [], 0.0
+    for ls in AUC_LABEL_SEEDS:
+        rng = np.random.default_rng(ls)
+        for name, x32, xl in (("ctr", pc32, pcl), ("ctvr", pv32, pvl)):
+            (p32, pl), y, sd = _spread_and_label(x32, (x32, xl), rng)
+            assert 1000 <= y.sum() <= len(y) - 1000
+            e32, b32 = _auc_pair(y, p32.astype(np.float32), cuda)
+            el, bl = _auc_pair(y, pl.astype(np.float32), cuda)
+            assert e32 > 0.7
+            out.append((ls, name, round(e32, 5), "%.1e" % abs(el - e32), "%.1e" % abs(bl - b32), round(float(np.abs(xl - x32).max() / sd), 3)))
+            worst = max(worst, abs(el - e32), abs(bl - b32))
+    print("AUC %s weights %d (n = %d): (label seed, task, exact fp32 AUC, |d| exact, |d| 200-bin, max |dlogit| / std): %s; WORST %.2e"
+          % (cfg, pseed, nb * B, out, worst))
+    guard = {"configs1_L50_bf16": 1e-4, "configs4_L200_bf16": 3e-4, "configs4_L200_fp8": 6e-4}[cfg]      # (a broken kernel moves the AUC by 1e-2)
+    assert worst < guard, (cfg, pseed, "regression guard", worst)
+    if worst >= AUC_BAR:
         assert cfg != "configs1_L50_bf16"          # the benchmarked configuration must meet the bar outright
-        pytest.xfail("%s: |d AUC| = %.2e does not meet north_star's 1e-4 bar" % (cfg, worst))
+        pytest.xfail("%s, weights %d: worst |d AUC| = %.2e over %d label draws x 2 tasks x 2 estimators does not meet north_star's 1e-4 bar"
+                     % (cfg, pseed, worst, len(AUC_LABEL_SEEDS)))
+
+
+@pytest.mark.parametrize("cfg,n_batches", [("configs1_L50_bf16", 8), ("configs4_L200_bf16", 2), ("configs4_L200_fp8", 2)])
+def test_auc_against_the_oracle_with_labels_from_the_oracle_scores(cuda, cfg, n_batches):
+    """HIP against the ORACLE (not HIP against HIP): the CPU restatement (oracle/dmt_oracle_torch.py, float64) scores n_batches x 4096
+    synthetic examples, the labels are drawn from ITS sharpened scores, and the HIP engine's low-precision scores of the same examples
+    are rated on those labels.  The oracle costs ~0.3 GFLOP per example at L = 50 and ~1 GFLOP at L = 200 in float64 on the host, so
+    the sets are 32 768 and 8 192 examples: |d AUC| is resolved to ~1e-4 on the first and to ~3e-4 on the second (the estimators' own
+    1 / sqrt(n) -- the 102 400-example HIP-vs-HIP test above is the one that resolves the bar for L = 200).  Asserted: the bar itself at
+    L = 50, 3 x the bar at L = 200 (stated, not a relaxed claim of meeting it), and that the fp32 HIP engine's logits ARE the oracle's."""
+    long = "L200" in cfg
+    so, sp = _long_spec(200) if long else (dict(S.scaled_spec(S.e64_spec(), E64_ROWS)),) * 2
+    P = _params(so, seed=31)
+    B = 4096
+    seq_lens = {grp[0][0]: 200 for grp in sp["attention_embed_pairs"][:2]} if long else None
+    batches = []
+    for i in range(n_batches):
+        inputs, mask, _ = make_batch(sp, B, seed=2000 + i, lengths="ragged", seq_lens=seq_lens)
+        batches.append((inputs, mask))
+    Pt = OT.to_torch(P, torch.float64, requires_grad=False)
+    oc, ov = [], []
+    with torch.no_grad():
+        for (inputs, _mask) in batches:
+            for lo in range(0, B, 512):                                  # (512 examples at a time: the float64 score tensors of L = 200)
+                sub = GU.slice_inputs(inputs, lo, lo + 512) if hasattr(GU, "slice_inputs") else _slice_inputs(inputs, lo, lo + 512)
+                (c, o), yb = OT.forward(Pt, sub, so)
+                oc.append((c + yb).numpy().reshape(-1))
+                ov.append((o + yb).numpy().reshape(-1))
+    oc, ov = np.concatenate(oc), np.concatenate(ov)
+    ad = "fp8" if cfg.endswith("fp8") else ("bf16" if long else None)
+    pcl, pvl = _eval_scores(cuda, sp, P, torch.bfloat16, ad, batches)
+    pc32, pv32 = _eval_scores(cuda, sp, P, torch.float32, None, batches[:1])
+    sd_c = oc.std()
+    assert np.abs(pc32 - oc[:B]).max() < 2e-3 * max(sd_c, 1e-3) + 2e-4       # the fp32 engine reproduces the oracle's logits
+    worst, out = 0.0, []
+    for ls in AUC_LABEL_SEEDS:
+        rng = np.random.default_rng(ls)
+        for name, xo, xl in (("ctr", oc, pcl), ("ctvr", ov, pvl)):
+            (po, pl), y, sd = _spread_and_label(xo, (xo, xl), rng)
+            eo, bo = _auc_pair(y, po.astype(np.float32), cuda)
+            el, bl = _auc_pair(y, pl.astype(np.float32), cuda)
+            out.append((ls, name, round(eo, 5), "%.1e" % abs(el - eo), "%.1e" % abs(bl - bo)))
+            worst = max(worst, abs(el - eo), abs(bl - bo))
+    print("AUC vs oracle %s (n = %d): (label seed, task, oracle AUC, |d| exact, |d| 200-bin): %s; WORST %.2e" % (cfg, n_batches * B, out, worst))
+    assert worst < (AUC_BAR if not long else 3 * AUC_BAR), (cfg, worst)
+
+
+def _slice_inputs(inputs, lo, hi):
+    """Examples lo .. hi - 1 of an `inputs` dict (dense features + SparseTensorValues)."""
+    out = {}
+    for k, v in inputs.items():
+        if isinstance(v, SparseTensorValue) or (hasattr(v, "indices") and hasattr(v, "dense_shape")):
+            idx = np.asarray(v.indices)
+            sel = (idx[:, 0] >= lo) & (idx[:, 0] < hi)
+            ind = idx[sel].copy()
+            ind[:, 0] -= lo
+            out[k] = SparseTensorValue(ind, np.asarray(v.values)[sel], np.array([hi - lo, int(np.asarray(v.dense_shape)[1])], dtype=np.int64))
+        else:
+            out[k] = np.asarray(v)[lo:hi]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------- configs[3]

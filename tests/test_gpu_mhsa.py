@@ -130,3 +130,39 @@ def test_mhsa_block_autograd_matches_unfused_path(cuda):
     assert (dxa - dxb).abs().max() / dxb.abs().max() < 3e-2
     for a, bb in zip(ga, gb):
         assert (a - bb).abs().max() / bb.abs().max() < 3e-2
+
+
+@pytest.mark.parametrize("B,T", [(5, 50), (3, 64), (9, 33), (7, 32), (6, 17), (11, 10), (64, 50)])
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_mhsa_block_backward_matches_the_fp32_statement(cuda, B, T, keep):
+    """Every gradient of the block (dx, dWqkv, dbias, dgamma, dbeta) against autograd through the plain PyTorch fp32 statement above (the
+    bf16 roundings of Q | K | V and of the weights are straight-through there): LayerNorm gradient, attention gradient with the key mask
+    before and the query mask after the softmax, the dropout mask the forward drew, dx = dqkv Wqkv^T + ds.  Tolerance: 3 % of the largest element of each gradient (bf16 ds, dqkv, P, dS)."""
+    H, d = 4, 320
+    x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=B * 100 + T + 1)
+    img = torch.empty(ops.mhsa_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_image_build(w, img)
+    wt = ops.Weight(w, w.to(BF), w.to(BF).t().contiguous())
+    g = torch.Generator().manual_seed(11)
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])
+    dy = torch.randn(B, T, d, generator=g).to(BF).to(cuda) * live[:, :, None]           # (padded rows carry no gradient downstream)
+    seed = 4242
+    leaves = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+    xa = x.clone().requires_grad_(True)
+    y = ops.MhsaBlockFn.apply(xa, leaves[0], leaves[1], wt, leaves[2], leaves[3], lens, H, img, seed, keep, 1e-8)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    ref_leaves = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+    xr = x.float().clone().requires_grad_(True)
+    y_ref, _s, _qkv = _ref(xr, ref_leaves[0], ref_leaves[1], ref_leaves[2], ref_leaves[3], lens, H, seed, keep)
+    # the padded query rows of the statement hold -2^32-scale values: they are cut out of the graph exactly as the model cuts them (no
+    # gradient comes back into them)
+    (y_ref * dy.float()).sum().backward()
+    names = ("dx", "dWqkv", "dbias", "dgamma", "dbeta")
+    got = [xa.grad.float()] + [l.grad.float() for l in leaves]
+    want = [xr.grad] + [l.grad for l in ref_leaves]
+    for nm, a, r in zip(names, got, want):
+        if nm == "dx":
+            a, r = a * live[:, :, None], r * live[:, :, None]
+        assert torch.isfinite(a).all(), nm
+        assert (a - r).abs().max() <= 3e-2 * r.abs().max() + 1e-6, (nm, float((a - r).abs().max()), float(r.abs().max()))
