@@ -4,6 +4,7 @@
 // Backward recomputes P from Q, K (flash-style: no [B,H,T,T] tensor ever touches HBM) and keeps the
 // per-key dK / dV rows in registers.  Masking follows the reference literally (see dmt_hip.h).
 #include "dmt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -1772,7 +1773,11 @@ extern "C" int dmt_attn_bwd(const dmt_attn_bwd_desc* d, void* stream) {
         const int tmax = (packed && f.max_len > 0 && f.max_len < f.Tq) ? f.max_len : f.Tq;
         const int ntq = tmax <= 32 ? 1 : 2, ntk = (packed ? tmax : f.Tk) <= 32 ? 1 : 2;
         const long long n_ex = f.ex_list ? f.n_list : f.B;
-#define DMT_BWD_CO(DHV) do { const size_t lb = (size_t)CoBwd<DHV>::BYTES; \
+        size_t lds_extra = 0;      // timing experiments only (make EXPERIMENTS=1): LDS a wavefront reserves on top of its own -- fewer wavefronts per CU
+#ifdef DMT_TIMING_EXPERIMENTS
+        { const char* e = getenv("DMT_ATTN_BWD_LDS_EXTRA"); lds_extra = e ? (size_t)atoi(e) : 0; }
+#endif
+#define DMT_BWD_CO(DHV) do { const size_t lb = (size_t)CoBwd<DHV>::BYTES + lds_extra; \
     const unsigned nbx = (unsigned)((n_ex + 7) / 8 * 8 * f.H);       /* (examples in groups of 8: one per XCD) */ \
     if (ntq == 1 && ntk == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 1>), dim3(nbx), dim3(64), lb, st, a); \
     else if (ntq == 1) hipLaunchKernelGGL((attn_bwd_co_kernel<DHV, 1, 2>), dim3(nbx), dim3(64), lb, st, a); \

@@ -513,6 +513,18 @@ class DMTEngine:
     def _wslice(w: Weight, a, b) -> Weight:
         return Weight(w.f32[:, a:b], w.lp[:, a:b] if w.lp is not None else None, w.lp_t[a:b, :] if w.lp_t is not None else None)
 
+    def release(self):
+        """Drop what the last pass left behind: `intermediates` holds graph-attached tensors whose autograd nodes point back at this engine
+        (GatherFn keeps it in its ctx) -- a cycle through C++ graph edges that Python's collector cannot see, so an engine that is simply
+        dropped keeps its last step's activations allocated (tens of GB at L = 200 in fp32: eighteen engines in one test module ran the
+        device out of memory).  A long-lived engine never needs this; code that builds engines in a loop calls it (Trainer.close())."""
+        self.intermediates = {}
+        self._last_packs = None
+        self._pending_sparse = None
+        self._sparse = None
+        self._l2_coef = None
+        self._ws = {}
+
     @property
     def sparse(self):
         """(uniq_keys, n_uniq, grad_rows, cap) of the last backward.  The gradient of l2_norm (if the loss went through it) is added

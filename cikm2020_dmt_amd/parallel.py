@@ -275,7 +275,7 @@ def pin_rank_to_cores(local_rank: int, local_world: int, device_index: int = Non
                 if n >= 0:
                     cl = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read())
                     node, node_cores = n, [c for c in cl if c in set(allowed)]
-        except (OSError, ValueError, AttributeError) as e:
+        except Exception as e:          # (never fatal: the plan below falls back to a plain slice -- but said aloud, not swallowed)
             import warnings
             warnings.warn("pin_rank_to_cores: NUMA node of device %s not found (%s: %s); the rank keeps a plain slice of the host's cores"
                           % (device_index, type(e).__name__, e))

@@ -728,6 +728,12 @@ class Trainer:
         self.opt.step(sparse, grad_scale=1.0 / W)
         return loss
 
+    def close(self):
+        """Release the last step's tensors (DMTEngine.release): for code that builds Trainers in a loop."""
+        self.last = {}
+        self._inflight = None
+        self.engine.release()
+
     @torch.no_grad()
     def predict(self, batch: DeviceBatch):
         """run_dnn.predict scoring (run_dnn.py:663-687): sigmoid(logit + y_bias)."""

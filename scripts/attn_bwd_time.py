@@ -5,6 +5,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from cikm2020_dmt_amd import _lib
+if os.environ.get("DMT_LIB_OVERRIDE"):          # an experimental build (make EXPERIMENTS=1) kept beside the shipped library
+    _lib.LIB_PATH = os.path.abspath(os.environ["DMT_LIB_OVERRIDE"])
 from cikm2020_dmt_amd import ops
 
 dev = torch.device("cuda")

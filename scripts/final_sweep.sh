@@ -1,7 +1,7 @@
 #!/bin/bash
 # The measurement set of a build, in one call on one box (run from the repo root on the GPU box):  scripts/final_sweep.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r05}
+tag=${1:-r06}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R

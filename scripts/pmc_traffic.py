@@ -21,6 +21,8 @@ FAMILIES = {
     "gemm_small": ["gemm_small_kernel"],
     "adam_catchup": ["adam_catchup_kernel"],
     "ln": ["ln_fwd", "ln_bwd"],
+    "index_sort": ["rs_hist_kernel", "rs_scan_kernel", "rs_scatter_kernel", "sh_count_kernel", "sh_scan_kernel", "sh_write_kernel"],     # csrc/dmt_sort.hip (round 6)
+    "embgrad_keys": ["embgrad_keys_kernel"],
 }
 
 

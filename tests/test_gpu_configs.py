@@ -161,7 +161,14 @@ def _eval_scores(cuda, sp, state, dt, ad, batches):
         (c, o), yb = tr.engine.inference(b)               # run_dnn.predict scores sigmoid(logit + y_bias) (run_dnn.py:663-687)
         pc.append((c + yb).detach().float().cpu().numpy().reshape(-1).astype(np.float64))
         pv.append((o + yb).detach().float().cpu().numpy().reshape(-1).astype(np.float64))
+        del b, c, o, yb
+    tr.close()
     del tr
+    # (Trainer.close(): the engine's `intermediates` hold graph-attached tensors whose autograd nodes point back at the engine -- a cycle
+    #  through C++ graph edges no collector sees; eighteen L = 200 engines of this module ran the device out of memory without it)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     return np.concatenate(pc), np.concatenate(pv)
 
 
@@ -252,13 +259,16 @@ def test_auc_against_the_oracle_with_labels_from_the_oracle_scores(cuda, cfg, n_
         batches.append((inputs, mask))
     Pt = OT.to_torch(P, torch.float64, requires_grad=False)
     oc, ov = [], []
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # (torch's intra-op pool is far slower at 256 threads than at 32 on these shapes: bench.py)
     with torch.no_grad():
         for (inputs, _mask) in batches:
             for lo in range(0, B, 512):                                  # (512 examples at a time: the float64 score tensors of L = 200)
-                sub = GU.slice_inputs(inputs, lo, lo + 512) if hasattr(GU, "slice_inputs") else _slice_inputs(inputs, lo, lo + 512)
+                sub = _slice_inputs(inputs, lo, lo + 512)
                 (c, o), yb = OT.forward(Pt, sub, so)
                 oc.append((c + yb).numpy().reshape(-1))
                 ov.append((o + yb).numpy().reshape(-1))
+    torch.set_num_threads(nthreads)
     oc, ov = np.concatenate(oc), np.concatenate(ov)
     ad = "fp8" if cfg.endswith("fp8") else ("bf16" if long else None)
     pcl, pvl = _eval_scores(cuda, sp, P, torch.bfloat16, ad, batches)
