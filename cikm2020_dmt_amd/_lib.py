@@ -114,6 +114,11 @@ class MhsaDesc(C.Structure):
                 ("blocks", c_vp), ("n_tiles", c_i32), ("n_rows", c_i64)]                          # revision 5: packed rows
 
 
+class MhsaBwdDesc(C.Structure):
+    _fields_ = [("d_model", c_i32), ("num_heads", c_i32), ("B", c_i32), ("T", c_i32), ("ds", c_vp), ("qkv", c_vp), ("lens", c_vp), ("image", c_vp),
+                ("dqkv", c_vp), ("dx", c_vp), ("drop_seed", C.c_uint32), ("drop_keep", c_f32), ("blocks", c_vp), ("n_tiles", c_i32), ("n_rows", c_i64)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("A", c_vp), ("ld_a", c_i64), ("a_cols", c_i32), ("B", c_vp), ("ld_b", c_i64), ("M", c_i64), ("N", c_i32), ("C", c_vp),
                 ("ldc", c_i64), ("transposed", c_i32), ("bias", c_vp), ("bias_of", c_i32), ("det_ws", c_vp), ("det_ws_bytes", C.c_uint64)]
@@ -134,6 +139,9 @@ class TableMap(C.Structure):
 _SIGS = {
     "dmt_gather_fwd": [C.POINTER(GatherDesc), c_vp],
     "dmt_embgrad_keys": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp],
+    "dmt_mhsa_bwd_image_bytes": [C.POINTER(c_i64)],
+    "dmt_mhsa_bwd_image_build": [c_vp, c_i64, c_vp, c_vp],
+    "dmt_mhsa_block_bwd": [C.POINTER(MhsaBwdDesc), c_vp],
     "dmt_sort_pairs": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_segment_heads": [c_vp, c_i64, C.c_uint32, c_vp, c_vp, c_vp, c_vp, C.POINTER(C.c_uint64), c_vp],
     "dmt_entry_slots": [C.POINTER(EmbGradDesc), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],

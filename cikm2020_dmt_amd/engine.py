@@ -459,6 +459,9 @@ class DMTEngine:
         # three-launch path (dmt_proj, dmt_attn_fwd, dmt_ln_fwd)
         self._use_mhsa = False
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "1") == "1"
+        # the block's backward as ONE launch behind the LayerNorm gradient (dmt_mhsa_block_bwd) instead of dmt_attn_bwd + the dx GEMM.  Off by
+        # default: measured 1.4x SLOWER than the two launches it replaces; DMT_FUSED_MHSA_BWD=1 selects it.
+        self.use_mhsa_bwd = os.environ.get("DMT_FUSED_MHSA_BWD", "0") == "1"
         self.defer_sparse, self._pending_sparse = False, None     # GatherFn.backward leaves its work to finish_sparse_backward()
         self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") != "0"        # side streams for the behaviour sequences
         self.use_q1mem = os.environ.get("DMT_Q1MEM", "1") == "1"                # decoder attention over raw memory rows (dmt_q1mem.hip)
@@ -691,8 +694,15 @@ class DMTEngine:
         img = self.store.mhsa.get(a) if x.dtype == torch.bfloat16 else None
         if pack is not None or (img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1], x.shape[0])):
             seed, keep = self._attn_drop(stream)
+            img_b = None
+            if self.use_mhsa_bwd and img is not None:
+                if not self.store.mhsa_bwd_in_use:             # (first use: build the images now; from here on every refresh rebuilds them)
+                    self.store.mhsa_bwd_in_use = True
+                    for scope, im in self.store.mhsa_bwd.items():
+                        ops.mhsa_bwd_image_build(self.store.leaf[scope + "qkv_kernel"].detach(), im)
+                img_b = self.store.mhsa_bwd.get(a)
             return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
-                                         self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8, pack)
+                                         self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8, pack, img_b)
         s1 = ops.SelfAttnBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"), lens, H,
                                        *self._attn_drop(stream), self.kopts)
         return ops.layer_norm(s1, self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"))

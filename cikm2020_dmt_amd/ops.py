@@ -1353,12 +1353,48 @@ def mhsa_block_fwd(x, lens, image, bias, gamma, beta, eps, H, drop_seed, drop_ke
     return y, s, stats, qkv
 
 
+def mhsa_bwd_image_bytes():
+    n = C.c_int64(0)
+    L.call("dmt_mhsa_bwd_image_bytes", C.byref(n))
+    return int(n.value)
+
+
+def mhsa_bwd_image_build(wqkv_f32, image):
+    L.call("dmt_mhsa_bwd_image_build", p(wqkv_f32), wqkv_f32.stride(0), p(image), stream_ptr())
+
+
+def mhsa_block_bwd(ds, qkv, lens, image_bwd, H, drop_seed, drop_keep, pack=None):
+    """dqkv, dx = the attention gradient and dx = dqkv Wqkv^T + ds in ONE launch (dmt_mhsa_block_bwd).  ds / qkv: [B, T, d] / [B, T, 3 d]
+    (pack: [1, R, .] packed rows)."""
+    B, T, d = ds.shape
+    dqkv = torch.empty_like(qkv)
+    dx = torch.empty_like(ds)
+    dd = L.MhsaBwdDesc()
+    if pack is not None:
+        rows = T
+        B, T = pack.B, pack.T
+        dd.blocks, dd.n_tiles, dd.n_rows = pack.blocks.data_ptr(), pack.n_tiles, pack.R
+    else:
+        rows = B * T
+    dd.d_model, dd.num_heads, dd.B, dd.T = d, H, B, T
+    dd.ds, dd.qkv, dd.lens, dd.image = ds.data_ptr(), qkv.data_ptr(), lens.data_ptr(), image_bwd.data_ptr()
+    dd.dqkv, dd.dx = dqkv.data_ptr(), dx.data_ptr()
+    dd.drop_seed, dd.drop_keep = int(drop_seed), float(drop_keep)
+    # S, dP in both orientations + dQ, dK, dV (14 T^2 d / 4 ... counted as the 10 T^2 d of the unfused core: recomputation is not algorithmic work) + dx GEMM
+    flops = 10.0 * rows * (T if pack is None else max(1, rows // max(B, 1))) * d + 2.0 * rows * 3 * d * d
+    with _Timed("mhsa_bwd", flops):
+        L.call("dmt_mhsa_block_bwd", C.byref(dd), stream_ptr())
+    if PROFILE is not None:
+        PROFILE.setdefault("mhsa_bwd_bytes", []).append(float(rows * d * 2 * (1 + 3 + 3 + 1) + image_bwd.numel()))
+    return dqkv, dx
+
+
 class MhsaBlockFn(torch.autograd.Function):
     """y = ln(x + MHA(x, x, x)): the encoder's self-attention block (TransformerModel_util.py:160-209 + ln :58-78) as ONE forward
     launch.  Backward: LayerNorm gradient, attention gradient from the saved (Q | K | V), dx = dqkv Wqkv^T + ds, weight gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_leaf, b_leaf, w: Weight, gamma, beta, lens, H, image, drop_seed, drop_keep, eps, pack=None):
+    def forward(ctx, x, w_leaf, b_leaf, w: Weight, gamma, beta, lens, H, image, drop_seed, drop_keep, eps, pack=None, image_bwd=None):
         _chk3(x, "x")
         if not x.is_contiguous():
             x = x.contiguous()
@@ -1368,6 +1404,7 @@ class MhsaBlockFn(torch.autograd.Function):
             ctx.save_for_backward(x, qkv, s, stats, lens)
         ctx.w, ctx.leaves, ctx.gb, ctx.H, ctx.drop = w, (w_leaf, b_leaf), (gamma, beta), H, (int(drop_seed), float(drop_keep))
         ctx.pack = pack
+        ctx.image_bwd = image_bwd
         return y
 
     @staticmethod
@@ -1391,6 +1428,12 @@ class MhsaBlockFn(torch.autograd.Function):
         npart = L.load().dmt_ln_bwd_partials(M)
         partials = torch.empty((npart, 2 * d), dtype=F32, device=x.device)
         ln_bwd(L.DMT_BF16, M, d, s2, d, gamma, stats, dy2, _row_major2d(dy2, "dy"), ds, d, dg, db, partials, direct)
+        if ctx.image_bwd is not None:
+            # ---- attention gradient + dx = dqkv Wqkv^T + ds in one launch (dmt_mhsa_block_bwd); the weight gradient reads the dqkv it wrote
+            dqkv, dx = mhsa_block_bwd(ds.view(B, T, d), qkv, lens, ctx.image_bwd, ctx.H, *ctx.drop, pack=ctx.pack)
+            dz = dqkv.view(M, 3 * d)
+            dW, dbq = linear_backward_weight(x.view(M, d), dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
+            return (dx if ctx.needs_input_grad[0] else None), dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None, None
         # ---- attention gradient
         ds3 = ds.view(B, T, d)
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
@@ -1400,7 +1443,7 @@ class MhsaBlockFn(torch.autograd.Function):
         dz = dqkv.view(M, 3 * d)
         dx = linear_backward_input(dz, ctx.w, resid=ds).view(B, T, d) if ctx.needs_input_grad[0] else None
         dW, dbq = linear_backward_weight(x.view(M, d), dz, want_bias=ctx.leaves[1] is not None, w_leaf=ctx.leaves[0], b_leaf=ctx.leaves[1])
-        return dx, dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None
+        return dx, dW, dbq, None, (None if direct else dg), (None if direct else db), None, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

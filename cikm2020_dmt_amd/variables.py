@@ -278,6 +278,14 @@ class VariableStore:
                 if name.endswith("self-attention/qkv_kernel"):
                     self.mhsa[name[: -len("qkv_kernel")]] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
+        # ... and of its one-launch backward (dmt_mhsa_block_bwd: attention gradient + dx = dqkv Wqkv^T + ds), built only while an engine uses it
+        self.mhsa_bwd: Dict[str, torch.Tensor] = {}
+        self.mhsa_bwd_in_use = False
+        if self.mhsa:
+            nb = ops.mhsa_bwd_image_bytes()
+            for scope in self.mhsa:
+                self.mhsa_bwd[scope] = torch.empty(nb, dtype=torch.uint8, device=dev)
+
     # ------------------------------------------------------------------ values
     def initialize(self, seed: int = 0):
         rng = np.random.default_rng(seed)
@@ -385,6 +393,9 @@ class VariableStore:
         if self.mhsa_in_use:              # (the one-launch self-attention block is optional: DMTEngine.use_mhsa)
             for scope, img in self.mhsa.items():
                 ops.mhsa_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
+            if self.mhsa_bwd_in_use:
+                for scope, img in self.mhsa_bwd.items():
+                    ops.mhsa_bwd_image_build(self.leaf[scope + "qkv_kernel"].detach(), img)
         if getattr(self, "_image_jobs", None) is None:
             jobs = ops.ImageJobs(self.device)
             for name, img in self.proj.items():

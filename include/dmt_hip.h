@@ -45,7 +45,7 @@ extern "C" {
  *   readable -- rebuild with dmt_mhsa_image_build; s_out may be NULL; B * T * 1920 < 2^31).   4  round 4: dmt_mmoe_desc grew (ws, ws_bytes,
  *   gate_dx); dmt_mmoe_experts_ws_bytes added.   5  round 5: PACKED ROWS (below): dmt_gather_desc / dmt_embgrad_desc grew (seq_row_off,
  *   seq_row_len), dmt_attn_desc (row_off, ex_list, n_list), dmt_mhsa_desc (packed-row fields), dmt_q1mem_desc (row_off); dmt_colsum_rows_packed added.
- *   6  round 6: dmt_sort_pairs / dmt_segment_heads are the library's own kernels (vals_in may be NULL; 16-byte aligned workspace; the
+ *   6  round 6: dmt_mhsa_block_bwd + dmt_mhsa_bwd_image_* added; dmt_sort_pairs / dmt_segment_heads are the library's own kernels (vals_in may be NULL; 16-byte aligned workspace; the
  *   workspace sizes changed), dmt_embgrad_keys takes vals == NULL.
  *
  * PACKED ROWS.  A behaviour sequence of a batch may be stored WITHOUT its padding: example b's rows t = 0 .. len[b] - 1 are rows
@@ -628,6 +628,40 @@ typedef struct {
 int dmt_mhsa_image_bytes(int64_t* bytes);
 int dmt_mhsa_image_build(const float* wqkv, int64_t ldw, void* image, void* stream);
 int dmt_mhsa_block_fwd(const dmt_mhsa_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * revision 6.  Backward of the self-attention block in ONE launch (bf16; d_model 320 = 4 heads x 80, T <= 64), from the gradient ds of
+ * the pre-LayerNorm sum (what dmt_ln_bwd hands back for s_out) and the forward's saved qkv:
+ *     dqkv = gradient of concat_h softmax(mask(Q_h K_h^T / sqrt(d_h))) V_h   w.r.t. (Q | K | V)      [rows, 960]
+ *     dx   = dqkv Wqkv^T + ds                                                                         [rows, 320]
+ * Replaces: the gradient TF autodiff builds for multihead_attention(queries == keys == values) up to its three dense layers' inputs
+ *           (TransformerModel_util.py:160-209, 11-56, 80-108): dmt_attn_bwd + the [rows, 960] x [960, 320] dmt_gemm with its residual.
+ *           dWqkv = x^T dqkv stays dmt_wgrad320 (it reads the dqkv written here); dbias = column sums of dqkv.
+ * image: dmt_mhsa_bwd_image_build(Wqkv fp32 [320, 960], ldw) -- dmt_mhsa_bwd_image_bytes() bytes, rebuilt after every optimizer step (private
+ *        layout: 60 stages of 32 dx columns x 160 dqkv columns).
+ * Masks, dropout counter (element index ((b*H + h)*T + q)*T + k) and packed rows (blocks / n_tiles / n_rows: the forward's table) as in
+ * dmt_mhsa_block_fwd.  Rows t >= T of a padded tile do not exist; padded queries of the dense layout (lens[b] <= t < T) get dq = 0 and
+ * reach dv with the reference's constant -2^32 + 1 weights, as in dmt_attn_bwd.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t d_model, num_heads;
+  int32_t B, T;
+  const void* ds;         /* bf16 [rows, d_model]                        */
+  const void* qkv;        /* bf16 [rows, 3 * d_model] (forward side output) */
+  const int32_t* lens;    /* [B]                                         */
+  const void* image;
+  void* dqkv;             /* bf16 [rows, 3 * d_model] out                */
+  void* dx;               /* bf16 [rows, d_model] out                    */
+  uint32_t drop_seed;
+  float drop_keep;
+  const int32_t* blocks;  /* packed rows (NULL: dense), as dmt_mhsa_desc */
+  int32_t n_tiles;
+  int64_t n_rows;
+} dmt_mhsa_bwd_desc;
+
+int dmt_mhsa_bwd_image_bytes(int64_t* bytes);
+int dmt_mhsa_bwd_image_build(const float* wqkv, int64_t ldw, void* image, void* stream);
+int dmt_mhsa_block_bwd(const dmt_mhsa_bwd_desc* d, void* stream);
 
 /* Column sums: out[c] += sum_r x[r*ldx + c]  (fp32 out, atomics across row blocks; out zeroed by caller).
  * Used for the learned-position gradient (TransformerModel_util.py:302-306 lookup by range(T)).       */

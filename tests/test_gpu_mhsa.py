@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from cikm2020_dmt_amd import ops
+from cikm2020_dmt_amd._lib import route_trace as L_route
 from oracle import dmt_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -157,6 +158,77 @@ def test_mhsa_block_backward_matches_the_fp32_statement(cuda, B, T, keep):
     y_ref, _s, _qkv = _ref(xr, ref_leaves[0], ref_leaves[1], ref_leaves[2], ref_leaves[3], lens, H, seed, keep)
     # the padded query rows of the statement hold -2^32-scale values: they are cut out of the graph exactly as the model cuts them (no
     # gradient comes back into them)
+    (y_ref * dy.float()).sum().backward()
+    names = ("dx", "dWqkv", "dbias", "dgamma", "dbeta")
+    got = [xa.grad.float()] + [l.grad.float() for l in leaves]
+    want = [xr.grad] + [l.grad for l in ref_leaves]
+    for nm, a, r in zip(names, got, want):
+        if nm == "dx":
+            a, r = a * live[:, :, None], r * live[:, :, None]
+        assert torch.isfinite(a).all(), nm
+        assert (a - r).abs().max() <= 3e-2 * r.abs().max() + 1e-6, (nm, float((a - r).abs().max()), float(r.abs().max()))
+
+
+def _bwd_inputs(cuda, B, T, seed, ragged=True):
+    H, d = 4, 320
+    x, w, b, gamma, beta, lens = _mk(cuda, B, T, seed=seed)
+    if not ragged:
+        lens[:] = T
+    img = torch.empty(ops.mhsa_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_image_build(w, img)
+    imgb = torch.empty(ops.mhsa_bwd_image_bytes(), dtype=torch.uint8, device=cuda)
+    ops.mhsa_bwd_image_build(w, imgb)
+    g = torch.Generator().manual_seed(seed + 1)
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])
+    ds = torch.randn(B, T, d, generator=g).to(BF).to(cuda) * live[:, :, None]
+    return x, w, b, gamma, beta, lens, img, imgb, ds, live
+
+
+@pytest.mark.parametrize("B,T", [(5, 50), (4, 64), (3, 64), (9, 33), (8, 32), (6, 17), (16, 16), (11, 10), (13, 1), (300, 50)])
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_mhsa_block_bwd_kernel_matches_the_unfused_kernels(cuda, B, T, keep):
+    """dmt_mhsa_block_bwd (attention gradient + dx = dqkv Wqkv^T + ds in one launch) against the two launches it replaces, on the same
+    bf16 inputs: dmt_attn_bwd for dqkv, the [M, 960] x [960, 320] GEMM with its residual for dx.  Same masks, same dropout counter; both
+    round P, dS and dqkv to bf16, so the two agree to a few bf16 roundings of the largest element -- and to nothing worse on any row."""
+    H, d = 4, 320
+    x, w, b, gamma, beta, lens, img, imgb, ds, live = _bwd_inputs(cuda, B, T, seed=B * 10 + T)
+    y, s, stats, qkv = ops.mhsa_block_fwd(x, lens, img, b, gamma, beta, 1e-8, H, 4321, keep)
+    dqkv, dx = ops.mhsa_block_bwd(ds, qkv, lens, imgb, H, 4321, keep)
+    torch.cuda.synchronize()
+    ref = torch.zeros_like(qkv)
+    ops.attn_core_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], lens, lens, None, ds, ref[..., :d], ref[..., d:2 * d], ref[..., 2 * d:], H, 4321, keep)
+    wt = ops.Weight(w, w.to(BF), w.to(BF).t().contiguous())
+    dx_ref = ops.linear_backward_input(ref.view(B * T, 3 * d), wt, resid=ds.view(B * T, d)).view(B, T, d)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(dx.float()).all()
+    for name, lo in (("dq", 0), ("dk", d), ("dv", 2 * d)):
+        a, r = dqkv[..., lo:lo + d].float(), ref[..., lo:lo + d].float()
+        assert (a - r).abs().max() <= 2e-2 * r.abs().max() + 1e-6, (name, float((a - r).abs().max()), float(r.abs().max()))
+    a, r = dx.float() * live[:, :, None], dx_ref.float() * live[:, :, None]
+    assert (a - r).abs().max() <= 2e-2 * r.abs().max() + 1e-6, ("dx", float((a - r).abs().max()), float(r.abs().max()))
+
+
+@pytest.mark.parametrize("B,T", [(5, 50), (3, 64), (9, 33), (7, 32), (6, 17), (11, 10), (64, 50)])
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_mhsa_block_with_the_fused_backward_matches_the_fp32_statement(cuda, B, T, keep):
+    """MhsaBlockFn with image_bwd (LayerNorm gradient -> dmt_mhsa_block_bwd -> weight gradient): every gradient against autograd through the
+    plain PyTorch fp32 statement, as test_mhsa_block_backward_matches_the_fp32_statement does for the four-launch backward."""
+    H, d = 4, 320
+    x, w, b, gamma, beta, lens, img, imgb, _ds, live = _bwd_inputs(cuda, B, T, seed=B * 100 + T + 1)
+    wt = ops.Weight(w, w.to(BF), w.to(BF).t().contiguous())
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(B, T, d, generator=g).to(BF).to(cuda) * live[:, :, None]
+    seed = 4242
+    leaves = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+    xa = x.clone().requires_grad_(True)
+    with L_route() as rt:
+        y = ops.MhsaBlockFn.apply(xa, leaves[0], leaves[1], wt, leaves[2], leaves[3], lens, H, img, seed, keep, 1e-8, None, imgb)
+        y.backward(dy)
+    torch.cuda.synchronize()
+    assert rt.counts.get("dmt_mhsa_block_bwd", 0) == 1 and not any(k.startswith("dmt_attn_bwd") for k in rt.counts)
+    ref_leaves = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+    xr = x.float().clone().requires_grad_(True)
+    y_ref, _s, _qkv = _ref(xr, ref_leaves[0], ref_leaves[1], ref_leaves[2], ref_leaves[3], lens, H, seed, keep)
     (y_ref * dy.float()).sum().backward()
     names = ("dx", "dWqkv", "dbias", "dgamma", "dbeta")
     got = [xa.grad.float()] + [l.grad.float() for l in leaves]

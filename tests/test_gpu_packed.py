@@ -175,3 +175,41 @@ def test_packed_position_gradient_kernel_against_torch(cuda):
                    ops.stream_ptr())
             torch.cuda.synchronize()
             assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed,B,dropout", [(False, 40, True), (True, 40, True), (True, 700, True), (False, 300, False)])
+def test_fused_self_attention_backward_in_the_engine(cuda, monkeypatch, packed, B, dropout):
+    """DMTEngine.use_mhsa_bwd (DMT_FUSED_MHSA_BWD=1): the block's backward as LayerNorm gradient -> dmt_mhsa_block_bwd -> weight gradient,
+    in the dense layout and on packed rows (all three padded lengths 16 / 32 / 64 occur in a ragged batch), against the four-launch
+    backward of the same engine settings: same loss (the forward is the same), every gradient to the bf16 rounding of dS / dqkv."""
+    monkeypatch.setattr(ops, "WGRAD320_MIN_ROWS", 1024)
+    sp = S.scaled_spec(S.e64_spec(), E64_ROWS)
+    P = _params(dict(sp))
+    inputs, mask, label = make_batch(sp, B, seed=19, lengths="ragged", weights="random")
+    res = []
+    for fused in (False, True):
+        tr = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, init=False, dropout=dropout, dropout_seed=77, packed_rows=packed)
+        tr.engine.use_mhsa_bwd = fused
+        tr.store.load_state(P)
+        batch = tr.make_batch(inputs, mask, label)
+        with L.route_trace() as rt:
+            loss = float(tr.forward_backward(batch))
+            torch.cuda.synchronize()
+        g = dict(tr.store.grad_dict())
+        g.update(sparse_to_dense_tables(tr.store, tr.engine.sparse))
+        res.append((loss, g, dict(rt.counts)))
+        tr.close()
+    (l0, g0, r0), (l1, g1, r1) = res
+    key = "dmt_mhsa_block_bwd(packed)" if packed else "dmt_mhsa_block_bwd"
+    assert r1.get(key, 0) == 3 and r0.get(key, 0) == 0
+    assert not any(k.startswith("dmt_attn_bwd(mfma") for k in r1)          # (the decoders' one-query attention has its own routes)
+    assert l0 == l1
+    gscale = max(np.abs(v).max() for v in g0.values())
+    worst = []
+    for name, ref in g0.items():
+        e = float(np.linalg.norm(g1[name] - ref) / max(np.linalg.norm(ref), 1e-3 * gscale * np.sqrt(ref.size)))
+        worst.append((e, name))
+    worst.sort(reverse=True)
+    print("fused vs four-launch backward (packed %s, B %d): worst relative gradient distances:" % (packed, B), worst[:4])
+    assert worst[0][0] < 2e-2, worst[:6]
