@@ -219,6 +219,7 @@ def main():
         "attn_long": "attn_long_fwd/bwd_kernel + attn_q1_long_kernel (dmt_attn_long.hip): flash-style attention core, 64 < T <= 256",
         "attn": "attn_fwd/bwd_co_kernel + attn_q1v_kernel (dmt_attn.hip): attention core, T <= 64",
         "mhsa_block": "mhsa_fwd_kernel (dmt_mhsa.hip): fused self-attention block",
+        "mhsa_bwd": "mhsa_bwd_kernel (dmt_mhsa_bwd.hip): the block's backward in one launch, attention gradient + dx GEMM (opt-in: DMT_FUSED_MHSA_BWD=1)",
         "q1mem": "q1m_fwd/bwd_kernel (dmt_q1mem.hip): decoder cross attention over the raw memory rows (HBM-bound: memory rows read once, d mem written once)",
         "mmoe_experts": "mmoe_experts_fwd/bwd_kernel (dmt_mmoe.hip): expert layers 1-2 + gates + mixtures",
     }

@@ -324,10 +324,10 @@ extern "C" int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const
   const SortPlan p = sort_plan(n, end_bit);
   if (ws == nullptr) { *ws_bytes = p.total; return DMT_OK; }
   DMT_CHECK_ARG(*ws_bytes >= p.total, "dmt_sort_pairs: workspace too small (%llu < %llu)", (unsigned long long)*ws_bytes, (unsigned long long)p.total);
+  if (n == 0) return DMT_OK;
   DMT_CHECK_ARG(keys_in && keys_out && vals_out, "dmt_sort_pairs: null argument");
   DMT_CHECK_ARG((((uintptr_t)ws) & 15) == 0, "dmt_sort_pairs: workspace must be 16-byte aligned");
   DMT_CHECK_ARG(keys_in != keys_out && vals_in != vals_out, "dmt_sort_pairs: outputs must not alias the inputs");
-  if (n == 0) return DMT_OK;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* w8 = (unsigned char*)ws;
   uint32_t* tk = (uint32_t*)(w8 + p.tmp_keys);

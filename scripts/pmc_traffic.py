@@ -18,6 +18,7 @@ FAMILIES = {
     "embgrad_reduce": ["embgrad_reduce_kernel"],
     "adam_sparse": ["adam_sparse_kernel"],
     "mhsa_block": ["mhsa_fwd_kernel"],
+    "mhsa_bwd": ["mhsa_bwd_kernel"],
     "gemm_small": ["gemm_small_kernel"],
     "adam_catchup": ["adam_catchup_kernel"],
     "ln": ["ln_fwd", "ln_bwd"],
