@@ -79,6 +79,7 @@ extern "C" int dmt_struct_size(int which) {
     case 11: return (int)sizeof(dmt_mmoe_desc);
     case 12: return (int)sizeof(dmt_heads_desc);
     case 13: return (int)sizeof(dmt_q1mem_desc);
+    case 14: return (int)sizeof(dmt_mhsa_bwd_desc);
     default: return -1;
   }
 }

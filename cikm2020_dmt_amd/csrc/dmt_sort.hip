@@ -8,9 +8,10 @@
 // One pass = three launches, all sized by the tile count (a tile = 4096 consecutive entries = one workgroup of 256 threads):
 //   rs_hist_kernel     counts[tile][256]: digit histogram of the tile (per-wavefront LDS counters fed by ballot matches: one LDS add
 //                      per distinct digit of a 64-entry round, no same-address atomics -- Zipf ids make every round a pile-up);
-//   rs_scan_kernel     ONE workgroup: the tiles are cut into <= 32 chunks; chunk_base[chunk][digit] = entries with a smaller digit +
-//                      entries of this digit in earlier chunks (chunk sums in LDS, a 256-wide scan over the digit totals);
-//   rs_scatter_kernel  a tile adds the counts of its chunk's earlier tiles to its chunk's base (<= chunk - 1 coalesced 1 KB reads),
+//                      the tile's totals are also added (integer atomics) to those of its CHUNK: the tiles are cut into <= 128 chunks;
+//   rs_scan_kernel     ONE workgroup over the <= 128 x 256 chunk totals: per chunk and digit the entries of this digit in earlier chunks,
+//                      per digit the entries with a smaller digit (a 256-wide scan); it leaves the chunk totals zeroed for the next pass;
+//   rs_scatter_kernel  a tile adds the counts of its chunk's earlier tiles (<= chunk - 1 coalesced 1 KB reads: <= 9 at 5 M entries),
 //                      ranks its entries -- wavefront w owns entries [1024 w, 1024 w + 1024) of the tile, 16 rounds of 64; the rank
 //                      inside the tile is (entries of the digit in earlier wavefronts) + (in earlier rounds of this wavefront) +
 //                      (in lower lanes of this round): stable by construction --, reorders keys and values by digit through LDS and
@@ -21,7 +22,7 @@
 
 namespace {
 
-constexpr int RS_NT = 256, RS_KPT = 16, RS_TILE = RS_NT * RS_KPT, RS_RADIX = 256, RS_MAXCHUNK = 32;
+constexpr int RS_NT = 256, RS_KPT = 16, RS_TILE = RS_NT * RS_KPT, RS_RADIX = 256, RS_MAXCHUNK = 128;
 constexpr int RS_WAVES = RS_NT / 64, RS_SUB = RS_TILE / RS_WAVES;       // entries per wavefront
 
 // lanes of the wavefront (among `valid` ones) whose 8-bit digit equals this lane's
@@ -37,19 +38,24 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
 }
 
 __global__ __launch_bounds__(RS_NT) void rs_hist_kernel(const uint32_t* __restrict__ keys, long long n, int shift, uint32_t mask,
-                                                        int* __restrict__ counts) {
+                                                        int* __restrict__ counts, int* __restrict__ csum, int chunk) {
   __shared__ int wcnt[RS_WAVES][RS_RADIX];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_NT) (&wcnt[0][0])[i] = 0;
-  __syncthreads();
   const long long base = (long long)blockIdx.x * RS_TILE + (long long)w * RS_SUB;
+  uint32_t key[RS_KPT];
+#pragma unroll
+  for (int r = 0; r < RS_KPT; ++r) {                  // every request of the tile up front: ONE exposed round trip per workgroup
+    const long long e = base + r * 64 + lane;
+    key[r] = e < n ? keys[e] : 0u;
+  }
+  __syncthreads();
   volatile int* wc = wcnt[w];
   const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll 4
+#pragma unroll
   for (int r = 0; r < RS_KPT; ++r) {
-    const long long e = base + r * 64 + lane;
-    const bool valid = e < n;
-    const unsigned d = valid ? ((keys[e] >> shift) & mask) : 0u;
+    const bool valid = base + r * 64 + lane < n;
+    const unsigned d = valid ? ((key[r] >> shift) & mask) : 0u;
     const unsigned long long m = rs_match(d, valid);
     if (valid && (m & lt) == 0ull) wc[d] = wc[d] + (int)__popcll(m);      // the lowest lane of every distinct digit: distinct addresses
   }
@@ -58,48 +64,52 @@ __global__ __launch_bounds__(RS_NT) void rs_hist_kernel(const uint32_t* __restri
 #pragma unroll
   for (int k = 0; k < RS_WAVES; ++k) s += wcnt[k][tid];
   counts[(long long)blockIdx.x * RS_RADIX + tid] = s;
+  if (s != 0) atomicAdd(csum + ((int)blockIdx.x / chunk) * RS_RADIX + tid, s);      // the chunk's digit totals (integer sums: any order, one result)
 }
 
-// One workgroup of 1024 threads: thread (d = tid & 255, q = tid >> 8) sums the counts of digit d over the chunks c = q, q + 4, ...
-__global__ __launch_bounds__(1024) void rs_scan_kernel(const int* __restrict__ counts, int ntiles, int chunk, int nchunks,
-                                                       int* __restrict__ chunk_base) {
-  __shared__ int cs[RS_MAXCHUNK][RS_RADIX];
+// One workgroup of 1024 threads over the chunk totals csum[chunk][256] (<= 128 chunks): thread (d = tid & 255, q = tid >> 8) owns the chunks of
+// quarter q of digit d.  Out: cexcl[chunk][d] = entries of digit d in earlier chunks, dbase[d] = entries with a smaller digit; csum is left
+// zeroed for the next pass.
+__global__ __launch_bounds__(1024) void rs_scan_kernel(int* __restrict__ csum, int nchunks, int* __restrict__ cexcl, int* __restrict__ dbase) {
+  __shared__ int qsum[4][RS_RADIX];
   __shared__ int tot[RS_RADIX];
   const int tid = threadIdx.x, d = tid & 255, q = tid >> 8;
-  for (int c = q; c < nchunks; c += 4) {
-    const int t0 = c * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
-    int s = 0;
-#pragma unroll 8
-    for (int t = t0; t < t1; ++t) s += counts[(long long)t * RS_RADIX + d];
-    cs[c][d] = s;
-  }
+  const int per = (nchunks + 3) / 4;
+  const int c0 = q * per, c1 = (c0 + per < nchunks) ? c0 + per : nchunks;
+  int v[RS_MAXCHUNK / 4];
+#pragma unroll
+  for (int i = 0; i < RS_MAXCHUNK / 4; ++i) v[i] = (c0 + i < c1) ? csum[(c0 + i) * RS_RADIX + d] : 0;      // (independent requests: one round trip)
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < RS_MAXCHUNK / 4; ++i) s += v[i];
+  qsum[q][d] = s;
   __syncthreads();
-  if (tid < RS_RADIX) {
-    int run = 0;
-    for (int c = 0; c < nchunks; ++c) { const int v = cs[c][d]; cs[c][d] = run; run += v; }
-    tot[d] = run;
-  }
+  int run = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) run += (k < q) ? qsum[k][d] : 0;
+  if (q == 0) tot[d] = qsum[0][d] + qsum[1][d] + qsum[2][d] + qsum[3][d];
+#pragma unroll
+  for (int i = 0; i < RS_MAXCHUNK / 4; ++i)
+    if (c0 + i < c1) { cexcl[(c0 + i) * RS_RADIX + d] = run; run += v[i]; csum[(c0 + i) * RS_RADIX + d] = 0; }
   __syncthreads();
   // exclusive scan of the 256 digit totals (Hillis-Steele over LDS: 8 steps)
-  int v = tid < RS_RADIX ? tot[tid] : 0;
-  const int mine = v;
+  int t = tid < RS_RADIX ? tot[tid] : 0;
+  const int mine = t;
   for (int off = 1; off < RS_RADIX; off <<= 1) {
     int add = 0;
     if (tid < RS_RADIX && tid >= off) add = tot[tid - off];
     __syncthreads();
-    if (tid < RS_RADIX) { v += add; tot[tid] = v; }
+    if (tid < RS_RADIX) { t += add; tot[tid] = t; }
     __syncthreads();
   }
-  if (tid < RS_RADIX) tot[tid] = v - mine;
-  __syncthreads();
-  for (int c = q; c < nchunks; c += 4) chunk_base[c * RS_RADIX + d] = tot[d] + cs[c][d];
+  if (tid < RS_RADIX) dbase[tid] = t - mine;
 }
 
 template <bool IOTA>
 __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long long n,
                                                            int shift, uint32_t mask, const int* __restrict__ counts,
-                                                           const int* __restrict__ chunk_base, int chunk) {
+                                                           const int* __restrict__ cexcl, const int* __restrict__ dbase, int chunk) {
   __shared__ uint32_t sk[RS_TILE];
   __shared__ uint32_t sv[RS_TILE];
   __shared__ int wcnt[RS_WAVES][RS_RADIX];
@@ -112,7 +122,8 @@ __global__ __launch_bounds__(RS_NT) void rs_scatter_kernel(const uint32_t* __res
   {
     // global offset of digit `tid`: the chunk's base + this digit's entries in the chunk's earlier tiles
     const int c = tile / chunk;
-    int off = chunk_base[c * RS_RADIX + tid];
+    int off = dbase[tid] + cexcl[c * RS_RADIX + tid];
+#pragma unroll 8
     for (int t = c * chunk; t < tile; ++t) off += counts[(long long)t * RS_RADIX + tid];
     goff[tid] = off;
   }
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(RS_NT) void sh_write_kernel(const uint32_t* __restr
   }
 }
 
-struct SortPlan { int ntiles, chunk, nchunks, npass; size_t tmp_keys, tmp_vals, counts, cbase, total; };
+struct SortPlan { int ntiles, chunk, nchunks, npass; size_t tmp_keys, tmp_vals, counts, csum, cexcl, dbase, total; };
 static SortPlan sort_plan(int64_t n, int end_bit) {
   SortPlan p;
   p.ntiles = (int)cdiv64(n > 0 ? n : 1, RS_TILE);
@@ -307,9 +318,15 @@ static SortPlan sort_plan(int64_t n, int end_bit) {
   p.tmp_keys = 0;
   p.tmp_vals = p.tmp_keys + (p.npass > 1 ? al((size_t)n * 4) : 0);
   p.counts = p.tmp_vals + (p.npass > 1 ? al((size_t)n * 4) : 0);
-  p.cbase = p.counts + al((size_t)p.ntiles * RS_RADIX * 4);
-  p.total = p.cbase + al((size_t)RS_MAXCHUNK * RS_RADIX * 4);
+  p.csum = p.counts + al((size_t)p.ntiles * RS_RADIX * 4);
+  p.cexcl = p.csum + al((size_t)RS_MAXCHUNK * RS_RADIX * 4);
+  p.dbase = p.cexcl + al((size_t)RS_MAXCHUNK * RS_RADIX * 4);
+  p.total = p.dbase + al((size_t)RS_RADIX * 4);
   return p;
+}
+
+__global__ __launch_bounds__(256) void rs_zero_kernel(int* __restrict__ x, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) x[i] = 0;
 }
 
 }  // namespace
@@ -333,9 +350,12 @@ extern "C" int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const
   uint32_t* tk = (uint32_t*)(w8 + p.tmp_keys);
   uint32_t* tv = (uint32_t*)(w8 + p.tmp_vals);
   int* counts = (int*)(w8 + p.counts);
-  int* cbase = (int*)(w8 + p.cbase);
+  int* csum = (int*)(w8 + p.csum);
+  int* cexcl = (int*)(w8 + p.cexcl);
+  int* dbase = (int*)(w8 + p.dbase);
   const uint32_t* ki = keys_in;
   const uint32_t* vi = vals_in;
+  hipLaunchKernelGGL(rs_zero_kernel, dim3(32), dim3(256), 0, st, csum, p.nchunks * RS_RADIX);     // (every pass's scan leaves it zeroed for the next)
   for (int ps = 0; ps < p.npass; ++ps) {
     // the last pass lands in the caller's buffers; the ones before it alternate so that it does
     const bool to_out = ((p.npass - 1 - ps) & 1) == 0;
@@ -344,12 +364,12 @@ extern "C" int dmt_sort_pairs(const uint32_t* keys_in, uint32_t* keys_out, const
     const int shift = 8 * ps;
     const int bits = end_bit - shift < 8 ? end_bit - shift : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(p.ntiles), dim3(RS_NT), 0, st, ki, (long long)n, shift, mask, counts);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, counts, p.ntiles, p.chunk, p.nchunks, cbase);
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(p.ntiles), dim3(RS_NT), 0, st, ki, (long long)n, shift, mask, counts, csum, p.chunk);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, st, csum, p.nchunks, cexcl, dbase);
     if (vi == nullptr)
-      hipLaunchKernelGGL((rs_scatter_kernel<true>), dim3(p.ntiles), dim3(RS_NT), 0, st, ki, vi, ko, vo, (long long)n, shift, mask, counts, cbase, p.chunk);
+      hipLaunchKernelGGL((rs_scatter_kernel<true>), dim3(p.ntiles), dim3(RS_NT), 0, st, ki, vi, ko, vo, (long long)n, shift, mask, (const int*)counts, (const int*)cexcl, (const int*)dbase, p.chunk);
     else
-      hipLaunchKernelGGL((rs_scatter_kernel<false>), dim3(p.ntiles), dim3(RS_NT), 0, st, ki, vi, ko, vo, (long long)n, shift, mask, counts, cbase, p.chunk);
+      hipLaunchKernelGGL((rs_scatter_kernel<false>), dim3(p.ntiles), dim3(RS_NT), 0, st, ki, vi, ko, vo, (long long)n, shift, mask, (const int*)counts, (const int*)cexcl, (const int*)dbase, p.chunk);
     ki = ko;
     vi = vo;
   }

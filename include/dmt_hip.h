@@ -60,7 +60,8 @@ int dmt_version(void);
 /* gfx arch string the device code was built for ("gfx950"). */
 const char* dmt_build_arch(void);
 /* sizeof() of the ABI structs: 0 gather_feature, 1 gather_desc, 2 embgrad_desc, 3 gemm_desc, 4 attn_desc,
- * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc, 10 mhsa_desc (lets a binding verify its struct layout). */
+ * 5 attn_bwd_desc, 6 table_map, 7 cast_job, 8 chain_desc, 9 wgrad_desc, 10 mhsa_desc, 11 mmoe_desc, 12 heads_desc, 13 q1mem_desc,
+ * 14 mhsa_bwd_desc (lets a binding verify its struct layout). */
 int dmt_struct_size(int which);
 /* Launch-route trace (diagnostic, off by default).  dmt_route_trace(1) clears the counters and starts counting every successful launch
  * under its route label (the name of the kernel variant an entry point dispatched to, e.g. "dmt_attn_fwd(mfma, coalesced)",

@@ -29,7 +29,7 @@ def test_ctypes_struct_layouts_match_the_header():
     lib.dmt_struct_size.restype = C.c_int
     lib.dmt_struct_size.argtypes = [C.c_int]
     for i, st in enumerate([L.GatherFeature, L.GatherDesc, L.EmbGradDesc, L.GemmDesc, L.AttnDesc, L.AttnBwdDesc, L.TableMap, L.CastJob,
-                            L.ChainDesc, L.WgradDesc, L.MhsaDesc, L.MmoeDesc, L.HeadsDesc, L.Q1memDesc]):
+                            L.ChainDesc, L.WgradDesc, L.MhsaDesc, L.MmoeDesc, L.HeadsDesc, L.Q1memDesc, L.MhsaBwdDesc]):
         assert C.sizeof(st) == lib.dmt_struct_size(i), st.__name__
     assert C.sizeof(L.EmbGradDesc) < 4096 and C.sizeof(L.GatherDesc) < 4096   # passed by value as kernel arguments
 
