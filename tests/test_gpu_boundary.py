@@ -416,3 +416,32 @@ def test_a_step_that_raises_after_its_early_begin_is_rolled_back(cuda):
     assert a[4] == b[4] == 5
     for x, y in zip(a[:4], b[:4]):
         assert torch.equal(x, y)
+
+
+def test_trainer_close_releases_the_last_steps_activations(cuda):
+    """An engine's `intermediates` hold graph-attached tensors whose autograd nodes point back at the engine: a cycle through C++ graph edges
+    that Python's collector cannot see.  Trainer.close() breaks it -- after close + del the device memory of a Trainer that ran a forward /
+    backward pass is back (without close() the pass's activations stay allocated: the AUC tests of tests/test_gpu_configs.py ran the device
+    out of memory that way)."""
+    import gc
+    from cikm2020_dmt_amd import spec as S
+    sp = S.scaled_spec(S.e64_spec(), {"Sku": 20000, "Brand": 3000, "Shopid": 3000, "Cid3": 1200})
+    inputs, mask, label = make_batch(sp, 1024, seed=3, lengths="full")
+    gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(cuda)
+    held = []
+    for closed in (False, True):
+        tr = Trainer(sp, device=cuda, compute_dtype=torch.bfloat16, seed=1, dropout=True)
+        b = tr.make_batch(inputs, mask, label)
+        float(tr.forward_backward(b))
+        (c, o), yb = tr.engine.inference(b)              # (a forward pass whose graph nobody walks: what an evaluation loop leaves behind)
+        del c, o, yb, b
+        if closed:
+            tr.close()
+        del tr
+        gc.collect(); torch.cuda.synchronize()
+        held.append(torch.cuda.memory_allocated(cuda) - base)
+        base = torch.cuda.memory_allocated(cuda)
+    print("device bytes still allocated after dropping a Trainer: without close() %.1f MB, with close() %.1f MB" % (held[0] / 1e6, held[1] / 1e6))
+    assert held[1] < 8e6                                    # (the lane streams' probe buffers and the like: a few MB, once)
+    assert held[0] > 20 * max(held[1], 1e6) or held[0] < 8e6      # the leak this guards against (absent only if torch ever learns to collect it)
