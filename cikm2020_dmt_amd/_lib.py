@@ -231,6 +231,13 @@ def load():
         raise RuntimeError(
             "libdmt_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C cikm2020_dmt_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # torch FIRST: its wheel carries its own libamdhip64.  Loaded after torch, this library's HIP dependency resolves to that copy (one
+    # runtime in the process); loaded BEFORE torch it pulls in /opt/rocm's copy, torch then brings its own, and this library's launches
+    # go to a runtime that holds none of torch's state ("no ROCm-capable device is detected" -- seen with build() and smoke() in one process)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)
