@@ -93,3 +93,28 @@ def test_no_vendor_sort_symbols_in_the_library():
     so = os.path.join(os.path.dirname(L.__file__), "csrc", "libdmt_hip.so")
     out = subprocess.run(["strings", so], capture_output=True, text=True).stdout
     assert "rocprim" not in out
+
+
+def test_sort_soak_against_torch_stable_sort(cuda):
+    """300 sorts of fresh data at the step's size class (0.5 - 6 M pairs, Zipf and uniform keys, 20 - 27 key bits) against torch's stable sort on the
+    device: the ranking's LDS read-then-write ordering inside a wavefront and the integer atomics of the chunk totals must hold every time."""
+    g = torch.Generator(device=cuda).manual_seed(7)
+    need = C.c_uint64(0)
+    for it in range(300):
+        n = int(torch.randint(500_000, 6_000_000, (1,), generator=g, device=cuda).item()) if it % 3 else int(torch.randint(1, 70_000, (1,), generator=g, device=cuda).item())
+        bits = 20 + it % 8
+        if it % 2:
+            u = torch.rand(n, generator=g, device=cuda)
+            keys = ((1.0 / (u + 1e-7)) ** 1.2).clamp_(max=2.0 ** 30).to(torch.int64).clamp_(max=(1 << bits) - 1)      # heavy head: most keys on a few rows
+        else:
+            keys = torch.randint(0, 1 << bits, (n,), generator=g, device=cuda, dtype=torch.int64)
+        k32 = keys.to(torch.int32)
+        ks, vs = torch.empty_like(k32), torch.empty_like(k32)
+        L.call("dmt_sort_pairs", ops.p(k32), ops.p(ks), None, ops.p(vs), n, bits, None, C.byref(need), ops.stream_ptr())
+        ws = torch.empty((max(int(need.value), 16),), dtype=torch.uint8, device=cuda)
+        ws.random_(0, 255)                                   # (the workspace arrives dirty: nothing may depend on its content)
+        have = C.c_uint64(ws.numel())
+        L.call("dmt_sort_pairs", ops.p(k32), ops.p(ks), None, ops.p(vs), n, bits, ops.p(ws), C.byref(have), ops.stream_ptr())
+        want_k, want_i = torch.sort(keys, stable=True)
+        assert torch.equal(ks.to(torch.int64), want_k), (it, n, bits)
+        assert torch.equal(vs.to(torch.int64), want_i), (it, n, bits)
