@@ -461,6 +461,7 @@ class DMTEngine:
         self.use_mhsa = os.environ.get("DMT_FUSED_MHSA", "1") == "1"
         # the block's backward as ONE launch behind the LayerNorm gradient (dmt_mhsa_block_bwd) instead of dmt_attn_bwd + the dx GEMM.  Off by
         # default: measured 1.4x SLOWER than the two launches it replaces; DMT_FUSED_MHSA_BWD=1 selects it.
+        self._use_mhsa_bwd = False
         self.use_mhsa_bwd = os.environ.get("DMT_FUSED_MHSA_BWD", "0") == "1"
         self.defer_sparse, self._pending_sparse = False, None     # GatherFn.backward leaves its work to finish_sparse_backward()
         self.seq_streams = os.environ.get("DMT_SEQ_STREAMS", "1") != "0"        # side streams for the behaviour sequences
@@ -485,6 +486,20 @@ class DMTEngine:
         self._use_mhsa = bool(on)
         if self._use_mhsa and not self.store.mhsa_in_use:
             self.store.mhsa_in_use = True
+            self.store.refresh_shadows()
+
+    @property
+    def use_mhsa_bwd(self):
+        return self._use_mhsa_bwd
+
+    @use_mhsa_bwd.setter
+    def use_mhsa_bwd(self, on):
+        """As use_mhsa: the store builds (and from then on rebuilds) the backward's weight images while an engine uses them -- here, on the
+        caller's stream and before any sequence lane runs, not lazily from inside a lane (a lane would build all three images on ITS stream
+        while the other lanes read theirs)."""
+        self._use_mhsa_bwd = bool(on)
+        if self._use_mhsa_bwd and self.store.mhsa_bwd and not self.store.mhsa_bwd_in_use:
+            self.store.mhsa_bwd_in_use = True
             self.store.refresh_shadows()
 
     def gather_bytes(self, batch, seq_T) -> float:
@@ -695,11 +710,7 @@ class DMTEngine:
         if pack is not None or (img is not None and self.use_mhsa and ops.mhsa_supported(d, H, x.shape[1], x.shape[0])):
             seed, keep = self._attn_drop(stream)
             img_b = None
-            if self.use_mhsa_bwd and img is not None:
-                if not self.store.mhsa_bwd_in_use:             # (first use: build the images now; from here on every refresh rebuilds them)
-                    self.store.mhsa_bwd_in_use = True
-                    for scope, im in self.store.mhsa_bwd.items():
-                        ops.mhsa_bwd_image_build(self.store.leaf[scope + "qkv_kernel"].detach(), im)
+            if self.use_mhsa_bwd and img is not None and self.store.mhsa_bwd_in_use:
                 img_b = self.store.mhsa_bwd.get(a)
             return ops.MhsaBlockFn.apply(x, self._lf(a + "qkv_kernel"), self._lf(a + "qkv_bias"), self._w(a + "qkv_kernel"),
                                          self._lf(a + "ln/gamma"), self._lf(a + "ln/beta"), lens, H, img, seed, keep, 1e-8, pack, img_b)
